@@ -1,0 +1,123 @@
+/* sfm_hip.h — C ABI of libsfm_hip.so: MI355X (gfx950) kernels for the RANSAC essential-matrix,
+ * cheirality and triangulation hot path of Bazs/structure_from_motion.
+ *
+ * The reference has no FFI for this path (it is pure Python); each entry point below replaces the
+ * Python inner loop cited next to it (paths relative to the reference repo).  A maintainer binds them
+ * with ctypes as shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer marked "dev" is device memory (hipMalloc / a torch ROCm tensor's data_ptr());
+ *     "host" pointers are ordinary process memory.  All arrays are dense, row-major, float64 unless
+ *     another element type is given.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls only enqueue work;
+ *     nothing synchronises with the host.
+ *   - a leading `batch` dimension runs independent image pairs (blockIdx.y); batch == 1 for one pair.
+ *   - return value: 0 on success, a negative SFM_E* code otherwise; sfm_last_error() returns a
+ *     thread-local message for the last failure.
+ */
+#ifndef SFM_HIP_H
+#define SFM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SFM_OK 0
+#define SFM_EINVAL (-1) /* bad argument (null pointer, negative size, n < 8, ...) */
+#define SFM_EHIP (-2)   /* a HIP runtime call failed (message has the hipError string) */
+
+/* error aggregation of reference lib/ransac/ransac.py:12-16 */
+#define SFM_AGG_SUM 0
+#define SFM_AGG_SQUARE 1
+#define SFM_AGG_MEAN 2
+#define SFM_AGG_RMS 3
+
+/* per-hypothesis fit flags written by sfm_fit_eight_point */
+#define SFM_FIT_DEGENERATE 1 /* eight_point.py:415-421 predicate: second-smallest eigenvalue <= 1e-10 */
+
+/* Result record of sfm_select_best (one per batch entry, device memory, 40 bytes). */
+typedef struct sfm_select_result {
+    uint64_t key;          /* IEEE bits of best_err (monotone for err >= 0); INT64_MAX (0x7FFF...F) if no model */
+    int64_t best_h;        /* global hypothesis index (h_offset + local), -1 if no model */
+    double best_err;       /* aggregated inlier error of the winner (ransac.py:80-82), +inf if none */
+    int64_t first_flagged; /* lowest global index with a fit flag set, INT64_MAX if none */
+    int32_t n_flagged;     /* number of flagged hypotheses */
+    int32_t best_cnt;      /* extra-inlier count of the winner */
+} sfm_select_result;
+
+const char* sfm_last_error(void);
+int sfm_abi_version(void);
+
+/* K-normalise matched pixel coordinates (eight_point.py:127-133, hoisted out of the H x N loop):
+ * corr[i] = [(xa-cx)/fx, (ya-cy)/fy, (xb-cx)/fx, (yb-cy)/fy].
+ * pix_a, pix_b: dev [count,2]; corr: dev [count,4]. */
+int sfm_normalize_correspondences(const double* pix_a, const double* pix_b, int64_t count, double fx,
+                                  double fy, double cx, double cy, double* corr, void* stream);
+
+/* Counter-based hypothesis sampler (replaces the sequential random.shuffle of ransac.py:62-63 for
+ * large H): S[b,h,:] = 8 distinct indices in [0,n) from Philox(seed + b*seed_stride, h_begin + h).
+ * S: dev int32 [batch,h_count,8]. */
+int sfm_sample_philox(uint64_t seed, uint64_t seed_stride, int64_t h_begin, int64_t h_count, int64_t n,
+                      int64_t batch, int32_t* S, void* stream);
+
+/* Normalised eight-point fit of every hypothesis (epipolar_ransac.py:28-42 -> eight_point.py:136-170).
+ * corr: dev [batch,n,4]; S: dev int32 [batch,h_count,8]; E: dev [batch,h_count,9] (row-major 3x3,
+ * E[8] == 1); flags: dev int32 [batch,h_count]; lambda2: optional dev [batch,h_count] receiving the
+ * second-smallest eigenvalue of Y^T Y (NULL to skip). */
+int sfm_fit_eight_point(const double* corr, int64_t n, const int32_t* S, int64_t h_count, int64_t batch,
+                        double* E, int32_t* flags, double* lambda2, void* stream);
+
+/* Symmetric-epipolar-distance scoring of all n correspondences under all hypotheses
+ * (ransac.py:66-82 with epipolar_ransac.py:18-25 / sed.py:7-30 as the scorer).
+ * cnt[b,h] = #non-sample points with sed <= thr; s1 / s2 = sum of sed / sed^2 over the 8 sample points
+ * plus those survivors.  cnt: dev int32 [batch,h_count]; s1, s2: dev [batch,h_count]. */
+int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t* S, int64_t h_count,
+                  int64_t batch, double thr, int32_t* cnt, double* s1, double* s2, void* stream);
+
+/* Model selection (ransac.py:75-86): lowest aggregated error among hypotheses with
+ * cnt >= min_extra, strict <, earliest index wins, NaN/inf never win.  result: dev [batch]. */
+int sfm_select_best(const int32_t* cnt, const double* s1, const double* s2, const int32_t* flags,
+                    int64_t h_count, int64_t batch, double min_extra, int aggregation, int64_t h_offset,
+                    sfm_select_result* result, void* stream);
+
+/* Inlier mask of the selected model: mask[b,i] = 1 if point i is a non-sample survivor, 2 if it is one of
+ * the 8 sample points, 0 otherwise.  `result` as written by sfm_select_best with h_offset 0 (or with
+ * best_h rewritten to a local index); entries with best_h < 0 leave their mask zeroed.
+ * mask: dev uint8 [batch,n]. */
+int sfm_inlier_mask(const double* corr, int64_t n, const double* E, const int32_t* S, int64_t h_count,
+                    int64_t batch, const sfm_select_result* result, double thr, uint8_t* mask,
+                    void* stream);
+
+/* SED of n correspondences under one E (sed.py:7-30).  E: dev [9]; out: dev [n]. */
+int sfm_sed_values(const double* corr, int64_t n, const double* E, double* out, void* stream);
+
+/* Cheirality test of m normalised correspondences under `poses` candidate poses
+ * (eight_point.py:449-488).  pose_rt: dev [poses,12] rows [R(9) | t(3)]; pass: dev uint8 [poses,m]. */
+int sfm_cheirality(const double* corr, int64_t m, const double* pose_rt, int64_t poses,
+                   double distance_threshold, uint8_t* pass, void* stream);
+
+/* Linear (DLT) triangulation of m correspondences (triangulation.py:9-39).  P1, P2: dev [12] each
+ * (rows 0..2 of the camera matrices, 4 columns); X: dev [m,3]. */
+int sfm_triangulate(const double* corr, int64_t m, const double* P1, const double* P2, double* X,
+                    void* stream);
+
+/* Decompose an essential matrix into the four candidate poses in the order (R1,t),(R1,-t),(R2,t),(R2,-t)
+ * (eight_point.py:245-280, 210-212).  E: dev [batch,9]; pose_rt: dev [batch,4,12];
+ * status: dev int32 [batch], 0 ok, 1 = smallest singular value not ~0 (eight_point.py:268-271). */
+int sfm_decompose_essential(const double* E, int64_t batch, double* pose_rt, int32_t* status,
+                            void* stream);
+
+/* HOST: exact replay of CPython's random.shuffle as used by ransac.py:59-64.  `mt_state` is the 624-word
+ * MT19937 state and `*mt_index` its position (random.getstate()[1]); both are advanced.  The cumulative
+ * permutation of range(n) is shuffled `iterations` times; S_out[it,:] receives its first 8 entries.  If
+ * perm_io != NULL it supplies the starting permutation (n entries) and receives the final one; if
+ * snapshot_iteration >= 0 and snapshot != NULL, the permutation after that iteration is stored there. */
+int sfm_pyshuffle_table(uint32_t* mt_state, int32_t* mt_index, int64_t n, int64_t iterations,
+                        int32_t* S_out, int32_t* perm_io, int64_t snapshot_iteration, int32_t* snapshot);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SFM_HIP_H */

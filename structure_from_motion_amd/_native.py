@@ -1,0 +1,90 @@
+"""ctypes binding of csrc/libsfm_hip.so (the C ABI of include/sfm_hip.h).
+
+Loading never needs a GPU (so symbol checks run anywhere); calling a kernel entry point does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libsfm_hip.so")
+
+SFM_OK = 0
+AGG_SUM, AGG_SQUARE, AGG_MEAN, AGG_RMS = 0, 1, 2, 3
+FIT_DEGENERATE = 1
+INT64_MAX = (1 << 63) - 1
+ABI_VERSION = 1
+
+
+class SelectResult(C.Structure):
+    """struct sfm_select_result (40 bytes)."""
+
+    _fields_ = [
+        ("key", C.c_uint64),
+        ("best_h", C.c_int64),
+        ("best_err", C.c_double),
+        ("first_flagged", C.c_int64),
+        ("n_flagged", C.c_int32),
+        ("best_cnt", C.c_int32),
+    ]
+
+
+_P = C.c_void_p
+_I64 = C.c_int64
+_U64 = C.c_uint64
+_D = C.c_double
+
+# name -> argtypes; every function returns int.  Must list every symbol of include/sfm_hip.h.
+SIGNATURES = {
+    "sfm_normalize_correspondences": [_P, _P, _I64, _D, _D, _D, _D, _P, _P],
+    "sfm_sample_philox": [_U64, _U64, _I64, _I64, _I64, _I64, _P, _P],
+    "sfm_fit_eight_point": [_P, _I64, _P, _I64, _I64, _P, _P, _P, _P],
+    "sfm_score_sed": [_P, _I64, _P, _P, _I64, _I64, _D, _P, _P, _P, _P],
+    "sfm_select_best": [_P, _P, _P, _P, _I64, _I64, _D, C.c_int, _I64, _P, _P],
+    "sfm_inlier_mask": [_P, _I64, _P, _P, _I64, _I64, _P, _D, _P, _P],
+    "sfm_sed_values": [_P, _I64, _P, _P, _P],
+    "sfm_cheirality": [_P, _I64, _P, _I64, _D, _P, _P],
+    "sfm_triangulate": [_P, _I64, _P, _P, _P, _P],
+    "sfm_decompose_essential": [_P, _I64, _P, _P, _P],
+    "sfm_pyshuffle_table": [_P, _P, _I64, _I64, _P, _P, _I64, _P],
+}
+OTHER_SYMBOLS = ["sfm_last_error", "sfm_abi_version"]
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load libsfm_hip.so (built by structure_from_motion_amd/build.py).  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -m structure_from_motion_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the hot path."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    lib.sfm_last_error.restype = C.c_char_p
+    lib.sfm_last_error.argtypes = []
+    lib.sfm_abi_version.restype = C.c_int
+    lib.sfm_abi_version.argtypes = []
+    if lib.sfm_abi_version() != ABI_VERSION:
+        raise NativeLibraryError(
+            f"libsfm_hip.so ABI {lib.sfm_abi_version()} != expected {ABI_VERSION}; rebuild it")
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != SFM_OK:
+        msg = load().sfm_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed ({status}): {msg}")

@@ -1,0 +1,719 @@
+// HIP kernels (gfx950 / MI355X) + C ABI for the RANSAC essential-matrix, cheirality and
+// triangulation hot path.  See include/sfm_hip.h for the contract of each entry point and the
+// reference lines it replaces; DESIGN.md for the data layout and the roofline of each kernel.
+//
+// Layout in HBM
+//   corr  [batch][n][4]  f64  rows {xa, ya, xb, yb}: one 32-byte record per correspondence, read by a
+//                             lane as two 16-byte loads; a wave reads 2 KiB contiguous per step.
+//   S     [batch][H][8]  i32  sample table (indices into corr)
+//   E     [batch][H][9]  f64  candidate essential matrices, row-major, E[8] == 1
+//   cnt/s1/s2/flags [batch][H]
+//
+// Compiled with -ffp-contract=off (see sfm_math.h).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/sfm_hip.h"
+#include "sfm_math.h"
+
+namespace {
+
+thread_local char g_error[512] = "";
+
+int fail(int code, const char* msg) {
+    snprintf(g_error, sizeof(g_error), "%s", msg);
+    return code;
+}
+
+int check_launch(const char* what) {
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) {
+        snprintf(g_error, sizeof(g_error), "%s: %s", what, hipGetErrorString(err));
+        return SFM_EHIP;
+    }
+    return SFM_OK;
+}
+
+constexpr int kWave = 64;
+static_assert(sizeof(sfm_select_result) == 40, "sfm_select_result layout is part of the ABI");
+
+struct alignas(32) Corr {
+    double xa, ya, xb, yb;
+};
+
+// ------------------------------------------------------------------------------------------------
+// K-normalisation pre-pass: one thread per correspondence, 2x16 B in, 32 B out.
+// ------------------------------------------------------------------------------------------------
+__global__ void normalize_kernel(const double2* __restrict__ pix_a, const double2* __restrict__ pix_b,
+                                 int64_t count, double fx, double fy, double cx, double cy,
+                                 Corr* __restrict__ corr) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const double2 a = pix_a[i];
+        const double2 b = pix_b[i];
+        Corr c;
+        c.xa = (a.x - cx) / fx;
+        c.ya = (a.y - cy) / fy;
+        c.xb = (b.x - cx) / fx;
+        c.yb = (b.y - cy) / fy;
+        corr[i] = c;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Philox sampler: one thread per hypothesis, 32 B out.
+// ------------------------------------------------------------------------------------------------
+__global__ void sample_philox_kernel(uint64_t seed, uint64_t seed_stride, int64_t h_begin,
+                                     int64_t h_count, uint32_t n, int32_t* __restrict__ S) {
+    const int64_t h = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= h_count) return;
+    const int64_t b = blockIdx.y;
+    int32_t idx[8];
+    sfm::philox_sample8(seed + (uint64_t)b * seed_stride, (uint64_t)(h_begin + h), n, idx);
+    int4* dst = reinterpret_cast<int4*>(S + (b * h_count + h) * 8);
+    dst[0] = make_int4(idx[0], idx[1], idx[2], idx[3]);
+    dst[1] = make_int4(idx[4], idx[5], idx[6], idx[7]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Eight-point fit: one lane per hypothesis (all 64 lanes of a wave busy), everything in registers.
+// ------------------------------------------------------------------------------------------------
+struct Hartley {
+    double scale, cx, cy;  // forward transform T = [[s,0,-s*cx],[0,s,-s*cy],[0,0,1]]
+};
+
+// reference eight_point.py:308-338 on 8 points, same operation order as NumPy:
+// centroid = sequential sum / 8; mean norm = pairwise tree over 8 (NumPy's unrolled pairwise sum).
+SFM_DEVICE Hartley hartley8(double (&x)[8], double (&y)[8]) {
+    double sx = x[0], sy = y[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        sx += x[k];
+        sy += y[k];
+    }
+    Hartley h;
+    h.cx = sx / 8.0;
+    h.cy = sy / 8.0;
+    double nrm[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        x[k] -= h.cx;
+        y[k] -= h.cy;
+        nrm[k] = sqrt(x[k] * x[k] + y[k] * y[k]);
+    }
+    const double total = ((nrm[0] + nrm[1]) + (nrm[2] + nrm[3])) + ((nrm[4] + nrm[5]) + (nrm[6] + nrm[7]));
+    h.scale = sqrt(2.0) / (total / 8.0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        x[k] *= h.scale;
+        y[k] *= h.scale;
+    }
+    return h;
+}
+
+__global__ __launch_bounds__(kWave) void fit_eight_point_kernel(
+    const Corr* __restrict__ corr, int64_t n, const int32_t* __restrict__ S, int64_t h_count,
+    double* __restrict__ E, int32_t* __restrict__ flags, double* __restrict__ lambda2) {
+    const int64_t b = blockIdx.y;
+    const int64_t h_raw = (int64_t)blockIdx.x * kWave + threadIdx.x;
+    const bool active = h_raw < h_count;
+    // inactive tail lanes redo the last hypothesis so the wave-uniform Jacobi loops stay convergent
+    const int64_t h = active ? h_raw : h_count - 1;
+    const Corr* pts = corr + b * n;
+    const int32_t* sample = S + (b * h_count + h) * 8;
+
+    double xa[8], ya[8], xb[8], yb[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const Corr c = pts[sample[k]];
+        xa[k] = c.xa; ya[k] = c.ya; xb[k] = c.xb; yb[k] = c.yb;
+    }
+    const Hartley t1 = hartley8(xa, ya);
+    const Hartley t2 = hartley8(xb, yb);
+
+    // Y^T Y, upper triangle, accumulated in point order (eight_point.py:363-393)
+    double a[45];
+#pragma unroll
+    for (int i = 0; i < 45; ++i) a[i] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const double col[9] = {xb[k] * xa[k], xb[k] * ya[k], xb[k], yb[k] * xa[k], yb[k] * ya[k],
+                               yb[k],         xa[k],         ya[k], 1.0};
+        int idx = 0;
+#pragma unroll
+        for (int p = 0; p < 9; ++p)
+#pragma unroll
+            for (int q = p; q < 9; ++q) a[idx++] += col[p] * col[q];
+    }
+
+    double v[81], w[9];
+    sfm::jacobi_eig9(a, v, w);
+
+    // eight_point.py:413-424: flag if any but the smallest eigenvalue is <= 1e-10; take argmin |w|
+    double smallest = w[0], second = INFINITY;
+    double best_abs = fabs(w[0]);
+    double f[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) f[k] = v[k * 9 + 0];
+#pragma unroll
+    for (int j = 1; j < 9; ++j) {
+        const bool lt = w[j] < smallest;
+        second = lt ? smallest : fmin(second, w[j]);
+        smallest = lt ? w[j] : smallest;
+        const bool closer = fabs(w[j]) < best_abs;
+        best_abs = closer ? fabs(w[j]) : best_abs;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) f[k] = closer ? v[k * 9 + j] : f[k];
+    }
+    const int flag = (second <= 1e-10) ? SFM_FIT_DEGENERATE : 0;
+
+    // rank-2 enforcement (eight_point.py:440-445): drop the smallest singular direction
+    double g[3][3], vv[3][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) g[c][r] = f[r * 3 + c];
+    sfm::hestenes_svd<3>(g, vv);
+    double n2[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) n2[c] = g[c][0] * g[c][0] + g[c][1] * g[c][1] + g[c][2] * g[c][2];
+    const int drop = (n2[0] <= n2[1] && n2[0] <= n2[2]) ? 0 : ((n2[1] <= n2[2]) ? 1 : 2);
+    double fr[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) acc += (k == drop) ? 0.0 : g[k][r] * vv[k][c];
+            fr[r][c] = acc;
+        }
+
+    // E = T2^T F T1 (eight_point.py:163), then divide by E[2][2] (:166, unguarded)
+    const double tx1 = -t1.scale * t1.cx, ty1 = -t1.scale * t1.cy;
+    const double tx2 = -t2.scale * t2.cx, ty2 = -t2.scale * t2.cy;
+    double m[3][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        m[0][c] = t2.scale * fr[0][c];
+        m[1][c] = t2.scale * fr[1][c];
+        m[2][c] = (tx2 * fr[0][c] + ty2 * fr[1][c]) + fr[2][c];
+    }
+    double e[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        e[r * 3 + 0] = m[r][0] * t1.scale;
+        e[r * 3 + 1] = m[r][1] * t1.scale;
+        e[r * 3 + 2] = (m[r][0] * tx1 + m[r][1] * ty1) + m[r][2];
+    }
+    const double e22 = e[8];
+    if (active) {
+        double* out = E + (b * h_count + h) * 9;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) out[k] = e[k] / e22;
+        flags[b * h_count + h] = flag;
+        if (lambda2 != nullptr) lambda2[b * h_count + h] = second;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// SED scoring: the H x N loop.  One wave owns HPW hypotheses (their E in scalar registers) and
+// streams all n correspondences; lane l takes points l, l+64, ...  Per-lane partial (count, sum,
+// sum of squares) are combined by a fixed-order butterfly, so results are run-to-run identical.
+// The 8 sample points are fixed up by lanes 0..7 afterwards: they are never counted, always summed.
+// ------------------------------------------------------------------------------------------------
+template <int HPW>
+__global__ __launch_bounds__(256) void score_sed_kernel(
+    const Corr* __restrict__ corr, int n, const double* __restrict__ E, const int32_t* __restrict__ S,
+    int h_count, double thr, int32_t* __restrict__ cnt, double* __restrict__ s1,
+    double* __restrict__ s2) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave));
+    const int h0 = wave * HPW;
+    if (h0 >= h_count) return;
+    const int64_t b = blockIdx.y;
+    const Corr* __restrict__ pts = corr + b * (int64_t)n;
+    const double* __restrict__ Eb = E + b * (int64_t)h_count * 9;
+    const int32_t* __restrict__ Sb = S + b * (int64_t)h_count * 8;
+
+    double e[HPW][9];
+#pragma unroll
+    for (int k = 0; k < HPW; ++k) {
+        const int h = min(h0 + k, h_count - 1);
+#pragma unroll
+        for (int j = 0; j < 9; ++j) e[k][j] = Eb[(int64_t)h * 9 + j];
+    }
+    int c[HPW];
+    double a1[HPW], a2[HPW];
+#pragma unroll
+    for (int k = 0; k < HPW; ++k) {
+        c[k] = 0;
+        a1[k] = 0.0;
+        a2[k] = 0.0;
+    }
+    for (int i = lane; i < n; i += kWave) {
+        const Corr p = pts[i];
+#pragma unroll
+        for (int k = 0; k < HPW; ++k) {
+            const double sed = sfm::sed_value(e[k], p.xa, p.ya, p.xb, p.yb);
+            const bool ok = sed <= thr;
+            c[k] += ok ? 1 : 0;
+            a1[k] += ok ? sed : 0.0;
+            a2[k] += ok ? sed * sed : 0.0;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < HPW; ++k) {
+        int ck = sfm::wave_sum(c[k]);
+        double s1k = sfm::wave_sum(a1[k]);
+        double s2k = sfm::wave_sum(a2[k]);
+        const int h = h0 + k;
+        if (h < h_count) {
+            // sample fix-up: lanes 0..7 each re-score one sample point
+            int dc = 0;
+            double d1 = 0.0, d2 = 0.0;
+            if (lane < 8) {
+                const Corr p = pts[Sb[(int64_t)h * 8 + lane]];
+                const double sed = sfm::sed_value(e[k], p.xa, p.ya, p.xb, p.yb);
+                const bool counted = sed <= thr;  // already in (ck, s1k, s2k)
+                dc = counted ? -1 : 0;
+                d1 = counted ? 0.0 : sed;          // NaN / inf propagate: such a model never wins
+                d2 = counted ? 0.0 : sed * sed;
+            }
+            ck += sfm::wave_sum(dc);
+            s1k += sfm::wave_sum(d1);
+            s2k += sfm::wave_sum(d2);
+            if (lane == 0) {
+                const int64_t o = b * (int64_t)h_count + h;
+                cnt[o] = ck;
+                s1[o] = s1k;
+                s2[o] = s2k;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Selection: one 1024-thread block per batch entry; lexicographic min over (error bits, index).
+// ------------------------------------------------------------------------------------------------
+SFM_DEVICE double aggregate_error(int aggregation, int count, double sum1, double sum2) {
+    const double nn = (double)(count + 8);
+    switch (aggregation) {
+        case SFM_AGG_SUM: return sum1;
+        case SFM_AGG_SQUARE: return sum2;
+        case SFM_AGG_MEAN: return sum1 / nn;
+        default: return sqrt(sum2 / nn);
+    }
+}
+
+// "no model" key: above every finite non-negative double's bit pattern, and still positive when the
+// record is viewed as int64 (so a cross-GPU MIN all-reduce on int64 works).
+constexpr uint64_t kNoModelKey = 0x7FFFFFFFFFFFFFFFull;
+
+struct Candidate {
+    uint64_t key;
+    int64_t h;
+};
+
+SFM_DEVICE Candidate better(Candidate x, Candidate y) {
+    const bool take_y = (y.key < x.key) || (y.key == x.key && y.h < x.h);
+    return take_y ? y : x;
+}
+
+__global__ __launch_bounds__(1024) void select_best_kernel(
+    const int32_t* __restrict__ cnt, const double* __restrict__ s1, const double* __restrict__ s2,
+    const int32_t* __restrict__ flags, int64_t h_count, double min_extra, int aggregation,
+    int64_t h_offset, sfm_select_result* __restrict__ result) {
+    const int64_t b = blockIdx.x;
+    cnt += b * h_count; s1 += b * h_count; s2 += b * h_count;
+    if (flags != nullptr) flags += b * h_count;
+    Candidate best = {kNoModelKey, INT64_MAX};
+    int64_t first_flag = INT64_MAX;
+    int n_flag = 0;
+    for (int64_t h = threadIdx.x; h < h_count; h += blockDim.x) {
+        const int ch = cnt[h];
+        const double err = aggregate_error(aggregation, ch, s1[h], s2[h]);
+        // ransac.py:75 gate and :83 strict compare against an initial +inf: NaN and inf never win.
+        // Hypotheses whose sample was flagged degenerate never compete (the reference aborts on them).
+        const bool flagged = flags != nullptr && flags[h] != 0;
+        const bool ok = ((double)ch >= min_extra) && (err < INFINITY) && !flagged;
+        uint64_t bits = (uint64_t)__double_as_longlong(err);
+        if (bits == 0x8000000000000000ull) bits = 0;  // -0.0 orders as +0.0
+        Candidate cand = {ok ? bits : kNoModelKey, ok ? h : INT64_MAX};
+        best = better(best, cand);
+        if (flagged) {
+            first_flag = h < first_flag ? h : first_flag;
+            ++n_flag;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        Candidate o;
+        o.key = __shfl_xor(best.key, off, 64);
+        o.h = __shfl_xor(best.h, off, 64);
+        best = better(best, o);
+        const int64_t of = __shfl_xor(first_flag, off, 64);
+        first_flag = of < first_flag ? of : first_flag;
+        n_flag += __shfl_xor(n_flag, off, 64);
+    }
+    __shared__ Candidate sh_best[16];
+    __shared__ int64_t sh_first[16];
+    __shared__ int sh_n[16];
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+    if (lane == 0) {
+        sh_best[wave] = best;
+        sh_first[wave] = first_flag;
+        sh_n[wave] = n_flag;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int waves = blockDim.x / kWave;
+        for (int k = 1; k < waves; ++k) {
+            best = better(best, sh_best[k]);
+            first_flag = sh_first[k] < first_flag ? sh_first[k] : first_flag;
+            n_flag += sh_n[k];
+        }
+        sfm_select_result r;
+        const bool found = best.key != kNoModelKey;
+        r.key = best.key;
+        r.best_h = found ? best.h + h_offset : -1;
+        r.best_err = found ? __longlong_as_double((long long)best.key) : INFINITY;
+        r.first_flagged = (first_flag == INT64_MAX) ? INT64_MAX : first_flag + h_offset;
+        r.n_flagged = n_flag;
+        r.best_cnt = found ? cnt[best.h] : 0;
+        result[b] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Inlier mask of the winner (ransac.py:70-76): 1 = surviving non-sample point, 2 = sample point.
+// ------------------------------------------------------------------------------------------------
+__global__ void inlier_mask_kernel(const Corr* __restrict__ corr, int64_t n,
+                                   const double* __restrict__ E, const int32_t* __restrict__ S,
+                                   int64_t h_count, const sfm_select_result* __restrict__ result,
+                                   double thr, uint8_t* __restrict__ mask) {
+    const int64_t b = blockIdx.y;
+    const int64_t h = result[b].best_h;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    uint8_t* out = mask + b * n;
+    if (h < 0 || h >= h_count) {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = 0;
+        return;
+    }
+    double e[9];
+    int32_t smp[8];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) e[k] = E[(b * h_count + h) * 9 + k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) smp[k] = S[(b * h_count + h) * 8 + k];
+    const Corr* pts = corr + b * n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const Corr p = pts[i];
+        const double sed = sfm::sed_value(e, p.xa, p.ya, p.xb, p.yb);
+        bool in_sample = false;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) in_sample |= (smp[k] == (int32_t)i);
+        out[i] = in_sample ? 2 : ((sed <= thr) ? 1 : 0);
+    }
+}
+
+__global__ void sed_values_kernel(const Corr* __restrict__ corr, int64_t n, const double* __restrict__ E,
+                                  double* __restrict__ out) {
+    double e[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) e[k] = E[k];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const Corr p = corr[i];
+        out[i] = sfm::sed_value(e, p.xa, p.ya, p.xb, p.yb);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cheirality (eight_point.py:449-488): one lane per (pose, pair).  P1 = I4, P2 = [R t; 0 0 0 1].
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWave) void cheirality_kernel(const Corr* __restrict__ corr, int64_t m,
+                                                           const double* __restrict__ pose_rt,
+                                                           double distance_threshold,
+                                                           uint8_t* __restrict__ pass) {
+    const int64_t i_raw = (int64_t)blockIdx.x * kWave + threadIdx.x;
+    const bool active = i_raw < m;
+    const int64_t i = active ? i_raw : m - 1;
+    const int pose = blockIdx.y;
+    const double* rt = pose_rt + pose * 12;
+    double P1[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    double P2[12];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        P2[r * 4 + 0] = rt[r * 3 + 0];
+        P2[r * 4 + 1] = rt[r * 3 + 1];
+        P2[r * 4 + 2] = rt[r * 3 + 2];
+        P2[r * 4 + 3] = rt[9 + r];
+    }
+    const Corr p = corr[i];
+    double X[3];
+    sfm::triangulate_dlt(P1, P2, p.xa, p.ya, p.xb, p.yb, X);
+    // depth in camera 2: third row of P2 @ [X, 1] (eight_point.py:476), left to right
+    const double z2 = ((P2[8] * X[0] + P2[9] * X[1]) + P2[10] * X[2]) + P2[11];
+    const double norm = sqrt((X[0] * X[0] + X[1] * X[1]) + X[2] * X[2]);
+    const bool ok = (X[2] >= -1e-8) && (z2 >= -1e-8) && (norm <= distance_threshold);
+    if (active) pass[(int64_t)pose * m + i] = ok ? 1 : 0;
+}
+
+__global__ __launch_bounds__(kWave) void triangulate_kernel(const Corr* __restrict__ corr, int64_t m,
+                                                            const double* __restrict__ P1g,
+                                                            const double* __restrict__ P2g,
+                                                            double* __restrict__ Xout) {
+    const int64_t i_raw = (int64_t)blockIdx.x * kWave + threadIdx.x;
+    const bool active = i_raw < m;
+    const int64_t i = active ? i_raw : m - 1;
+    double P1[12], P2[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        P1[k] = P1g[k];
+        P2[k] = P2g[k];
+    }
+    const Corr p = corr[i];
+    double X[3];
+    sfm::triangulate_dlt(P1, P2, p.xa, p.ya, p.xb, p.yb, X);
+    if (active) {
+        Xout[i * 3 + 0] = X[0];
+        Xout[i * 3 + 1] = X[1];
+        Xout[i * 3 + 2] = X[2];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Essential-matrix decomposition (eight_point.py:245-280): E = U S V^T, t = vee(U Z U^T) = u3,
+// R1 = U W^T V^T, R2 = U W V^T with U, V made proper rotations.  One lane per matrix.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWave) void decompose_essential_kernel(const double* __restrict__ E,
+                                                                    int64_t batch,
+                                                                    double* __restrict__ pose_rt,
+                                                                    int32_t* __restrict__ status) {
+    const int64_t b_raw = (int64_t)blockIdx.x * kWave + threadIdx.x;
+    const bool active = b_raw < batch;
+    const int64_t b = active ? b_raw : batch - 1;
+    const double* e = E + b * 9;
+    double g[3][3], v[3][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) g[c][r] = e[r * 3 + c];
+    sfm::hestenes_svd<3>(g, v);
+    double sig[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) sig[c] = sqrt(g[c][0] * g[c][0] + g[c][1] * g[c][1] + g[c][2] * g[c][2]);
+    // order columns by decreasing singular value: (i0, i1, i2)
+    int i0 = 0, i1 = 1, i2 = 2;
+    if (sig[i0] < sig[i1]) { int t = i0; i0 = i1; i1 = t; }
+    if (sig[i1] < sig[i2]) { int t = i1; i1 = i2; i2 = t; }
+    if (sig[i0] < sig[i1]) { int t = i0; i0 = i1; i1 = t; }
+    double u[3][3], vt[3][3];  // u[col][row], vt[col][row] = V columns
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        double g0 = 0, g1 = 0, v0 = 0, v1 = 0, v2 = 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            g0 = (c == i0) ? g[c][r] : g0;
+            g1 = (c == i1) ? g[c][r] : g1;
+            v0 = (c == i0) ? v[c][r] : v0;
+            v1 = (c == i1) ? v[c][r] : v1;
+            v2 = (c == i2) ? v[c][r] : v2;
+        }
+        u[0][r] = g0;
+        u[1][r] = g1;
+        vt[0][r] = v0;
+        vt[1][r] = v1;
+        vt[2][r] = v2;
+    }
+    double s0 = 0, s1v = 0, s2v = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        s0 = (c == i0) ? sig[c] : s0;
+        s1v = (c == i1) ? sig[c] : s1v;
+        s2v = (c == i2) ? sig[c] : s2v;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        u[0][r] /= s0;
+        u[1][r] /= s1v;
+    }
+    // third left singular vector from the cross product: U is a proper rotation by construction,
+    // which is what the det(U) == -1 -> U *= -1 branch (eight_point.py:263-264) establishes.
+    u[2][0] = u[0][1] * u[1][2] - u[0][2] * u[1][1];
+    u[2][1] = u[0][2] * u[1][0] - u[0][0] * u[1][2];
+    u[2][2] = u[0][0] * u[1][1] - u[0][1] * u[1][0];
+    // make V proper as well: flip v3 if det(V) < 0 (the reference flips all of V^T; R1/R2 below are
+    // then the same pair of rotations)
+    const double cx = vt[0][1] * vt[1][2] - vt[0][2] * vt[1][1];
+    const double cy = vt[0][2] * vt[1][0] - vt[0][0] * vt[1][2];
+    const double cz = vt[0][0] * vt[1][1] - vt[0][1] * vt[1][0];
+    const double detv = cx * vt[2][0] + cy * vt[2][1] + cz * vt[2][2];
+    if (detv < 0.0) {
+        vt[2][0] = -vt[2][0];
+        vt[2][1] = -vt[2][1];
+        vt[2][2] = -vt[2][2];
+    }
+    // np.isclose(0, s[-1]) with atol 1e-8 (eight_point.py:268)
+    const int st = (s2v <= 1e-8 + 1e-5 * s2v) ? 0 : 1;
+    // R1 = U W^T V^T, R2 = U W V^T with W = [[0,-1,0],[1,0,0],[0,0,1]]:
+    //   U W^T = [-u2, u1, u3] columns -> R1 = -u2 v1^T + u1 v2^T + u3 v3^T
+    //   U W   = [ u2,-u1, u3]         -> R2 =  u2 v1^T - u1 v2^T + u3 v3^T
+    if (active) {
+        double* out = pose_rt + b * 48;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const double r1 = (-(u[1][r] * vt[0][c]) + u[0][r] * vt[1][c]) + u[2][r] * vt[2][c];
+                const double r2 = (u[1][r] * vt[0][c] - u[0][r] * vt[1][c]) + u[2][r] * vt[2][c];
+                out[0 * 12 + r * 3 + c] = r1;
+                out[1 * 12 + r * 3 + c] = r1;
+                out[2 * 12 + r * 3 + c] = r2;
+                out[3 * 12 + r * 3 + c] = r2;
+            }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            // t = vee(U Z U^T) = u1 x u2 = u3
+            out[0 * 12 + 9 + r] = u[2][r];
+            out[1 * 12 + 9 + r] = -u[2][r];
+            out[2 * 12 + 9 + r] = u[2][r];
+            out[3 * 12 + 9 + r] = -u[2][r];
+        }
+        status[b] = st;
+    }
+}
+
+inline unsigned grid_for(int64_t work, int block, int64_t cap = 1 << 20) {
+    int64_t g = (work + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+}  // namespace
+
+// ==================================================================================================
+// C ABI
+// ==================================================================================================
+extern "C" {
+
+const char* sfm_last_error(void) { return g_error; }
+int sfm_abi_version(void) { return 1; }
+
+int sfm_normalize_correspondences(const double* pix_a, const double* pix_b, int64_t count, double fx,
+                                  double fy, double cx, double cy, double* corr, void* stream) {
+    if (count < 0) return fail(SFM_EINVAL, "sfm_normalize_correspondences: negative count");
+    if (count == 0) return SFM_OK;
+    if (!pix_a || !pix_b || !corr) return fail(SFM_EINVAL, "sfm_normalize_correspondences: null pointer");
+    hipLaunchKernelGGL(normalize_kernel, dim3(grid_for(count, 256, 2048)), dim3(256), 0,
+                       (hipStream_t)stream, (const double2*)pix_a, (const double2*)pix_b, count, fx, fy,
+                       cx, cy, (Corr*)corr);
+    return check_launch("normalize_kernel");
+}
+
+int sfm_sample_philox(uint64_t seed, uint64_t seed_stride, int64_t h_begin, int64_t h_count, int64_t n,
+                      int64_t batch, int32_t* S, void* stream) {
+    if (h_count < 0 || batch < 0 || h_begin < 0) return fail(SFM_EINVAL, "sfm_sample_philox: negative size");
+    if (n < 8 || n > 0x7FFFFFFF) return fail(SFM_EINVAL, "sfm_sample_philox: need 8 <= n < 2^31");
+    if (h_count == 0 || batch == 0) return SFM_OK;
+    if (!S) return fail(SFM_EINVAL, "sfm_sample_philox: null pointer");
+    hipLaunchKernelGGL(sample_philox_kernel, dim3(grid_for(h_count, 256), (unsigned)batch), dim3(256), 0,
+                       (hipStream_t)stream, seed, seed_stride, h_begin, h_count, (uint32_t)n, S);
+    return check_launch("sample_philox_kernel");
+}
+
+int sfm_fit_eight_point(const double* corr, int64_t n, const int32_t* S, int64_t h_count, int64_t batch,
+                        double* E, int32_t* flags, double* lambda2, void* stream) {
+    if (h_count < 0 || batch < 0) return fail(SFM_EINVAL, "sfm_fit_eight_point: negative size");
+    if (n < 8) return fail(SFM_EINVAL, "sfm_fit_eight_point: need at least 8 correspondences");
+    if (h_count == 0 || batch == 0) return SFM_OK;
+    if (!corr || !S || !E || !flags) return fail(SFM_EINVAL, "sfm_fit_eight_point: null pointer");
+    hipLaunchKernelGGL(fit_eight_point_kernel, dim3(grid_for(h_count, kWave), (unsigned)batch),
+                       dim3(kWave), 0, (hipStream_t)stream, (const Corr*)corr, n, S, h_count, E, flags,
+                       lambda2);
+    return check_launch("fit_eight_point_kernel");
+}
+
+int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t* S, int64_t h_count,
+                  int64_t batch, double thr, int32_t* cnt, double* s1, double* s2, void* stream) {
+    if (h_count < 0 || batch < 0 || n < 0) return fail(SFM_EINVAL, "sfm_score_sed: negative size");
+    if (n > 0x7FFFFFFF || h_count > 0x3FFFFFFF) return fail(SFM_EINVAL, "sfm_score_sed: size too large");
+    if (h_count == 0 || batch == 0) return SFM_OK;
+    if (!corr || !E || !S || !cnt || !s1 || !s2) return fail(SFM_EINVAL, "sfm_score_sed: null pointer");
+    constexpr int HPW = 4;
+    const int64_t waves = (h_count + HPW - 1) / HPW;
+    hipLaunchKernelGGL(score_sed_kernel<HPW>, dim3(grid_for(waves, 4), (unsigned)batch), dim3(256), 0,
+                       (hipStream_t)stream, (const Corr*)corr, (int)n, E, S, (int)h_count, thr, cnt, s1,
+                       s2);
+    return check_launch("score_sed_kernel");
+}
+
+int sfm_select_best(const int32_t* cnt, const double* s1, const double* s2, const int32_t* flags,
+                    int64_t h_count, int64_t batch, double min_extra, int aggregation, int64_t h_offset,
+                    sfm_select_result* result, void* stream) {
+    if (h_count < 0 || batch < 0) return fail(SFM_EINVAL, "sfm_select_best: negative size");
+    if (aggregation < SFM_AGG_SUM || aggregation > SFM_AGG_RMS)
+        return fail(SFM_EINVAL, "sfm_select_best: unknown aggregation");
+    if (batch == 0) return SFM_OK;
+    if (!result || (h_count > 0 && (!cnt || !s1 || !s2)))
+        return fail(SFM_EINVAL, "sfm_select_best: null pointer");
+    hipLaunchKernelGGL(select_best_kernel, dim3((unsigned)batch), dim3(1024), 0, (hipStream_t)stream, cnt,
+                       s1, s2, flags, h_count, min_extra, aggregation, h_offset, result);
+    return check_launch("select_best_kernel");
+}
+
+int sfm_inlier_mask(const double* corr, int64_t n, const double* E, const int32_t* S, int64_t h_count,
+                    int64_t batch, const sfm_select_result* result, double thr, uint8_t* mask,
+                    void* stream) {
+    if (h_count < 0 || batch < 0 || n < 0) return fail(SFM_EINVAL, "sfm_inlier_mask: negative size");
+    if (n == 0 || batch == 0) return SFM_OK;
+    if (!corr || !E || !S || !result || !mask) return fail(SFM_EINVAL, "sfm_inlier_mask: null pointer");
+    hipLaunchKernelGGL(inlier_mask_kernel, dim3(grid_for(n, 256, 1024), (unsigned)batch), dim3(256), 0,
+                       (hipStream_t)stream, (const Corr*)corr, n, E, S, h_count, result, thr, mask);
+    return check_launch("inlier_mask_kernel");
+}
+
+int sfm_sed_values(const double* corr, int64_t n, const double* E, double* out, void* stream) {
+    if (n < 0) return fail(SFM_EINVAL, "sfm_sed_values: negative size");
+    if (n == 0) return SFM_OK;
+    if (!corr || !E || !out) return fail(SFM_EINVAL, "sfm_sed_values: null pointer");
+    hipLaunchKernelGGL(sed_values_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream,
+                       (const Corr*)corr, n, E, out);
+    return check_launch("sed_values_kernel");
+}
+
+int sfm_cheirality(const double* corr, int64_t m, const double* pose_rt, int64_t poses,
+                   double distance_threshold, uint8_t* pass, void* stream) {
+    if (m < 0 || poses < 0) return fail(SFM_EINVAL, "sfm_cheirality: negative size");
+    if (m == 0 || poses == 0) return SFM_OK;
+    if (!corr || !pose_rt || !pass) return fail(SFM_EINVAL, "sfm_cheirality: null pointer");
+    hipLaunchKernelGGL(cheirality_kernel, dim3(grid_for(m, kWave), (unsigned)poses), dim3(kWave), 0,
+                       (hipStream_t)stream, (const Corr*)corr, m, pose_rt, distance_threshold, pass);
+    return check_launch("cheirality_kernel");
+}
+
+int sfm_triangulate(const double* corr, int64_t m, const double* P1, const double* P2, double* X,
+                    void* stream) {
+    if (m < 0) return fail(SFM_EINVAL, "sfm_triangulate: negative size");
+    if (m == 0) return SFM_OK;
+    if (!corr || !P1 || !P2 || !X) return fail(SFM_EINVAL, "sfm_triangulate: null pointer");
+    hipLaunchKernelGGL(triangulate_kernel, dim3(grid_for(m, kWave)), dim3(kWave), 0, (hipStream_t)stream,
+                       (const Corr*)corr, m, P1, P2, X);
+    return check_launch("triangulate_kernel");
+}
+
+int sfm_decompose_essential(const double* E, int64_t batch, double* pose_rt, int32_t* status,
+                            void* stream) {
+    if (batch < 0) return fail(SFM_EINVAL, "sfm_decompose_essential: negative size");
+    if (batch == 0) return SFM_OK;
+    if (!E || !pose_rt || !status) return fail(SFM_EINVAL, "sfm_decompose_essential: null pointer");
+    hipLaunchKernelGGL(decompose_essential_kernel, dim3(grid_for(batch, kWave)), dim3(kWave), 0,
+                       (hipStream_t)stream, E, batch, pose_rt, status);
+    return check_launch("decompose_essential_kernel");
+}
+
+}  // extern "C"

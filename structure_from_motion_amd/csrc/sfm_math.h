@@ -1,0 +1,321 @@
+// fp64 device primitives for the epipolar hot path (gfx950).
+//
+// Everything here is per-lane register math: all array indices are compile-time constants after
+// unrolling, so the small matrices live in VGPRs (no scratch).  The translation unit is compiled with
+// -ffp-contract=off: every multiply and add rounds separately, matching the NumPy elementwise
+// semantics of the reference; fused operations are written explicitly with fma() where wanted.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <utility>
+
+#define SFM_DEVICE __device__ __forceinline__
+
+namespace sfm {
+
+// --------------------------------------------------------------------------------------------------
+// Symmetric epipolar distance of one correspondence under one E (row-major e[9]).
+// Operation order is the contract shared with oracle/sfm_oracle.py::sed_values:
+//   line_b = E^T b, r = line_b . a   (reference sed.py:21,25:  coord_b.T @ e @ coord_a)
+//   line_a = E a                      (sed.py:24)
+//   sed = (1/(la0^2+la1^2) + 1/(lb0^2+lb1^2)) * r^2   (sed.py:27-29)
+// --------------------------------------------------------------------------------------------------
+SFM_DEVICE double sed_value(const double e[9], double xa, double ya, double xb, double yb) {
+    const double lb0 = (xb * e[0] + yb * e[3]) + e[6];
+    const double lb1 = (xb * e[1] + yb * e[4]) + e[7];
+    const double lb2 = (xb * e[2] + yb * e[5]) + e[8];
+    const double r = (lb0 * xa + lb1 * ya) + lb2;
+    const double la0 = (e[0] * xa + e[1] * ya) + e[2];
+    const double la1 = (e[3] * xa + e[4] * ya) + e[5];
+    const double da = la0 * la0 + la1 * la1;
+    const double db = lb0 * lb0 + lb1 * lb1;
+    return (1.0 / da + 1.0 / db) * (r * r);
+}
+
+// --------------------------------------------------------------------------------------------------
+// Jacobi rotation parameters that annihilate the off-diagonal g of [[a, g], [g, b]]:
+// returns (c, s, t) with t = tan(theta) the smaller root.  g == 0 gives the identity.
+// --------------------------------------------------------------------------------------------------
+SFM_DEVICE void jacobi_cs(double a, double b, double g, double& c, double& s, double& t) {
+    const double zeta = (b - a) / (2.0 * g);
+    // |zeta| may be inf (g tiny) -> t = 0; NaN only when g == 0 and a == b, handled by the select.
+    const double az = fabs(zeta);
+    double tt = 1.0 / (az + sqrt(1.0 + az * az));
+    tt = (zeta < 0.0) ? -tt : tt;
+    const bool live = (g != 0.0) && (az == az);
+    t = live ? tt : 0.0;
+    c = 1.0 / sqrt(1.0 + t * t);
+    s = t * c;
+}
+
+// --------------------------------------------------------------------------------------------------
+// Cyclic two-sided Jacobi eigen-decomposition of a symmetric 9x9 matrix held as its upper triangle.
+// On return w[9] are the eigenvalues (unsorted) and V[k*9 + j] is component k of eigenvector j.
+// Replaces np.linalg.eig at reference eight_point.py:410 (the matrix there is symmetric PSD).
+// --------------------------------------------------------------------------------------------------
+template <int P, int Q>
+struct TriIndex {  // index of (P,Q), P <= Q, in a row-major packed upper triangle of a 9x9
+    static constexpr int value = P * 9 - (P * (P - 1)) / 2 + (Q - P);
+};
+
+template <int P, int Q>
+SFM_DEVICE double& sym(double* a) {
+    if constexpr (P <= Q) return a[TriIndex<P, Q>::value];
+    else return a[TriIndex<Q, P>::value];
+}
+
+template <int P, int Q, int K>
+SFM_DEVICE void rotate_offdiag(double* a, double c, double s) {
+    if constexpr (K != P && K != Q) {
+        const double akp = sym<K, P>(a);
+        const double akq = sym<K, Q>(a);
+        sym<K, P>(a) = c * akp - s * akq;
+        sym<K, Q>(a) = s * akp + c * akq;
+    }
+}
+
+template <int P, int Q, int... K>
+SFM_DEVICE void rotate_all(double* a, double* v, double c, double s, std::integer_sequence<int, K...>) {
+    (rotate_offdiag<P, Q, K>(a, c, s), ...);
+    ((void)([&] {
+         const double vkp = v[K * 9 + P];
+         const double vkq = v[K * 9 + Q];
+         v[K * 9 + P] = c * vkp - s * vkq;
+         v[K * 9 + Q] = s * vkp + c * vkq;
+     }()),
+     ...);
+}
+
+template <int P, int Q>
+SFM_DEVICE void jacobi_rotate9(double* a, double* v) {
+    const double app = sym<P, P>(a);
+    const double aqq = sym<Q, Q>(a);
+    const double apq = sym<P, Q>(a);
+    double c, s, t;
+    jacobi_cs(app, aqq, apq, c, s, t);
+    sym<P, P>(a) = app - t * apq;
+    sym<Q, Q>(a) = aqq + t * apq;
+    sym<P, Q>(a) = 0.0;
+    rotate_all<P, Q>(a, v, c, s, std::make_integer_sequence<int, 9>{});
+}
+
+template <int P, int Q>
+SFM_DEVICE void jacobi_sweep_from(double* a, double* v) {
+    jacobi_rotate9<P, Q>(a, v);
+    if constexpr (Q + 1 < 9) jacobi_sweep_from<P, Q + 1>(a, v);
+    else if constexpr (P + 2 < 9) jacobi_sweep_from<P + 1, P + 2>(a, v);
+}
+
+SFM_DEVICE double offdiag_sq(const double* a) {
+    // sum of squares of the strict upper triangle of the packed array
+    double acc = 0.0;
+    int idx = 0;
+#pragma unroll
+    for (int p = 0; p < 9; ++p) {
+#pragma unroll
+        for (int q = p; q < 9; ++q) {
+            if (q != p) acc += a[idx] * a[idx];
+            ++idx;
+        }
+    }
+    return acc;
+}
+
+// a: packed upper triangle (45), destroyed; v: 81 outputs; w: 9 outputs.  Returns sweeps used.
+SFM_DEVICE int jacobi_eig9(double* a, double* v, double* w) {
+#pragma unroll
+    for (int i = 0; i < 81; ++i) v[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) v[i * 9 + i] = 1.0;
+    double diag_sq = 0.0;
+    {
+        int idx = 0;
+#pragma unroll
+        for (int p = 0; p < 9; ++p) {
+            diag_sq += a[idx] * a[idx];
+            idx += 9 - p;
+        }
+    }
+    // Converged when the off-diagonal mass is below rounding of the diagonal scale.  Jacobi converges
+    // quadratically, so the last sweep typically drives it to exactly zero / denormal.
+    const double stop = diag_sq * 1e-36;
+    int sweep = 0;
+#pragma unroll 1
+    for (; sweep < 24; ++sweep) {
+        const double off = offdiag_sq(a);
+        const bool more = off > stop;
+        if (!__any(more)) break;  // wave-uniform exit: all lanes sweep until the slowest is done
+        jacobi_sweep_from<0, 1>(a, v);
+    }
+    {
+        int idx = 0;
+#pragma unroll
+        for (int p = 0; p < 9; ++p) {
+            w[p] = a[idx];
+            idx += 9 - p;
+        }
+    }
+    return sweep;
+}
+
+// --------------------------------------------------------------------------------------------------
+// One-sided (Hestenes) Jacobi SVD of an NxN matrix stored column-wise: g[col][row].
+// On return the columns of g are sigma_k * u_k (mutually orthogonal) and v[col][row] holds V.
+// Works on A directly (never on A^T A), so small singular directions keep high relative accuracy.
+// --------------------------------------------------------------------------------------------------
+template <int N, int I, int J>
+SFM_DEVICE bool hestenes_rotate(double (&g)[N][N], double (&v)[N][N]) {
+    double alpha = 0.0, beta = 0.0, gamma = 0.0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        alpha += g[I][k] * g[I][k];
+        beta += g[J][k] * g[J][k];
+        gamma += g[I][k] * g[J][k];
+    }
+    // relative orthogonality test; columns that are exactly zero are left alone
+    const bool rot = fabs(gamma) > 1e-15 * sqrt(alpha * beta);
+    double c, s, t;
+    jacobi_cs(alpha, beta, rot ? gamma : 0.0, c, s, t);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const double gi = g[I][k], gj = g[J][k];
+        g[I][k] = c * gi - s * gj;
+        g[J][k] = s * gi + c * gj;
+        const double vi = v[I][k], vj = v[J][k];
+        v[I][k] = c * vi - s * vj;
+        v[J][k] = s * vi + c * vj;
+    }
+    return rot;
+}
+
+template <int N, int I, int J>
+SFM_DEVICE bool hestenes_sweep_from(double (&g)[N][N], double (&v)[N][N]) {
+    bool any = hestenes_rotate<N, I, J>(g, v);
+    if constexpr (J + 1 < N) any |= hestenes_sweep_from<N, I, J + 1>(g, v);
+    else if constexpr (I + 2 < N) any |= hestenes_sweep_from<N, I + 1, I + 2>(g, v);
+    return any;
+}
+
+template <int N>
+SFM_DEVICE void hestenes_svd(double (&g)[N][N], double (&v)[N][N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[i][k] = (i == k) ? 1.0 : 0.0;
+#pragma unroll 1
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        const bool rotated = hestenes_sweep_from<N, 0, 1>(g, v);
+        if (!__any(rotated)) break;
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// Right singular vector of the smallest singular value of a 4x4 matrix given by rows.
+// Replaces `np.linalg.svd(A)[2][-1]` of reference triangulation.py:34-35 (sign is irrelevant: the
+// caller divides by the last component).
+// --------------------------------------------------------------------------------------------------
+SFM_DEVICE void null_vector4(const double rows[4][4], double x[4]) {
+    double g[4][4], v[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) g[c][r] = rows[r][c];
+    hestenes_svd<4>(g, v);
+    double best = 0.0;
+    double n2[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        n2[c] = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) n2[c] += g[c][r] * g[c][r];
+    }
+    best = n2[0];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = v[0][k];
+#pragma unroll
+    for (int c = 1; c < 4; ++c) {
+        const bool smaller = n2[c] < best;
+        best = smaller ? n2[c] : best;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[k] = smaller ? v[c][k] : x[k];
+    }
+}
+
+// DLT triangulation of one pair (reference triangulation.py:9-39).  P1, P2: rows 0..2 of the camera
+// matrices, 4 columns each (row-major 12 doubles).  X = null(A)[:3] / null(A)[3], unguarded.
+SFM_DEVICE void triangulate_dlt(const double* P1, const double* P2, double xa, double ya, double xb,
+                                double yb, double X[3]) {
+    double A[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        A[0][k] = ya * P1[8 + k] - P1[4 + k];
+        A[1][k] = P1[k] - xa * P1[8 + k];
+        A[2][k] = yb * P2[8 + k] - P2[4 + k];
+        A[3][k] = P2[k] - xb * P2[8 + k];
+    }
+    double x[4];
+    null_vector4(A, x);
+    X[0] = x[0] / x[3];
+    X[1] = x[1] / x[3];
+    X[2] = x[2] / x[3];
+}
+
+// --------------------------------------------------------------------------------------------------
+// Philox-4x32-10 (Salmon et al., SC'11), bit-identical to oracle/sfm_oracle.py::philox4x32_10.
+// --------------------------------------------------------------------------------------------------
+SFM_DEVICE void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int round = 0; round < 10; ++round) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+
+// First 8 positions of a Fisher-Yates shuffle of range(n) for hypothesis h (sparse bookkeeping of the
+// at most 8 displaced positions).  Draw k: j = k + ((u_k * (n-k)) >> 32).
+SFM_DEVICE void philox_sample8(uint64_t seed, uint64_t h, uint32_t n, int32_t out[8]) {
+    uint32_t u[8];
+    {
+        uint32_t c[4] = {(uint32_t)h, (uint32_t)(h >> 32), 0u, 0u};
+        philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+        u[0] = c[0]; u[1] = c[1]; u[2] = c[2]; u[3] = c[3];
+        uint32_t d[4] = {(uint32_t)h, (uint32_t)(h >> 32), 1u, 0u};
+        philox4x32_10(d, (uint32_t)seed, (uint32_t)(seed >> 32));
+        u[4] = d[0]; u[5] = d[1]; u[6] = d[2]; u[7] = d[3];
+    }
+    uint32_t dpos[8], dval[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t j = (uint32_t)k + (uint32_t)(((uint64_t)u[k] * (uint64_t)(n - (uint32_t)k)) >> 32);
+        uint32_t vj = j, vk = (uint32_t)k;
+#pragma unroll
+        for (int m = 0; m < k; ++m) {
+            vj = (dpos[m] == j) ? dval[m] : vj;
+            vk = (dpos[m] == (uint32_t)k) ? dval[m] : vk;
+        }
+        out[k] = (int32_t)vj;
+        dpos[k] = j;
+        dval[k] = vk;
+    }
+}
+
+// 64-lane butterfly reductions with a fixed combination order (deterministic, no atomics).
+SFM_DEVICE double wave_sum(double x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+    return x;
+}
+SFM_DEVICE int wave_sum(int x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+    return x;
+}
+
+}  // namespace sfm

@@ -1,0 +1,260 @@
+"""Device plumbing: torch ROCm tensors for memory and streams, ctypes calls into libsfm_hip.so.
+
+Nothing here computes on the CPU.  Every wrapper only enqueues work on the current torch HIP stream;
+host synchronisation happens where a caller reads a result back (``.cpu()`` / ``read_select``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import random as _pyrandom
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _native
+from ._native import SelectResult, check
+
+F64 = torch.float64
+SELECT_BYTES = C.sizeof(SelectResult)
+assert SELECT_BYTES == 40
+
+
+def require_gpu() -> torch.device:
+    """The hot path has no CPU fallback: fail loudly without a ROCm device or the HIP library."""
+    _native.load()
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "structure_from_motion_amd: no ROCm GPU visible; the RANSAC / triangulation hot path "
+            "only runs as HIP kernels on MI355X (there is no CPU fallback)."
+        )
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device wrappers need contiguous ROCm tensors"
+    return t.data_ptr()
+
+
+def to_device(array, dtype=F64) -> torch.Tensor:
+    dev = require_gpu()
+    return torch.as_tensor(np.ascontiguousarray(array), dtype=dtype).to(dev)
+
+
+# ------------------------------------------------------------------------------------------------------
+# thin wrappers, one per C-ABI entry point
+# ------------------------------------------------------------------------------------------------------
+def normalize_correspondences(pix_a: torch.Tensor, pix_b: torch.Tensor, K, out=None) -> torch.Tensor:
+    """pix_a, pix_b: [..., 2] f64 on device -> corr [..., 4]."""
+    lib = _native.load()
+    count = pix_a.numel() // 2
+    assert pix_a.shape == pix_b.shape and pix_a.shape[-1] == 2
+    if out is None:
+        out = torch.empty(pix_a.shape[:-1] + (4,), dtype=F64, device=pix_a.device)
+    fx, fy, cx, cy = float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2])
+    check(lib.sfm_normalize_correspondences(_ptr(pix_a), _ptr(pix_b), count, fx, fy, cx, cy, _ptr(out),
+                                            _stream()), "sfm_normalize_correspondences")
+    return out
+
+
+def sample_philox(seed: int, h_begin: int, h_count: int, n: int, batch: int = 1, seed_stride: int = 1,
+                  out=None, device=None) -> torch.Tensor:
+    lib = _native.load()
+    if out is None:
+        out = torch.empty((batch, h_count, 8), dtype=torch.int32, device=device or require_gpu())
+    check(lib.sfm_sample_philox(seed & (2**64 - 1), seed_stride, h_begin, h_count, n, batch, _ptr(out),
+                                _stream()), "sfm_sample_philox")
+    return out
+
+
+def fit_eight_point(corr: torch.Tensor, S: torch.Tensor, E=None, flags=None, lambda2=None):
+    """corr [B,N,4], S [B,H,8] -> E [B,H,9], flags [B,H]."""
+    lib = _native.load()
+    B, N, _ = corr.shape
+    H = S.shape[1]
+    assert S.shape == (B, H, 8) and S.dtype == torch.int32
+    if E is None:
+        E = torch.empty((B, H, 9), dtype=F64, device=corr.device)
+    if flags is None:
+        flags = torch.empty((B, H), dtype=torch.int32, device=corr.device)
+    check(lib.sfm_fit_eight_point(_ptr(corr), N, _ptr(S), H, B, _ptr(E), _ptr(flags), _ptr(lambda2),
+                                  _stream()), "sfm_fit_eight_point")
+    return E, flags
+
+
+def score_sed(corr: torch.Tensor, E: torch.Tensor, S: torch.Tensor, thr: float, cnt=None, s1=None,
+              s2=None):
+    lib = _native.load()
+    B, N, _ = corr.shape
+    H = E.shape[1]
+    if cnt is None:
+        cnt = torch.empty((B, H), dtype=torch.int32, device=corr.device)
+    if s1 is None:
+        s1 = torch.empty((B, H), dtype=F64, device=corr.device)
+    if s2 is None:
+        s2 = torch.empty((B, H), dtype=F64, device=corr.device)
+    check(lib.sfm_score_sed(_ptr(corr), N, _ptr(E), _ptr(S), H, B, float(thr), _ptr(cnt), _ptr(s1),
+                            _ptr(s2), _stream()), "sfm_score_sed")
+    return cnt, s1, s2
+
+
+def select_best(cnt, s1, s2, flags, min_extra: float, aggregation: int, h_offset: int = 0, out=None):
+    """-> int64 tensor [B,5] viewing the sfm_select_result records."""
+    lib = _native.load()
+    B, H = cnt.shape
+    if out is None:
+        out = torch.empty((B, SELECT_BYTES // 8), dtype=torch.int64, device=cnt.device)
+    check(lib.sfm_select_best(_ptr(cnt), _ptr(s1), _ptr(s2), _ptr(flags), H, B, float(min_extra),
+                              int(aggregation), h_offset, _ptr(out), _stream()), "sfm_select_best")
+    return out
+
+
+def inlier_mask(corr, E, S, result, thr: float, out=None):
+    lib = _native.load()
+    B, N, _ = corr.shape
+    H = E.shape[1]
+    if out is None:
+        out = torch.empty((B, N), dtype=torch.uint8, device=corr.device)
+    check(lib.sfm_inlier_mask(_ptr(corr), N, _ptr(E), _ptr(S), H, B, _ptr(result), float(thr), _ptr(out),
+                              _stream()), "sfm_inlier_mask")
+    return out
+
+
+def read_select(result: torch.Tensor) -> List[SelectResult]:
+    """Copy the select records to the host (synchronises)."""
+    raw = result.cpu().numpy().tobytes()
+    return [SelectResult.from_buffer_copy(raw[i * SELECT_BYTES:(i + 1) * SELECT_BYTES])
+            for i in range(result.shape[0])]
+
+
+def sed_values(corr: torch.Tensor, E: torch.Tensor) -> torch.Tensor:
+    lib = _native.load()
+    n = corr.shape[0]
+    out = torch.empty((n,), dtype=F64, device=corr.device)
+    check(lib.sfm_sed_values(_ptr(corr), n, _ptr(E), _ptr(out), _stream()), "sfm_sed_values")
+    return out
+
+
+def cheirality(corr: torch.Tensor, pose_rt: torch.Tensor, distance_threshold: float) -> torch.Tensor:
+    lib = _native.load()
+    m = corr.shape[0]
+    poses = pose_rt.shape[0]
+    out = torch.empty((poses, m), dtype=torch.uint8, device=corr.device)
+    check(lib.sfm_cheirality(_ptr(corr), m, _ptr(pose_rt), poses, float(distance_threshold), _ptr(out),
+                             _stream()), "sfm_cheirality")
+    return out
+
+
+def triangulate(corr: torch.Tensor, P1: torch.Tensor, P2: torch.Tensor) -> torch.Tensor:
+    lib = _native.load()
+    m = corr.shape[0]
+    out = torch.empty((m, 3), dtype=F64, device=corr.device)
+    check(lib.sfm_triangulate(_ptr(corr), m, _ptr(P1), _ptr(P2), _ptr(out), _stream()), "sfm_triangulate")
+    return out
+
+
+def decompose_essential(E: torch.Tensor):
+    """E [B,9] -> pose_rt [B,4,12] (rows R(9)|t(3) in the reference's candidate order), status [B]."""
+    lib = _native.load()
+    B = E.shape[0]
+    poses = torch.empty((B, 4, 12), dtype=F64, device=E.device)
+    status = torch.empty((B,), dtype=torch.int32, device=E.device)
+    check(lib.sfm_decompose_essential(_ptr(E), B, _ptr(poses), _ptr(status), _stream()),
+          "sfm_decompose_essential")
+    return poses, status
+
+
+# ------------------------------------------------------------------------------------------------------
+# host sampler: exact replay of the reference's cumulative random.shuffle (ransac.py:59-64)
+# ------------------------------------------------------------------------------------------------------
+def pyshuffle_table(n: int, iterations: int, rng=_pyrandom, snapshot_iteration: int = -1,
+                    advance: bool = True) -> Tuple[np.ndarray, Optional[np.ndarray]]:
+    """Sample table S[iterations, 8] the reference would draw from the current state of ``rng``
+    (the ``random`` module or a ``random.Random``), via the C++ MT19937 replay.  With ``advance`` the
+    generator state is advanced exactly as ``iterations`` calls of ``random.shuffle`` would.
+    Optionally also returns the full permutation after ``snapshot_iteration``."""
+    lib = _native.load()
+    version, internal, gauss = rng.getstate()
+    state = (C.c_uint32 * 624)(*internal[:624])
+    index = C.c_int32(internal[624])
+    S = np.empty((iterations, 8), dtype=np.int32)
+    snap = np.empty((n,), dtype=np.int32) if snapshot_iteration >= 0 else None
+    check(lib.sfm_pyshuffle_table(
+        C.cast(state, C.c_void_p), C.cast(C.byref(index), C.c_void_p), n, iterations,
+        S.ctypes.data_as(C.c_void_p), None, snapshot_iteration,
+        snap.ctypes.data_as(C.c_void_p) if snap is not None else None), "sfm_pyshuffle_table")
+    if advance:
+        rng.setstate((version, tuple(state) + (index.value,), gauss))
+    return S, snap
+
+
+# ------------------------------------------------------------------------------------------------------
+# the RANSAC engine: sample table -> fit -> score -> select -> mask, all enqueued on one stream
+# ------------------------------------------------------------------------------------------------------
+@dataclass
+class RansacOutcome:
+    best_h: int                # winning hypothesis (global index), -1 if none
+    error: float               # aggregated inlier error of the winner
+    E: Optional[np.ndarray]    # (3,3) essential matrix of the winner
+    sample: Optional[np.ndarray]   # (8,) indices of the winner's sample, in sample order
+    mask: Optional[np.ndarray]     # (N,) uint8: 1 survivor, 2 sample point, 0 outlier
+    n_flagged: int             # hypotheses whose sample was degenerate (eight_point.py:415-421)
+    first_flagged: int         # lowest such hypothesis index, or -1
+    extra_inliers: int
+
+
+class RansacWorkspace:
+    """Pre-allocated device buffers for B pairs x H hypotheses x N correspondences."""
+
+    def __init__(self, batch: int, n: int, h: int, device=None):
+        dev = device or require_gpu()
+        self.batch, self.n, self.h = batch, n, h
+        self.S = torch.empty((batch, h, 8), dtype=torch.int32, device=dev)
+        self.E = torch.empty((batch, h, 9), dtype=F64, device=dev)
+        self.flags = torch.empty((batch, h), dtype=torch.int32, device=dev)
+        self.cnt = torch.empty((batch, h), dtype=torch.int32, device=dev)
+        self.s1 = torch.empty((batch, h), dtype=F64, device=dev)
+        self.s2 = torch.empty((batch, h), dtype=F64, device=dev)
+        self.result = torch.empty((batch, SELECT_BYTES // 8), dtype=torch.int64, device=dev)
+        self.mask = torch.empty((batch, n), dtype=torch.uint8, device=dev)
+
+    def run(self, corr: torch.Tensor, thr: float, min_extra: float, aggregation: int,
+            h_offset: int = 0, with_mask: bool = True) -> None:
+        """fit + score + select (+ mask) for the sample table currently in ``self.S``."""
+        fit_eight_point(corr, self.S, self.E, self.flags)
+        score_sed(corr, self.E, self.S, thr, self.cnt, self.s1, self.s2)
+        select_best(self.cnt, self.s1, self.s2, self.flags, min_extra, aggregation, h_offset,
+                    self.result)
+        if with_mask:
+            assert h_offset == 0, "mask needs local hypothesis indices"
+            inlier_mask(corr, self.E, self.S, self.result, thr, self.mask)
+
+    def outcome(self, b: int = 0, h_offset: int = 0) -> RansacOutcome:
+        rec = read_select(self.result)[b]
+        first = -1 if rec.first_flagged == _native.INT64_MAX else int(rec.first_flagged)
+        if rec.best_h < 0:
+            return RansacOutcome(-1, float("inf"), None, None, None, int(rec.n_flagged), first, 0)
+        local = int(rec.best_h) - h_offset
+        E = self.E[b, local].cpu().numpy().reshape(3, 3).copy()
+        sample = self.S[b, local].cpu().numpy().astype(np.int64)
+        mask = self.mask[b].cpu().numpy().copy()
+        return RansacOutcome(int(rec.best_h), float(rec.best_err), E, sample, mask, int(rec.n_flagged),
+                             first, int(rec.best_cnt))
+
+
+def ransac_essential(corr: torch.Tensor, S, thr: float, min_extra: float, aggregation: int) -> RansacOutcome:
+    """One image pair: corr [N,4] on device, S [H,8] (numpy or tensor) -> RansacOutcome."""
+    n = corr.shape[0]
+    S_t = S if isinstance(S, torch.Tensor) else to_device(S, torch.int32)
+    h = S_t.shape[0]
+    ws = RansacWorkspace(1, n, h, corr.device)
+    ws.S.copy_(S_t.reshape(1, h, 8))
+    ws.run(corr.reshape(1, n, 4), thr, min_extra, aggregation)
+    return ws.outcome(0)

@@ -1,0 +1,265 @@
+"""CPU tests of the host side: C-ABI exports, the exact random.shuffle replay, the generic RANSAC driver,
+the boundary value types, and the "fail loudly without a GPU" contract.  No kernel is launched."""
+import ctypes as C
+import os
+import random
+import re
+from functools import partial
+from math import isclose, sqrt
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_exported(native_lib):
+    """Every function include/sfm_hip.h declares is exported by libsfm_hip.so and bound in _native."""
+    from structure_from_motion_amd import _native
+
+    header = open(os.path.join(REPO, "include", "sfm_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(sfm_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 12
+    bound = set(_native.SIGNATURES) | set(_native.OTHER_SYMBOLS)
+    assert declared == bound, declared ^ bound
+    for name in declared:
+        assert getattr(native_lib, name) is not None
+    assert native_lib.sfm_abi_version() == _native.ABI_VERSION
+    assert C.sizeof(_native.SelectResult) == 40
+
+
+def test_argument_validation_without_gpu(native_lib):
+    """Bad sizes are rejected before any HIP call (safe on a CPU-only box)."""
+    assert native_lib.sfm_sample_philox(1, 1, 0, 10, 7, 1, None, None) == -1
+    assert b"n" in native_lib.sfm_last_error()
+    assert native_lib.sfm_fit_eight_point(None, 5, None, 4, 1, None, None, None, None) == -1
+    assert native_lib.sfm_score_sed(None, -1, None, None, 4, 1, 0.0, None, None, None, None) == -1
+    assert native_lib.sfm_select_best(None, None, None, None, 4, 1, 0.0, 9, 0, None, None) == -1
+    # empty work is a successful no-op
+    assert native_lib.sfm_triangulate(None, 0, None, None, None, None) == 0
+    assert native_lib.sfm_cheirality(None, 0, None, 4, 50.0, None, None) == 0
+
+
+@pytest.mark.parametrize("n,iters,seed", [(10, 100, 5), (75, 30, 0), (2, 10, 1), (1, 3, 2), (1000, 7, 123456789)])
+def test_pyshuffle_replay_matches_cpython(native_lib, n, iters, seed):
+    from structure_from_motion_amd import device
+
+    rng = random.Random(seed)
+    rng.random()  # move off the freshly seeded state (index != 624)
+    twin = random.Random()
+    twin.setstate(rng.getstate())
+    S, snap = device.pyshuffle_table(n, iters, rng, snapshot_iteration=iters // 2)
+    perm = list(range(n))
+    for it in range(iters):
+        twin.shuffle(perm)
+        np.testing.assert_array_equal(S[it][:min(n, 8)], perm[:8])
+        if it == iters // 2:
+            np.testing.assert_array_equal(snap, perm)
+    assert rng.getstate() == twin.getstate()  # generator advanced exactly as CPython would
+    if n < 8:
+        assert (S[:, n:] == -1).all()
+
+
+def test_pyshuffle_replay_uses_global_random(native_lib):
+    from structure_from_motion_amd import device
+
+    random.seed(5)
+    S, _ = device.pyshuffle_table(10, 100)
+    after = random.random()
+    d = np.load(os.path.join(REPO, "tests", "golden", "g2_ransac_seed5.npz"))
+    np.testing.assert_array_equal(S, d["S"])  # the samples the real reference drew after random.seed(5)
+    random.seed(5)
+    p = list(range(10))
+    for _ in range(100):
+        random.shuffle(p)
+    assert random.random() == after
+    random.seed(5)
+    S2, _ = device.pyshuffle_table(10, 100, advance=False)
+    p = list(range(10))
+    random.shuffle(p)
+    np.testing.assert_array_equal(S2[0], p[:8])  # state was not advanced
+
+
+# ------------------------------------------------------------------------------------------------------
+# generic driver (reference lib/ransac/tests/test_ransac.py)
+# ------------------------------------------------------------------------------------------------------
+def line_fitter_2d(points):
+    if np.allclose(points[0], points[1]):
+        raise ValueError("Cannot fit line on the same two points.")
+    if len(points) != 2:
+        raise ValueError(f"Two points are needed for line fitting, got {len(points)}.")
+    dx = points[1][0] - points[0][0]
+    if abs(dx) <= 1e-6:
+        return (1.0, 0.0, -points[0][0])
+    slope = (points[1][1] - points[0][1]) / dx
+    return (slope, -1.0, points[0][1] - slope * points[0][0])
+
+
+def line_scorer_2d(model, point):
+    return abs(model[0] * point[0] + model[1] * point[1] + model[2]) / sqrt(model[0] ** 2 + model[1] ** 2)
+
+
+def test_ransac_line_fit_equals_reference(golden):
+    """test_ransac.py:70-123 — and bit-equal to what the real reference returned (golden g10)."""
+    from lib.ransac import ransac
+
+    d = golden("g10_line_ransac")
+    all_points_list = list(d["points"])
+    snapshot = d["points"].copy()
+    random.seed(5)
+    model, inliers = ransac.fit_with_ransac(
+        data=all_points_list, model_fit_data_count=2, model_fitter=line_fitter_2d,
+        inlier_scorer=line_scorer_2d, inlier_threshold=0.2,
+        min_num_extra_inliers=len(all_points_list) / 2,  # a float, as in the reference test
+        error_aggregation_method=ransac.ErrorAggregationMethod.RMS)
+    inliers = np.array(inliers)
+    assert 0 <= len(inliers) - 50 <= 3
+    assert isclose(0.6, -model[0] / model[1], rel_tol=0, abs_tol=1e-7)
+    assert isclose(-np.sign(model[1]) * (5 - 4 * 0.6), model[2])
+    np.testing.assert_array_equal(np.array(model), d["model"])
+    np.testing.assert_array_equal(inliers, d["inliers"])
+    np.testing.assert_array_equal(np.array(all_points_list), snapshot)  # input not mutated
+
+
+def test_ransac_defaults_and_failure():
+    from lib.ransac import ransac
+
+    pts = [np.array([float(i), 2.0 * i]) for i in range(20)]
+    random.seed(0)
+    model, inliers = ransac.fit_with_ransac(pts, 2, line_fitter_2d, line_scorer_2d, 1e-9)
+    assert len(inliers) == 20 and isclose(-model[0] / model[1], 2.0)
+    with pytest.raises(ValueError, match="No model could be found with at least 102 inliers"):
+        ransac.fit_with_ransac(pts, 2, line_fitter_2d, line_scorer_2d, 1e-9, min_num_extra_inliers=100)
+    with pytest.raises(ValueError):
+        ransac.fit_with_ransac(pts, 2, line_fitter_2d, line_scorer_2d, 1e-9, max_iterations=0)
+
+    def nan_scorer(model, p):
+        return float("nan")
+
+    with pytest.raises(ValueError):  # NaN errors never win (ransac.py:83)
+        ransac.fit_with_ransac(pts, 2, line_fitter_2d, nan_scorer, 1.0)
+
+    def boom(points):
+        raise KeyError("fitter failure aborts the call")
+
+    with pytest.raises(KeyError):
+        ransac.fit_with_ransac(pts, 2, boom, line_scorer_2d, 1.0)
+
+
+def test_aggregate_error_modes():
+    from lib.ransac.ransac import ErrorAggregationMethod, _aggregate_error
+
+    e = [1.0, 2.0, 3.0, 4.0]
+    assert _aggregate_error(e, ErrorAggregationMethod.SUM) == 10.0
+    assert _aggregate_error(e, ErrorAggregationMethod.SQUARE) == 30.0
+    assert _aggregate_error(e, ErrorAggregationMethod.MEAN) == 2.5
+    assert _aggregate_error(e, ErrorAggregationMethod.RMS) == sqrt(7.5)
+    assert [m.value for m in ErrorAggregationMethod] == ["sum", "square", "mean", "rms"]
+
+
+def test_device_route_detection():
+    from structure_from_motion_amd.epipolar import epipolar_ransac as er
+    from structure_from_motion_amd.ransac import ransac
+
+    K = np.eye(3)
+    fit = partial(er.eight_point_model_fitter, camera_matrix=K)
+    score = partial(er.calculate_sed_inlier_score, camera_matrix=K)
+    assert np.array_equal(ransac._device_spec(fit, score, 8), K)
+    assert ransac._device_spec(fit, score, 7) is None
+    assert ransac._device_spec(line_fitter_2d, line_scorer_2d, 8) is None
+    assert ransac._device_spec(fit, partial(er.calculate_sed_inlier_score, camera_matrix=2 * K), 8) is None
+    assert ransac._device_spec(fit, partial(line_scorer_2d), 8) is None
+
+
+# ------------------------------------------------------------------------------------------------------
+# fail loudly without a GPU / library
+# ------------------------------------------------------------------------------------------------------
+def test_numeric_entry_points_fail_loudly_without_gpu(native_lib):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from lib.common.feature import Feature
+    from lib.epipolar import eight_point, epipolar_ransac
+    from lib.epipolar.sed import calculate_symmetric_epipolar_distance
+    from lib.epipolar.triangulation import triangulate_points
+    from lib.transforms.transforms import Transform3D
+
+    fa = [Feature(float(i), float(i * i % 7)) for i in range(10)]
+    m = eight_point.create_trivial_matches(10)
+    K = np.array([[50.0, 0, 256], [0, 50.0, 128], [0, 0, 1]])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        epipolar_ransac.estimate_essential_mat_with_ransac(K, fa, fa, m, 0.01)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        eight_point.estimate_fundamental_mat(fa, fa, m[:8])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        eight_point.recover_r_t_from_e(np.eye(3), K, fa, fa)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        triangulate_points(fa, fa, K, Transform3D.identity())
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        calculate_symmetric_epipolar_distance(fa[0], fa[1], np.eye(3))
+
+
+def test_missing_library_is_an_error(monkeypatch, tmp_path):
+    from structure_from_motion_amd import _native
+
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_native.NativeLibraryError, match="no CPU fallback"):
+        _native.load()
+
+
+def test_product_code_does_not_import_the_oracle():
+    pkg = os.path.join(REPO, "structure_from_motion_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(root, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text, f
+                assert "/root/reference" not in text, f
+    for f in os.listdir(os.path.join(REPO, "lib")):
+        pass
+
+
+# ------------------------------------------------------------------------------------------------------
+# boundary value types (reference a20)
+# ------------------------------------------------------------------------------------------------------
+def test_value_types():
+    from lib.common.feature import Feature
+    from lib.feature_matching.matching import Match
+    from lib.transforms.transforms import Transform3D
+    from lib.epipolar.eight_point import create_trivial_matches, to_normalized_image_coords
+
+    f = Feature(1.0, 2.0)
+    f.x = 3.0
+    assert f == Feature(3.0, 2.0) and Feature(x=1, y=2).y == 2
+    m = Match()
+    assert (m.a_index, m.b_index, m.match_score) == (-1, -1, np.inf)
+    assert Match(1, 2, 0.1) < Match(3, 4, 0.2) and not (Match(1, 2, 0.3) < Match(3, 4, 0.2))
+    tm = create_trivial_matches(3)
+    assert [(x.a_index, x.b_index, x.match_score) for x in tm] == [(0, 0, 0.0), (1, 1, 0.0), (2, 2, 0.0)]
+    K = np.array([[50.0, 0, 256], [0, 40.0, 128], [0, 0, 1]])
+    nf = to_normalized_image_coords(Feature(x=50, y=60), K)
+    expect = np.linalg.inv(K) @ np.array([50.0, 60.0, 1.0])
+    np.testing.assert_allclose([nf.x, nf.y], expect[:2])
+
+    R = np.array([[0.0, -1, 0], [1, 0, 0], [0, 0, 1]])
+    T = Transform3D.from_rmat_t(R, np.array([[1.0], [2.0], [3.0]]))  # column vector is reshaped
+    np.testing.assert_array_equal(T.t, [1, 2, 3])
+    np.testing.assert_array_equal(T.Rmat, R)
+    assert T.Tmat.shape == (4, 4) and T.Tmat[3].tolist() == [0, 0, 0, 1]
+    T.t = np.array([4.0, 5.0, 6.0])
+    assert T.Tmat[0, 3] == 4.0
+    np.testing.assert_allclose((T @ T.inv()).Tmat, np.eye(4), atol=1e-15)
+    np.testing.assert_array_equal((T * Transform3D.identity()).Tmat, T.Tmat)
+    np.testing.assert_array_equal(Transform3D.from_rmat_t().Tmat, np.eye(4))
+    assert str(T).startswith("Homogeneous transformation(")
+    with pytest.raises(ValueError):
+        Transform3D(np.eye(3))
+    with pytest.raises(ValueError):
+        Transform3D.from_rmat_t(np.eye(4))
+    with pytest.raises(ValueError):
+        Transform3D.from_rmat_t(np.eye(3), np.zeros(4))
+    with pytest.raises(TypeError):
+        T * 3
