@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Benchmark of the RANSAC essential-matrix hot path on MI355X.
+
+Metric (BASELINE.json): correspondence-evaluations/s = matches x hypotheses / wall time of one RANSAC
+pass (sample -> eight-point fit -> SED scoring -> selection -> inlier mask), inputs resident in HBM.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload: the configuration the north-star target is quoted on — 50 000 correspondences x 100 000
+hypotheses per GPU (BASELINE.json configs[2]); with N GPUs every rank processes its own 100 000
+hypotheses of one global Philox stream (weak scaling) and one 16-byte RCCL exchange per step picks the
+global best model.  One JSON line on stdout (rank 0).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+BYTES_PER_EVAL = 32.0          # xa, ya, xb, yb as f64, read once per hypothesis
+HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); ~6290 measured-achievable
+THR, MIN_EXTRA = 1.5e-6, 10    # reference apps/config/config.yaml:6-9 (RMS aggregation)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--matches", type=int, default=50_000)
+    ap.add_argument("--hypotheses", type=int, default=100_000, help="per GPU")
+    ap.add_argument("--seed", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration")
+    return ap.parse_args()
+
+
+def cpu_baseline(corr: np.ndarray, seed: int, target_seconds: float):
+    """Times the CPU oracle (numpy eight-point fit + plain-C/OpenMP SED scoring + numpy selection) on a
+    bounded number of hypotheses of the same workload.  The oracle is only the thing timed here."""
+    from oracle import sfm_oracle as orc
+
+    subprocess.run(["make", "-s", "-C", os.path.join(REPO, "oracle")], check=True)
+    lib = C.CDLL(os.path.join(REPO, "oracle", "libsfm_oracle.so"))
+    lib.sfm_oracle_score.restype = C.c_int
+    lib.sfm_oracle_score.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_double,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    n = corr.shape[0]
+    # a 1-GPU box's CPU share is 16 cores even when the host exposes more hardware threads
+    threads = int(os.environ.get("SFM_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16)))
+
+    def run(h):
+        t0 = time.perf_counter()
+        S = orc.philox_sample_table(seed, 0, h, n)
+        E, deg, _ = orc.fit_hypotheses(corr, S)
+        E = np.ascontiguousarray(E.reshape(h, 9))
+        cnt = np.zeros(h, dtype=np.int32)
+        s1 = np.zeros(h)
+        s2 = np.zeros(h)
+        used = lib.sfm_oracle_score(corr.ctypes.data, n, E.ctypes.data, S.ctypes.data, h, THR,
+                                    cnt.ctypes.data, s1.ctypes.data, s2.ctypes.data, threads)
+        best, err = orc.select_best(orc.aggregate(cnt, s1, s2, orc.RMS), cnt, MIN_EXTRA)
+        return time.perf_counter() - t0, used, best
+
+    probe_h = 256
+    t_probe, used, _ = run(probe_h)
+    h = int(max(probe_h, min(100_000, probe_h * target_seconds / max(t_probe, 1e-3))))
+    t, used, best = run(h)
+    return {
+        "value": n * h / t,
+        "unit": "correspondence-evals/s",
+        "cores": used,
+        "kind": "port",
+        "sample": f"{h} of the hypotheses x {n} matches, {t:.1f} s: numpy eight-point fit (1 thread) + "
+                  f"C/OpenMP SED scoring ({used} threads) + numpy selection",
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from structure_from_motion_amd import device, distributed, synthetic
+    from structure_from_motion_amd._native import AGG_RMS
+
+    device.require_gpu()
+    n, h = args.matches, args.hypotheses
+    pa, pb, K, *_ = synthetic.two_view_scene(n, seed=6)
+    corr = device.normalize_correspondences(device.to_device(pa), device.to_device(pb), K)
+    engine = distributed.ShardedRansac(corr, h, THR, MIN_EXTRA, AGG_RMS, rank, world)
+
+    # the dominant kernel (SED scoring) is bracketed with events on the stream it is launched on
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    score = device.score_sed
+    state = {"i": -1}
+
+    def timed_score(*a, **k):
+        i = state["i"]
+        if i >= 0:
+            ev[i][0].record()
+        out = score(*a, **k)
+        if i >= 0:
+            ev[i][1].record()
+        return out
+
+    device.score_sed = timed_score
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for w in range(args.warmup):
+        engine.step(args.seed + w)
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        state["i"] = s
+        engine.step(args.seed + 1000 + s)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    state["i"] = -1
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.cpu()[0])
+
+    best_h, err, E, sample, mask = engine.outcome()
+    score_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
+    evals_per_gpu = float(n) * float(h)
+    value = evals_per_gpu * world * args.steps / elapsed
+    achieved = evals_per_gpu * BYTES_PER_EVAL / (score_ms * 1e-3) / 1e9 if score_ms > 0 else None
+
+    if rank == 0:
+        line = {
+            "metric": "correspondence-evals/s (matches x hypotheses)",
+            "value": value,
+            "unit": "correspondence-evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"synthetic two-view, {n} correspondences x {h} RANSAC hypotheses per GPU "
+                            "(BASELINE.json configs[2]; the configuration the north-star target is quoted on)",
+                "matches": n, "hypotheses_per_gpu": h, "global_hypotheses": h * world,
+                "sed_inlier_threshold": THR, "min_num_extra_inliers": MIN_EXTRA, "aggregation": "rms",
+                "sampler": "philox", "parallelism": f"hypothesis-shard x{world}",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "score_sed_kernel",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                "traffic": None,
+                "kernel_ms": score_ms,
+                "note": "achieved = 32 B/eval x matches x hypotheses / avg score-kernel time (HIP events); "
+                        "the 1.6 MB correspondence set is L2-resident, so physical HBM traffic is far lower "
+                        "and the kernel is fp64-VALU bound (DESIGN.md)",
+            },
+            "result": {"best_h": best_h, "error": err, "inliers": int((mask != 0).sum()) if mask is not None else 0},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            corr_host = corr.cpu().numpy()
+            line["cpu_baseline"] = cpu_baseline(corr_host, args.seed, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

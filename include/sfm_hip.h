@@ -62,6 +62,12 @@ int sfm_normalize_correspondences(const double* pix_a, const double* pix_b, int6
 int sfm_sample_philox(uint64_t seed, uint64_t seed_stride, int64_t h_begin, int64_t h_count, int64_t n,
                       int64_t batch, int32_t* S, void* stream);
 
+/* Same sampler for ONE hypothesis per batch entry whose index is read from device memory:
+ * S[b,:] = sample of hypothesis h_index[b] (0..7 if h_index[b] < 0).  Lets the multi-GPU winner be
+ * re-derived on every rank without a host round trip.  h_index: dev int64 [batch]; S: dev int32 [batch,8]. */
+int sfm_sample_philox_at(uint64_t seed, uint64_t seed_stride, const int64_t* h_index, int64_t n,
+                         int64_t batch, int32_t* S, void* stream);
+
 /* Normalised eight-point fit of every hypothesis (epipolar_ransac.py:28-42 -> eight_point.py:136-170).
  * corr: dev [batch,n,4]; S: dev int32 [batch,h_count,8]; E: dev [batch,h_count,9] (row-major 3x3,
  * E[8] == 1); flags: dev int32 [batch,h_count]; lambda2: optional dev [batch,h_count] receiving the

@@ -77,6 +77,21 @@ __global__ void sample_philox_kernel(uint64_t seed, uint64_t seed_stride, int64_
     dst[1] = make_int4(idx[4], idx[5], idx[6], idx[7]);
 }
 
+// Re-derive the sample of one given hypothesis per batch entry (index read from device memory, so the
+// multi-GPU winner can be finalised without a host round trip).  Negative index -> 0..7.
+__global__ void sample_philox_at_kernel(uint64_t seed, uint64_t seed_stride,
+                                        const int64_t* __restrict__ h_index, uint32_t n, int64_t batch,
+                                        int32_t* __restrict__ S) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const int64_t h = h_index[b];
+    int32_t idx[8] = {0, 1, 2, 3, 4, 5, 6, 7};
+    if (h >= 0) sfm::philox_sample8(seed + (uint64_t)b * seed_stride, (uint64_t)h, n, idx);
+    int4* dst = reinterpret_cast<int4*>(S + b * 8);
+    dst[0] = make_int4(idx[0], idx[1], idx[2], idx[3]);
+    dst[1] = make_int4(idx[4], idx[5], idx[6], idx[7]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Eight-point fit: one lane per hypothesis (all 64 lanes of a wave busy), everything in registers.
 // ------------------------------------------------------------------------------------------------
@@ -624,6 +639,17 @@ int sfm_sample_philox(uint64_t seed, uint64_t seed_stride, int64_t h_begin, int6
     hipLaunchKernelGGL(sample_philox_kernel, dim3(grid_for(h_count, 256), (unsigned)batch), dim3(256), 0,
                        (hipStream_t)stream, seed, seed_stride, h_begin, h_count, (uint32_t)n, S);
     return check_launch("sample_philox_kernel");
+}
+
+int sfm_sample_philox_at(uint64_t seed, uint64_t seed_stride, const int64_t* h_index, int64_t n,
+                         int64_t batch, int32_t* S, void* stream) {
+    if (batch < 0) return fail(SFM_EINVAL, "sfm_sample_philox_at: negative size");
+    if (n < 8 || n > 0x7FFFFFFF) return fail(SFM_EINVAL, "sfm_sample_philox_at: need 8 <= n < 2^31");
+    if (batch == 0) return SFM_OK;
+    if (!S || !h_index) return fail(SFM_EINVAL, "sfm_sample_philox_at: null pointer");
+    hipLaunchKernelGGL(sample_philox_at_kernel, dim3(grid_for(batch, 64)), dim3(64), 0, (hipStream_t)stream,
+                       seed, seed_stride, h_index, (uint32_t)n, batch, S);
+    return check_launch("sample_philox_at_kernel");
 }
 
 int sfm_fit_eight_point(const double* corr, int64_t n, const int32_t* S, int64_t h_count, int64_t batch,

@@ -74,6 +74,17 @@ def sample_philox(seed: int, h_begin: int, h_count: int, n: int, batch: int = 1,
     return out
 
 
+def sample_philox_at(seed: int, h_index: torch.Tensor, n: int, seed_stride: int = 1, out=None) -> torch.Tensor:
+    """h_index: int64 [B] on device -> S [B,1,8]: the sample of hypothesis h_index[b] (no host sync)."""
+    lib = _native.load()
+    B = h_index.shape[0]
+    if out is None:
+        out = torch.empty((B, 1, 8), dtype=torch.int32, device=h_index.device)
+    check(lib.sfm_sample_philox_at(seed & (2**64 - 1), seed_stride, _ptr(h_index), n, B, _ptr(out),
+                                   _stream()), "sfm_sample_philox_at")
+    return out
+
+
 def fit_eight_point(corr: torch.Tensor, S: torch.Tensor, E=None, flags=None, lambda2=None):
     """corr [B,N,4], S [B,H,8] -> E [B,H,9], flags [B,H]."""
     lib = _native.load()

@@ -1,0 +1,116 @@
+"""Multi-GPU RANSAC: hypotheses shard across ranks, one tiny exchange picks the global best model.
+
+One process per GPU (``torch.distributed``; backend "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU for
+tests).  Rank r fits and scores hypotheses ``[r*H, (r+1)*H)`` of the global counter-based sample stream
+against its own replica of the correspondences (32 B x N, at most a few MB); the only data-path
+exchange is 16 bytes per rank:
+
+    key  = all_reduce(MIN) of the winner's error bits   (non-negative f64 bits are monotone as int64;
+                                                         "no model" is INT64_MAX)
+    h    = all_reduce(MIN) of the winner's global index, masked to ranks whose key equals the global key
+
+which reproduces the sequential rule "strictly lower error wins, earliest first" (reference
+``lib/ransac/ransac.py:83``) for any sharding.  Every rank then re-derives the winner locally
+(``finalize``): the sample is a pure function of (seed, h), so no E / mask broadcast is needed.
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import torch
+import torch.distributed as dist
+
+from ._native import INT64_MAX
+
+NO_MODEL_KEY = INT64_MAX
+
+
+def reduce_best(key: torch.Tensor, best_h: torch.Tensor, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """key, best_h: int64 tensors of equal shape (one entry per image pair) holding this rank's winner
+    (``sfm_select_result.key`` / ``.best_h`` with global indices; best_h = -1 and key = INT64_MAX if the
+    rank found no model).  Returns the global (key, best_h), identical on every rank."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return key.clone(), best_h.clone()
+    gkey = key.clone()
+    dist.all_reduce(gkey, op=dist.ReduceOp.MIN, group=group)
+    sentinel = torch.full_like(best_h, INT64_MAX)
+    cand = torch.where((key == gkey) & (best_h >= 0), best_h, sentinel)
+    dist.all_reduce(cand, op=dist.ReduceOp.MIN, group=group)
+    gbest = torch.where(cand == sentinel, torch.full_like(cand, -1), cand)
+    return gkey, gbest
+
+
+def reduce_flagged(first_flagged: torch.Tensor, n_flagged: torch.Tensor, group=None):
+    """Global (lowest flagged hypothesis index, number of flagged hypotheses) so that every rank raises
+    the same EightPointCalculationError."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return first_flagged.clone(), n_flagged.clone()
+    first = first_flagged.clone()
+    dist.all_reduce(first, op=dist.ReduceOp.MIN, group=group)
+    total = n_flagged.clone()
+    dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+    return first, total
+
+
+def shard_range(total_hypotheses: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block of hypothesis indices owned by ``rank``: (begin, count)."""
+    per = -(-total_hypotheses // world)
+    begin = min(total_hypotheses, rank * per)
+    return begin, max(0, min(total_hypotheses, begin + per) - begin)
+
+
+class ShardedRansac:
+    """RANSAC-E over ``world`` GPUs: rank r owns hypotheses [r*H, (r+1)*H) of the Philox stream.
+
+    ``step`` enqueues sample -> fit -> score -> select on the local shard, the 16-byte exchange, and the
+    local re-derivation of the global winner (sample, E, inlier mask) — no host synchronisation.
+    """
+
+    def __init__(self, corr: torch.Tensor, hypotheses_per_rank: int, thr: float, min_extra: float,
+                 aggregation: int, rank: int = 0, world: int = 1, group=None):
+        from . import device
+
+        self.device_api = device
+        self.corr = corr.reshape(1, -1, 4)
+        self.n = self.corr.shape[1]
+        self.h = hypotheses_per_rank
+        self.thr, self.min_extra, self.aggregation = thr, min_extra, aggregation
+        self.rank, self.world, self.group = rank, world, group
+        dev = corr.device
+        self.ws = device.RansacWorkspace(1, self.n, self.h, dev)
+        # winner re-derivation buffers (one hypothesis)
+        self.win_S = torch.empty((1, 1, 8), dtype=torch.int32, device=dev)
+        self.win_E = torch.empty((1, 1, 9), dtype=torch.float64, device=dev)
+        self.win_flags = torch.empty((1, 1), dtype=torch.int32, device=dev)
+        self.win_record = torch.zeros((1, 5), dtype=torch.int64, device=dev)
+        self.global_key = torch.empty((1,), dtype=torch.int64, device=dev)
+        self.global_best = torch.empty((1,), dtype=torch.int64, device=dev)
+
+    def step(self, seed: int) -> None:
+        d = self.device_api
+        begin = self.rank * self.h
+        d.sample_philox(seed, begin, self.h, self.n, out=self.ws.S)
+        single = self.world == 1
+        self.ws.run(self.corr, self.thr, self.min_extra, self.aggregation, h_offset=begin,
+                    with_mask=False)
+        key, best = self.ws.result[:, 0].contiguous(), self.ws.result[:, 1].contiguous()
+        gkey, gbest = (key, best) if single else reduce_best(key, best, self.group)
+        self.global_key.copy_(gkey)
+        self.global_best.copy_(gbest)
+        # every rank re-derives the winner from (seed, h*): same code path -> bit-identical E
+        d.sample_philox_at(seed, self.global_best, self.n, out=self.win_S)
+        d.fit_eight_point(self.corr, self.win_S, self.win_E, self.win_flags)
+        self.win_record[:, 0] = gkey
+        self.win_record[:, 1] = torch.where(gbest >= 0, torch.zeros_like(gbest), gbest)
+        d.inlier_mask(self.corr, self.win_E, self.win_S, self.win_record, self.thr, self.ws.mask)
+
+    def outcome(self):
+        """Host copy of the global winner (synchronises): (best_h, error, E (3,3), sample, mask)."""
+        import numpy as np
+
+        best = int(self.global_best.cpu()[0])
+        if best < 0:
+            return -1, float("inf"), None, None, None
+        err = float(self.global_key.view(torch.float64).cpu()[0])
+        E = self.win_E.cpu().numpy().reshape(3, 3)
+        return best, err, E, self.win_S.cpu().numpy().reshape(8).astype(np.int64), self.ws.mask.cpu().numpy()[0]

@@ -107,8 +107,13 @@ def test_estimate_essential_mat_with_ransac(golden):
     np.testing.assert_almost_equal(d["E_gt"], e, decimal=5)
     assert rel(e, d["E"]) <= 1e-6
     assert len(inlier_feature_pairs) == len(d["inlier_a"])
-    np.testing.assert_array_equal(np.array([[p[0].x, p[0].y] for p in inlier_feature_pairs]), d["inlier_a"])
-    np.testing.assert_array_equal(np.array([[p[1].x, p[1].y] for p in inlier_feature_pairs]), d["inlier_b"])
+    # This fixture is noise-free: the inliers' SEDs are ~1e-30 (pure rounding), so WHICH of the equivalent
+    # all-inlier samples wins is decided by rounding noise and only the inlier *set* is well defined
+    # (the ordered list is pinned on the noisy fixture in test_ransac_per_method_equals_reference).
+    got_a = np.array(sorted([p[0].x, p[0].y] for p in inlier_feature_pairs))
+    got_b = np.array(sorted([p[1].x, p[1].y] for p in inlier_feature_pairs))
+    np.testing.assert_array_equal(got_a, np.array(sorted(d["inlier_a"].tolist())))
+    np.testing.assert_array_equal(got_b, np.array(sorted(d["inlier_b"].tolist())))
     # the returned pairs are copies, inputs untouched (ransac.py:59 deepcopy)
     assert all(p[0] is not f for p in inlier_feature_pairs for f in features_1)
     # the global random state advanced exactly as 100 reference shuffles would
@@ -288,7 +293,17 @@ def test_sfm_call_sequence():
     ref = orc.ransac_essential(corr, S, 1.5e-6, 10, orc.RMS)
     assert rel(e, ref["E"]) <= 1e-6
     assert len(inlier_feature_pairs) == len(ref["inliers"])
-    # pose is right up to noise; scale-free translation
-    np.testing.assert_allclose(r, R_gt, atol=2e-2)
-    np.testing.assert_allclose(t, t_gt / np.linalg.norm(t_gt), atol=5e-2)
+    # pose and structure against the oracle on the same inliers (sample first, then shuffled survivors)
+    inl = np.array([[p[0].x, p[0].y, p[1].x, p[1].y] for p in inlier_feature_pairs])
+    corr_inl = orc.pack_correspondences(orc.to_normalized_image_coords(inl[:, 0:2], K),
+                                        orc.to_normalized_image_coords(inl[:, 2:4], K))
+    R_o, t_o, mask_o, _ = orc.recover_r_t(corr_inl, ref["E"])
+    np.testing.assert_allclose(r, R_o, atol=1e-6)
+    np.testing.assert_allclose(t, t_o, atol=1e-6)
+    np.testing.assert_array_equal(inlier_mask, mask_o)
+    T = np.eye(4)
+    T[:3, :3] = R_o
+    T[:3, 3] = t_o
+    pts_o = orc.triangulate_points(inl[mask_o, 0:2], inl[mask_o, 2:4], K, T)
+    assert np.max(np.abs(pts - pts_o) / np.linalg.norm(pts_o, axis=1, keepdims=True)) <= 1e-6
     assert np.median(pts[:, 2]) > 0

@@ -226,3 +226,19 @@ def test_c_oracle_matches_numpy_oracle(c_oracle):
     vals = np.zeros(n)
     c_oracle.sfm_oracle_sed_values(corr.ctypes.data, n, E_c[3].ctypes.data, vals.ctypes.data)
     np.testing.assert_array_equal(vals, orc.sed_values(E[3], corr))
+
+
+def test_oracle_fit_against_multiprecision():
+    """The LAPACK-based oracle fit agrees with a 40-digit evaluation of the same algorithm."""
+    from oracle.fit_mp import fit_eight_point_mp
+
+    n, h = 500, 24
+    pa, pb, K, *_ = orc.synthetic_two_view(n, seed=6)
+    corr = orc.pack_correspondences(orc.to_normalized_image_coords(pa, K), orc.to_normalized_image_coords(pb, K))
+    S = orc.philox_sample_table(7, 0, h, n)
+    E, deg, lam2 = orc.fit_hypotheses(corr, S)
+    for i in range(h):
+        truth, lam_true = fit_eight_point_mp(corr[S[i]][:, 0:2], corr[S[i]][:, 2:4])
+        # null-vector conditioning ~ eps * lambda_max / lambda_2 (lambda_max ~ 10 after Hartley scaling)
+        assert np.max(np.abs(E[i] - truth)) / np.max(np.abs(truth)) <= 1e-13 * max(100.0, 100.0 / lam_true)
+        assert abs(lam2[i] - lam_true) <= 1e-13
