@@ -28,6 +28,10 @@ if REPO not in sys.path:
 
 BYTES_PER_EVAL = 32.0          # xa, ya, xb, yb as f64, read once per hypothesis
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); ~6290 measured-achievable
+# secondary (real) bound of the scoring kernel: fp64 VALU issue.  68 VALU wave-instructions per
+# evaluation (ISA count) against 256 CU x 4 SIMD x 16 fp64 lanes/clk x 2.4 GHz.
+VALU_INSTR_PER_EVAL = 68.0
+FP64_VALU_PEAK = 256 * 4 * 16 * 2.4e9
 THR, MIN_EXTRA = 1.5e-6, 10    # reference apps/config/config.yaml:6-9 (RMS aggregation)
 
 
@@ -58,9 +62,8 @@ def cpu_baseline(corr: np.ndarray, seed: int, target_seconds: float):
     # a 1-GPU box's CPU share is 16 cores even when the host exposes more hardware threads
     threads = int(os.environ.get("SFM_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16)))
 
-    def run(h):
-        t0 = time.perf_counter()
-        S = orc.philox_sample_table(seed, 0, h, n)
+    def run(h, h_begin):
+        S = orc.philox_sample_table(seed, h_begin, h, n)
         E, deg, _ = orc.fit_hypotheses(corr, S)
         E = np.ascontiguousarray(E.reshape(h, 9))
         cnt = np.zeros(h, dtype=np.int32)
@@ -69,20 +72,38 @@ def cpu_baseline(corr: np.ndarray, seed: int, target_seconds: float):
         used = lib.sfm_oracle_score(corr.ctypes.data, n, E.ctypes.data, S.ctypes.data, h, THR,
                                     cnt.ctypes.data, s1.ctypes.data, s2.ctypes.data, threads)
         best, err = orc.select_best(orc.aggregate(cnt, s1, s2, orc.RMS), cnt, MIN_EXTRA)
-        return time.perf_counter() - t0, used, best
+        return used, err
 
-    probe_h = 256
-    t_probe, used, _ = run(probe_h)
-    h = int(max(probe_h, min(100_000, probe_h * target_seconds / max(t_probe, 1e-3))))
-    t, used, best = run(h)
+    run(64, 0)  # warm the caches / thread pool
+    chunk, done, used = 10_000, 0, 1
+    t0 = time.perf_counter()
+    while True:
+        used, _ = run(chunk, done)
+        done += chunk
+        elapsed = time.perf_counter() - t0
+        if elapsed >= target_seconds or done >= 2_000_000:
+            break
     return {
-        "value": n * h / t,
+        "value": n * done / elapsed,
         "unit": "correspondence-evals/s",
         "cores": used,
         "kind": "port",
-        "sample": f"{h} of the hypotheses x {n} matches, {t:.1f} s: numpy eight-point fit (1 thread) + "
-                  f"C/OpenMP SED scoring ({used} threads) + numpy selection",
+        "sample": f"{done} hypotheses x {n} matches of the same workload in {elapsed:.1f} s: numpy eight-point "
+                  f"fit (1 thread) + C/OpenMP SED scoring ({used} threads) + numpy selection",
     }
+
+
+def measured_traffic(n, h):
+    """HBM bytes per score-kernel launch from the committed rocprofv3 PMC passes (profiles/), if they were
+    taken on this workload: 2 x FETCH_SIZE (gfx950 counts 128-B requests as 64 B) + WRITE_SIZE."""
+    path = os.path.join(REPO, "profiles", "score_traffic.json")
+    try:
+        rec = json.load(open(path))
+    except OSError:
+        return None
+    if rec.get("matches") != n or rec.get("hypotheses") != h:
+        return None
+    return (2.0 * rec["fetch_size_kib"] + rec["write_size_kib"]) * 1024.0
 
 
 def main():
@@ -178,7 +199,11 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                "traffic": None,
+                "traffic": measured_traffic(n, h),
+                "traffic_unit": "bytes per launch (rocprofv3 PMC: 2 x FETCH_SIZE + WRITE_SIZE, profiles/)",
+                "algorithmic_bytes": evals_per_gpu * BYTES_PER_EVAL,
+                "valu_frac": (evals_per_gpu * VALU_INSTR_PER_EVAL / (score_ms * 1e-3)) / FP64_VALU_PEAK
+                if score_ms > 0 else None,
                 "kernel_ms": score_ms,
                 "note": "achieved = 32 B/eval x matches x hypotheses / avg score-kernel time (HIP events); "
                         "the 1.6 MB correspondence set is L2-resident, so physical HBM traffic is far lower "

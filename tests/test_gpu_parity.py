@@ -384,3 +384,41 @@ def test_triangulate_large_vs_oracle(dev):
     got = dev.triangulate(dev.to_device(orc.pack_correspondences(pa, pb)), dev.to_device((K_ext @ np.eye(4)).reshape(12)),
                           dev.to_device((K_ext @ T).reshape(12))).cpu().numpy()
     assert np.max(np.abs(got - want) / np.linalg.norm(want, axis=1, keepdims=True)) <= 1e-9
+
+
+# ------------------------------------------------------------------------------------------------------
+# sharding: G virtual shards on one GPU through the sharded engine == one run over all hypotheses
+# ------------------------------------------------------------------------------------------------------
+def test_virtual_shards_equal_single_run(dev):
+    from structure_from_motion_amd import distributed
+    from structure_from_motion_amd._native import AGG_RMS, INT64_MAX
+
+    n, h, G, seed = 1500, 400, 4, 21
+    _, _, _, corr = scene(n)
+    corr_d = dev.to_device(corr)
+    whole = distributed.ShardedRansac(corr_d, h * G, 1.5e-6, 10, AGG_RMS, rank=0, world=1)
+    whole.step(seed)
+    want = whole.outcome()
+    keys, bests = [], []
+    for r in range(G):
+        shard = distributed.ShardedRansac(corr_d, h, 1.5e-6, 10, AGG_RMS, rank=r, world=1)
+        shard.rank = r  # hypotheses [r*h, (r+1)*h) of the same Philox stream
+        shard.step(seed)
+        keys.append(int(shard.ws.result[0, 0].cpu()))
+        bests.append(int(shard.ws.result[0, 1].cpu()))
+    # the two MIN reductions of distributed.reduce_best, done by hand over the virtual ranks
+    gkey = min(keys)
+    gbest = min([b for k, b in zip(keys, bests) if k == gkey and b >= 0] or [-1])
+    assert gbest == want[0]
+    assert np.int64(gkey).view(np.float64) == want[1]
+    # re-derivation of the winner from (seed, h*) gives the same E / sample / mask on any rank
+    any_rank = distributed.ShardedRansac(corr_d, h, 1.5e-6, 10, AGG_RMS, rank=3, world=1)
+    any_rank.global_best.fill_(gbest)
+    d = dev
+    d.sample_philox_at(seed, any_rank.global_best, n, out=any_rank.win_S)
+    d.fit_eight_point(any_rank.corr, any_rank.win_S, any_rank.win_E, any_rank.win_flags)
+    np.testing.assert_array_equal(any_rank.win_E.cpu().numpy().reshape(3, 3), want[2])
+    np.testing.assert_array_equal(any_rank.win_S.cpu().numpy().reshape(8), want[3])
+    ref = orc.ransac_essential(corr, orc.philox_sample_table(seed, 0, h * G, n), 1.5e-6, 10, orc.RMS)
+    assert ref["best"] == want[0]
+    np.testing.assert_array_equal(np.nonzero(want[4])[0], np.sort(ref["inliers"]))
