@@ -78,9 +78,14 @@ int sfm_fit_eight_point(const double* corr, int64_t n, const int32_t* S, int64_t
 /* Symmetric-epipolar-distance scoring of all n correspondences under all hypotheses
  * (ransac.py:66-82 with epipolar_ransac.py:18-25 / sed.py:7-30 as the scorer).
  * cnt[b,h] = #non-sample points with sed <= thr; s1 / s2 = sum of sed / sed^2 over the 8 sample points
- * plus those survivors.  cnt: dev int32 [batch,h_count]; s1, s2: dev [batch,h_count]. */
+ * plus those survivors.  cnt: dev int32 [batch,h_count]; s1, s2: dev [batch,h_count].
+ * workspace: dev scratch of at least sfm_score_workspace_bytes(n, batch) bytes, 16-byte aligned; it
+ * enables the two-tier kernel (conservative fp32 pre-filter + exact fp64 evaluation of the survivors;
+ * identical counts and inlier decisions).  NULL selects the all-fp64 kernel. */
+int64_t sfm_score_workspace_bytes(int64_t n, int64_t batch);
 int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t* S, int64_t h_count,
-                  int64_t batch, double thr, int32_t* cnt, double* s1, double* s2, void* stream);
+                  int64_t batch, double thr, int32_t* cnt, double* s1, double* s2, void* workspace,
+                  int64_t workspace_bytes, void* stream);
 
 /* Model selection (ransac.py:75-86): lowest aggregated error among hypotheses with
  * cnt >= min_extra, strict <, earliest index wins, NaN/inf never win.  result: dev [batch]. */

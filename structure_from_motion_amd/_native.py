@@ -14,7 +14,7 @@ SFM_OK = 0
 AGG_SUM, AGG_SQUARE, AGG_MEAN, AGG_RMS = 0, 1, 2, 3
 FIT_DEGENERATE = 1
 INT64_MAX = (1 << 63) - 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class SelectResult(C.Structure):
@@ -41,7 +41,7 @@ SIGNATURES = {
     "sfm_sample_philox": [_U64, _U64, _I64, _I64, _I64, _I64, _P, _P],
     "sfm_sample_philox_at": [_U64, _U64, _P, _I64, _I64, _P, _P],
     "sfm_fit_eight_point": [_P, _I64, _P, _I64, _I64, _P, _P, _P, _P],
-    "sfm_score_sed": [_P, _I64, _P, _P, _I64, _I64, _D, _P, _P, _P, _P],
+    "sfm_score_sed": [_P, _I64, _P, _P, _I64, _I64, _D, _P, _P, _P, _P, _I64, _P],
     "sfm_select_best": [_P, _P, _P, _P, _I64, _I64, _D, C.c_int, _I64, _P, _P],
     "sfm_inlier_mask": [_P, _I64, _P, _P, _I64, _I64, _P, _D, _P, _P],
     "sfm_sed_values": [_P, _I64, _P, _P, _P],
@@ -50,7 +50,7 @@ SIGNATURES = {
     "sfm_decompose_essential": [_P, _I64, _P, _P, _P],
     "sfm_pyshuffle_table": [_P, _P, _I64, _I64, _P, _P, _I64, _P],
 }
-OTHER_SYMBOLS = ["sfm_last_error", "sfm_abi_version"]
+OTHER_SYMBOLS = ["sfm_last_error", "sfm_abi_version", "sfm_score_workspace_bytes"]
 
 _lib = None
 
@@ -78,6 +78,8 @@ def load() -> C.CDLL:
     lib.sfm_last_error.argtypes = []
     lib.sfm_abi_version.restype = C.c_int
     lib.sfm_abi_version.argtypes = []
+    lib.sfm_score_workspace_bytes.restype = C.c_int64
+    lib.sfm_score_workspace_bytes.argtypes = [_I64, _I64]
     if lib.sfm_abi_version() != ABI_VERSION:
         raise NativeLibraryError(
             f"libsfm_hip.so ABI {lib.sfm_abi_version()} != expected {ABI_VERSION}; rebuild it")

@@ -15,33 +15,23 @@
 #include <stdio.h>
 #include <string.h>
 
-#include "../../include/sfm_hip.h"
+#include "sfm_common.h"
 #include "sfm_math.h"
+
+namespace sfmhost {
+char* error_buffer() {
+    static thread_local char buffer[kErrorBytes] = "";
+    return buffer;
+}
+}  // namespace sfmhost
 
 namespace {
 
-thread_local char g_error[512] = "";
+using sfmhost::check_launch;
+using sfmhost::fail;
+using sfmhost::grid_for;
 
-int fail(int code, const char* msg) {
-    snprintf(g_error, sizeof(g_error), "%s", msg);
-    return code;
-}
-
-int check_launch(const char* what) {
-    hipError_t err = hipGetLastError();
-    if (err != hipSuccess) {
-        snprintf(g_error, sizeof(g_error), "%s: %s", what, hipGetErrorString(err));
-        return SFM_EHIP;
-    }
-    return SFM_OK;
-}
-
-constexpr int kWave = 64;
 static_assert(sizeof(sfm_select_result) == 40, "sfm_select_result layout is part of the ABI");
-
-struct alignas(32) Corr {
-    double xa, ya, xb, yb;
-};
 
 // ------------------------------------------------------------------------------------------------
 // K-normalisation pre-pass: one thread per correspondence, 2x16 B in, 32 B out.
@@ -230,83 +220,6 @@ __global__ __launch_bounds__(kWave) void fit_eight_point_kernel(
         for (int k = 0; k < 9; ++k) out[k] = e[k] / e22;
         flags[b * h_count + h] = flag;
         if (lambda2 != nullptr) lambda2[b * h_count + h] = second;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// SED scoring: the H x N loop.  One wave owns HPW hypotheses (their E in scalar registers) and
-// streams all n correspondences; lane l takes points l, l+64, ...  Per-lane partial (count, sum,
-// sum of squares) are combined by a fixed-order butterfly, so results are run-to-run identical.
-// The 8 sample points are fixed up by lanes 0..7 afterwards: they are never counted, always summed.
-// ------------------------------------------------------------------------------------------------
-template <int HPW>
-__global__ __launch_bounds__(256) void score_sed_kernel(
-    const Corr* __restrict__ corr, int n, const double* __restrict__ E, const int32_t* __restrict__ S,
-    int h_count, double thr, int32_t* __restrict__ cnt, double* __restrict__ s1,
-    double* __restrict__ s2) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave));
-    const int h0 = wave * HPW;
-    if (h0 >= h_count) return;
-    const int64_t b = blockIdx.y;
-    const Corr* __restrict__ pts = corr + b * (int64_t)n;
-    const double* __restrict__ Eb = E + b * (int64_t)h_count * 9;
-    const int32_t* __restrict__ Sb = S + b * (int64_t)h_count * 8;
-
-    double e[HPW][9];
-#pragma unroll
-    for (int k = 0; k < HPW; ++k) {
-        const int h = min(h0 + k, h_count - 1);
-#pragma unroll
-        for (int j = 0; j < 9; ++j) e[k][j] = Eb[(int64_t)h * 9 + j];
-    }
-    int c[HPW];
-    double a1[HPW], a2[HPW];
-#pragma unroll
-    for (int k = 0; k < HPW; ++k) {
-        c[k] = 0;
-        a1[k] = 0.0;
-        a2[k] = 0.0;
-    }
-    for (int i = lane; i < n; i += kWave) {
-        const Corr p = pts[i];
-#pragma unroll
-        for (int k = 0; k < HPW; ++k) {
-            const double sed = sfm::sed_value(e[k], p.xa, p.ya, p.xb, p.yb);
-            const bool ok = sed <= thr;
-            c[k] += ok ? 1 : 0;
-            a1[k] += ok ? sed : 0.0;
-            a2[k] += ok ? sed * sed : 0.0;
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < HPW; ++k) {
-        int ck = sfm::wave_sum(c[k]);
-        double s1k = sfm::wave_sum(a1[k]);
-        double s2k = sfm::wave_sum(a2[k]);
-        const int h = h0 + k;
-        if (h < h_count) {
-            // sample fix-up: lanes 0..7 each re-score one sample point
-            int dc = 0;
-            double d1 = 0.0, d2 = 0.0;
-            if (lane < 8) {
-                const Corr p = pts[Sb[(int64_t)h * 8 + lane]];
-                const double sed = sfm::sed_value(e[k], p.xa, p.ya, p.xb, p.yb);
-                const bool counted = sed <= thr;  // already in (ck, s1k, s2k)
-                dc = counted ? -1 : 0;
-                d1 = counted ? 0.0 : sed;          // NaN / inf propagate: such a model never wins
-                d2 = counted ? 0.0 : sed * sed;
-            }
-            ck += sfm::wave_sum(dc);
-            s1k += sfm::wave_sum(d1);
-            s2k += sfm::wave_sum(d2);
-            if (lane == 0) {
-                const int64_t o = b * (int64_t)h_count + h;
-                cnt[o] = ck;
-                s1[o] = s1k;
-                s2[o] = s2k;
-            }
-        }
     }
 }
 
@@ -602,13 +515,6 @@ __global__ __launch_bounds__(kWave) void decompose_essential_kernel(const double
     }
 }
 
-inline unsigned grid_for(int64_t work, int block, int64_t cap = 1 << 20) {
-    int64_t g = (work + block - 1) / block;
-    if (g < 1) g = 1;
-    if (g > cap) g = cap;
-    return (unsigned)g;
-}
-
 }  // namespace
 
 // ==================================================================================================
@@ -616,8 +522,8 @@ inline unsigned grid_for(int64_t work, int block, int64_t cap = 1 << 20) {
 // ==================================================================================================
 extern "C" {
 
-const char* sfm_last_error(void) { return g_error; }
-int sfm_abi_version(void) { return 1; }
+const char* sfm_last_error(void) { return sfmhost::error_buffer(); }
+int sfm_abi_version(void) { return 2; }
 
 int sfm_normalize_correspondences(const double* pix_a, const double* pix_b, int64_t count, double fx,
                                   double fy, double cx, double cy, double* corr, void* stream) {
@@ -662,20 +568,6 @@ int sfm_fit_eight_point(const double* corr, int64_t n, const int32_t* S, int64_t
                        dim3(kWave), 0, (hipStream_t)stream, (const Corr*)corr, n, S, h_count, E, flags,
                        lambda2);
     return check_launch("fit_eight_point_kernel");
-}
-
-int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t* S, int64_t h_count,
-                  int64_t batch, double thr, int32_t* cnt, double* s1, double* s2, void* stream) {
-    if (h_count < 0 || batch < 0 || n < 0) return fail(SFM_EINVAL, "sfm_score_sed: negative size");
-    if (n > 0x7FFFFFFF || h_count > 0x3FFFFFFF) return fail(SFM_EINVAL, "sfm_score_sed: size too large");
-    if (h_count == 0 || batch == 0) return SFM_OK;
-    if (!corr || !E || !S || !cnt || !s1 || !s2) return fail(SFM_EINVAL, "sfm_score_sed: null pointer");
-    constexpr int HPW = 4;
-    const int64_t waves = (h_count + HPW - 1) / HPW;
-    hipLaunchKernelGGL(score_sed_kernel<HPW>, dim3(grid_for(waves, 4), (unsigned)batch), dim3(256), 0,
-                       (hipStream_t)stream, (const Corr*)corr, (int)n, E, S, (int)h_count, thr, cnt, s1,
-                       s2);
-    return check_launch("score_sed_kernel");
 }
 
 int sfm_select_best(const int32_t* cnt, const double* s1, const double* s2, const int32_t* flags,

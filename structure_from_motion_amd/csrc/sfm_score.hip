@@ -1,0 +1,390 @@
+// SED scoring of N correspondences under H hypotheses — the H x N loop of the RANSAC driver
+// (reference lib/ransac/ransac.py:66-82, scorer lib/epipolar/sed.py:7-30).
+//
+// Two kernels produce the same (count, sum, sum of squares) per hypothesis:
+//
+//   score_sed_exact_kernel     every evaluation in fp64 (68 VALU instructions each).  Used when the
+//                              caller passes no workspace, and as the cross-check of the other one.
+//
+//   score_sed_filtered_kernel  two tiers.  Tier 1 evaluates a CONSERVATIVE fp32 lower bound of the
+//                              SED for every (hypothesis, point) and rejects the pair only when the
+//                              bound proves sed > thr.  Survivors (about the inlier fraction, a few
+//                              percent for a typical hypothesis) are compacted through a per-wave LDS
+//                              ring and tier 2 evaluates them with exactly the fp64 routine of the
+//                              exact kernel.  Every point whose fp64 SED could be <= thr reaches
+//                              tier 2, so counts and inlier decisions are identical to the exact
+//                              kernel bit for bit; only the summation order of the two sums differs.
+//
+// Tier-1 bound (u = 2^-24; hats = values rounded to fp32; a = (xa, ya, 1), b = (xb, yb, 1)):
+//   r  = b^T E a has 9 terms; r32 is the fp32 FMA evaluation of the same bilinear form.  Each term
+//        carries <= 3 input roundings and <= 4 FMA roundings, so |r32 - r| <= gamma_7 * R with
+//        R = sum |E_jk||b_j||a_k| <= Emax * M,  M >= (|xb|+|yb|+1)(|xa|+|ya|+1) for every point of the
+//        data set.  The fp64 value r_fl of the exact path differs from r by <= 6 * 2^-53 * R.  With
+//        delta = 10 u Emax M (inflated for its own roundings):   |r_fl| >= s := |r32| - delta.
+//   la_j = (E a)_j : |la_j32 - la_j,fl| <= 5 u A_j,  A_j = |E_j0| Xa + |E_j1| Ya + |E_j2|, with Xa, Ya the
+//        data-set maxima of |xa|, |ya|.  Hence dA := (|la_0,32| + eta_a0)^2 + (|la_1,32| + eta_a1)^2 >= da_fl
+//        (eta = 6 u A).  Same for lb = E^T b and dB.
+//   sed_fl >= (1 - 5*2^-53) * r_fl^2 (1/da_fl + 1/db_fl) >= s^2 (dA + dB) / (dA dB).
+//   Reject  <=>  s > 0  and  s^2 (dA + dB) > T dA dB  and  T dA dB > 1e-30,  T = thr * (1 + 1e-5).
+//   The factor 1e-5 covers every rounding of the fp32 evaluation of both sides (< 30 u = 1.8e-6).
+//   NaN / inf / overflow / underflow anywhere make a comparison false (or the guard fail) and the
+//   pair goes to tier 2.  thr < 0 or NaN switches the filter off.
+//
+// Compiled with -ffp-contract=off; the fp32 tier spells its FMAs explicitly.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "sfm_common.h"
+#include "sfm_math.h"
+
+namespace {
+
+using sfmhost::check_launch;
+using sfmhost::fail;
+using sfmhost::grid_for;
+
+constexpr int kHypPerWave = 4;
+constexpr int kRing = 128;  // entries per (wave, hypothesis) ring; drained in groups of 64
+
+// ------------------------------------------------------------------------------------------------
+// Epilogue shared by both kernels: fixed-order wave reduction + sample fix-up + store.
+// The 8 sample points are never counted and always summed (ransac.py:70-79): the main loop treats them
+// like any other point, lanes 0..7 then re-score them exactly and patch the totals.
+// ------------------------------------------------------------------------------------------------
+SFM_DEVICE void finish_hypothesis(const Corr* __restrict__ pts, const int32_t* __restrict__ sample,
+                                  const double (&e)[9], double thr, int lane, int c, double a1, double a2,
+                                  int32_t* cnt_out, double* s1_out, double* s2_out) {
+    int ck = sfm::wave_sum(c);
+    double s1k = sfm::wave_sum(a1);
+    double s2k = sfm::wave_sum(a2);
+    int dc = 0;
+    double d1 = 0.0, d2 = 0.0;
+    if (lane < 8) {
+        const Corr p = pts[sample[lane]];
+        const double sed = sfm::sed_value(e, p.xa, p.ya, p.xb, p.yb);
+        const bool counted = sed <= thr;  // already in (ck, s1k, s2k)
+        dc = counted ? -1 : 0;
+        d1 = counted ? 0.0 : sed;  // NaN / inf propagate: such a model never wins
+        d2 = counted ? 0.0 : sed * sed;
+    }
+    ck += sfm::wave_sum(dc);
+    s1k += sfm::wave_sum(d1);
+    s2k += sfm::wave_sum(d2);
+    if (lane == 0) {
+        *cnt_out = ck;
+        *s1_out = s1k;
+        *s2_out = s2k;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Exact kernel: one wave owns HPW hypotheses (E in scalar registers) and streams all n points.
+// ------------------------------------------------------------------------------------------------
+template <int HPW>
+__global__ __launch_bounds__(256) void score_sed_exact_kernel(
+    const Corr* __restrict__ corr, int n, const double* __restrict__ E, const int32_t* __restrict__ S,
+    int h_count, double thr, int32_t* __restrict__ cnt, double* __restrict__ s1,
+    double* __restrict__ s2) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave =
+        __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave));
+    const int h0 = wave * HPW;
+    if (h0 >= h_count) return;
+    const int64_t b = blockIdx.y;
+    const Corr* __restrict__ pts = corr + b * (int64_t)n;
+    const double* __restrict__ Eb = E + b * (int64_t)h_count * 9;
+    const int32_t* __restrict__ Sb = S + b * (int64_t)h_count * 8;
+
+    double e[HPW][9];
+#pragma unroll
+    for (int k = 0; k < HPW; ++k) {
+        const int h = min(h0 + k, h_count - 1);
+#pragma unroll
+        for (int j = 0; j < 9; ++j) e[k][j] = Eb[(int64_t)h * 9 + j];
+    }
+    int c[HPW];
+    double a1[HPW], a2[HPW];
+#pragma unroll
+    for (int k = 0; k < HPW; ++k) {
+        c[k] = 0;
+        a1[k] = 0.0;
+        a2[k] = 0.0;
+    }
+    for (int i = lane; i < n; i += kWave) {
+        const Corr p = pts[i];
+#pragma unroll
+        for (int k = 0; k < HPW; ++k) {
+            const double sed = sfm::sed_value(e[k], p.xa, p.ya, p.xb, p.yb);
+            const bool ok = sed <= thr;
+            c[k] += ok ? 1 : 0;
+            a1[k] += ok ? sed : 0.0;
+            a2[k] += ok ? sed * sed : 0.0;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < HPW; ++k) {
+        const int h = h0 + k;
+        if (h < h_count) {  // wave-uniform
+            const int64_t o = b * (int64_t)h_count + h;
+            finish_hypothesis(pts, Sb + (int64_t)h * 8, e[k], thr, lane, c[k], a1[k], a2[k], cnt + o, s1 + o,
+                              s2 + o);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Workspace preparation for the filtered kernel: fp32 copy of the correspondences and the data-set
+// maxima of |xa|, |ya|, |xb|, |yb| (as fp32 bit patterns: non-negative floats order like unsigned ints).
+// Workspace layout: [batch x 4 uint32 maxima][batch x n float4].
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ inline int64_t workspace_bytes_for(int64_t n, int64_t batch) { return 16 * batch + 16 * n * batch; }
+
+__global__ void score_prepare_kernel(const Corr* __restrict__ corr, int64_t n, unsigned char* __restrict__ ws) {
+    const int64_t b = blockIdx.y;
+    const int64_t batch = gridDim.y;
+    const Corr* pts = corr + b * n;
+    uint32_t* maxima = reinterpret_cast<uint32_t*>(ws + 16 * b);
+    float4* out = reinterpret_cast<float4*>(ws + 16 * batch) + b * n;
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const Corr p = pts[i];
+        const float4 q = make_float4((float)p.xa, (float)p.ya, (float)p.xb, (float)p.yb);
+        out[i] = q;
+        // NaN coordinates: fmaxf ignores them; such points always fail the filter's comparisons and are
+        // decided by the exact tier.
+        m0 = fmaxf(m0, fabsf(q.x));
+        m1 = fmaxf(m1, fabsf(q.y));
+        m2 = fmaxf(m2, fabsf(q.z));
+        m3 = fmaxf(m3, fabsf(q.w));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        m0 = fmaxf(m0, __shfl_xor(m0, off, 64));
+        m1 = fmaxf(m1, __shfl_xor(m1, off, 64));
+        m2 = fmaxf(m2, __shfl_xor(m2, off, 64));
+        m3 = fmaxf(m3, __shfl_xor(m3, off, 64));
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        atomicMax(maxima + 0, __float_as_uint(m0));
+        atomicMax(maxima + 1, __float_as_uint(m1));
+        atomicMax(maxima + 2, __float_as_uint(m2));
+        atomicMax(maxima + 3, __float_as_uint(m3));
+    }
+}
+
+// Per-hypothesis constants of the fp32 filter (all wave-uniform).
+struct FilterConsts {
+    float e[9];        // E rounded to fp32
+    float delta;       // >= |r32 - r_fl|
+    float eta_a0, eta_a1, eta_b0, eta_b1;  // >= |l32 - l_fl| for the four line components used
+};
+
+SFM_DEVICE FilterConsts make_filter_consts(const double (&E)[9], float Xa, float Ya, float Xb, float Yb) {
+    constexpr float u = 5.9604644775390625e-08f;  // 2^-24
+    constexpr float up = 1.0f + 1e-5f;            // absorbs the roundings of these bound computations
+    FilterConsts f;
+    float emax = 0.f;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        f.e[j] = (float)E[j];
+        emax = fmaxf(emax, fabsf(f.e[j]));
+    }
+    // NaN anywhere in E must poison the bounds (fmaxf would drop it): add the entries' NaN-ness back.
+    const float poison = (f.e[0] + f.e[1] + f.e[2] + f.e[3] + f.e[4] + f.e[5] + f.e[6] + f.e[7] + f.e[8]) * 0.0f;
+    const float M = (Xa + Ya + 1.0f) * (Xb + Yb + 1.0f);
+    f.delta = (10.0f * u) * emax * M * up + poison;
+    const float a0 = fabsf(f.e[0]) * Xa + fabsf(f.e[1]) * Ya + fabsf(f.e[2]);
+    const float a1 = fabsf(f.e[3]) * Xa + fabsf(f.e[4]) * Ya + fabsf(f.e[5]);
+    const float b0 = fabsf(f.e[0]) * Xb + fabsf(f.e[3]) * Yb + fabsf(f.e[6]);
+    const float b1 = fabsf(f.e[1]) * Xb + fabsf(f.e[4]) * Yb + fabsf(f.e[7]);
+    f.eta_a0 = (6.0f * u) * a0 * up + poison;
+    f.eta_a1 = (6.0f * u) * a1 * up + poison;
+    f.eta_b0 = (6.0f * u) * b0 * up + poison;
+    f.eta_b1 = (6.0f * u) * b1 * up + poison;
+    return f;
+}
+
+SFM_DEVICE float uniform(float x) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(x))); }
+
+// true => the pair provably has sed > thr in the exact fp64 evaluation
+SFM_DEVICE bool filter_rejects(const FilterConsts& f, float T, float xa, float ya, float xb, float yb) {
+    const float lb0 = fmaf(xb, f.e[0], fmaf(yb, f.e[3], f.e[6]));
+    const float lb1 = fmaf(xb, f.e[1], fmaf(yb, f.e[4], f.e[7]));
+    const float lb2 = fmaf(xb, f.e[2], fmaf(yb, f.e[5], f.e[8]));
+    const float r = fmaf(lb0, xa, fmaf(lb1, ya, lb2));
+    const float la0 = fmaf(f.e[0], xa, fmaf(f.e[1], ya, f.e[2]));
+    const float la1 = fmaf(f.e[3], xa, fmaf(f.e[4], ya, f.e[5]));
+    const float s = fabsf(r) - f.delta;
+    const float ua0 = fabsf(la0) + f.eta_a0;
+    const float ua1 = fabsf(la1) + f.eta_a1;
+    const float ub0 = fabsf(lb0) + f.eta_b0;
+    const float ub1 = fabsf(lb1) + f.eta_b1;
+    const float dA = fmaf(ua0, ua0, ua1 * ua1);
+    const float dB = fmaf(ub0, ub0, ub1 * ub1);
+    const float lhs = (s * s) * (dA + dB);
+    const float rhs = T * (dA * dB);
+    // bitwise '&': three compares and two s_and, no control flow
+    return (s > 0.0f) & (lhs > rhs) & (rhs > 1e-30f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Filtered kernel.
+// ------------------------------------------------------------------------------------------------
+template <int HPW>
+__global__ __launch_bounds__(256) void score_sed_filtered_kernel(
+    const Corr* __restrict__ corr, const unsigned char* __restrict__ ws, int n,
+    const double* __restrict__ E, const int32_t* __restrict__ S, int h_count, double thr,
+    int32_t* __restrict__ cnt, double* __restrict__ s1, double* __restrict__ s2) {
+    __shared__ int32_t ring[256 / kWave][HPW][kRing];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    const int wave = blockIdx.x * (256 / kWave) + wave_in_block;
+    const int h0 = wave * HPW;
+    if (h0 >= h_count) return;
+    const int64_t b = blockIdx.y;
+    const Corr* __restrict__ pts = corr + b * (int64_t)n;
+    const double* __restrict__ Eb = E + b * (int64_t)h_count * 9;
+    const int32_t* __restrict__ Sb = S + b * (int64_t)h_count * 8;
+    const uint32_t* maxima = reinterpret_cast<const uint32_t*>(ws + 16 * b);
+    const float4* __restrict__ pts32 = reinterpret_cast<const float4*>(ws + 16 * (int64_t)gridDim.y) + b * (int64_t)n;
+
+    // data-set coordinate maxima, inflated so they also bound the unrounded fp64 coordinates
+    const float Xa = __uint_as_float(maxima[0]) * (1.0f + 1e-6f);
+    const float Ya = __uint_as_float(maxima[1]) * (1.0f + 1e-6f);
+    const float Xb = __uint_as_float(maxima[2]) * (1.0f + 1e-6f);
+    const float Yb = __uint_as_float(maxima[3]) * (1.0f + 1e-6f);
+    // T = thr (1 + 1e-5), rounded up; a negative or NaN threshold switches the filter off
+    const float T = (thr >= 0.0) ? (float)(thr * (1.0 + 1e-5)) * (1.0f + 2e-7f) : INFINITY;
+
+    FilterConsts f[HPW];
+#pragma unroll
+    for (int k = 0; k < HPW; ++k) {
+        const int h = min(h0 + k, h_count - 1);
+        double e[9];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) e[j] = Eb[(int64_t)h * 9 + j];
+        f[k] = make_filter_consts(e, Xa, Ya, Xb, Yb);
+        // The four multiplier entries go to scalar registers (a VALU instruction takes ONE scalar operand
+        // for free); the five addend entries e2, e5, e6, e7, e8 and delta / eta stay in VGPRs as
+        // wave-uniform values: an FMA whose multiplier and addend were both scalar would need an extra
+        // v_mov, and the SGPR file (102) would be oversubscribed by 4 x 14 constants.
+        f[k].e[0] = uniform(f[k].e[0]);
+        f[k].e[1] = uniform(f[k].e[1]);
+        f[k].e[3] = uniform(f[k].e[3]);
+        f[k].e[4] = uniform(f[k].e[4]);
+    }
+
+    int c[HPW];
+    double a1[HPW], a2[HPW];
+    int head[HPW], tail[HPW];  // wave-uniform ring cursors (monotone; slots are taken modulo kRing)
+#pragma unroll
+    for (int k = 0; k < HPW; ++k) {
+        c[k] = 0;
+        a1[k] = 0.0;
+        a2[k] = 0.0;
+        head[k] = 0;
+        tail[k] = 0;
+    }
+
+    // tier 2: exact fp64 evaluation of `count` (<= 64) queued points of hypothesis k
+    auto drain = [&](int k, int count) __attribute__((always_inline)) {
+        const int h = min(h0 + k, h_count - 1);
+        double e[9];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) e[j] = Eb[(int64_t)h * 9 + j];
+        const bool active = lane < count;
+        const int slot = (head[k] + lane) & (kRing - 1);
+        const int idx = active ? ring[wave_in_block][k][slot] : 0;
+        const Corr p = pts[idx];
+        const double sed = sfm::sed_value(e, p.xa, p.ya, p.xb, p.yb);
+        const bool ok = active && (sed <= thr);
+        c[k] += ok ? 1 : 0;
+        a1[k] += ok ? sed : 0.0;
+        a2[k] += ok ? sed * sed : 0.0;
+        head[k] = __builtin_amdgcn_readfirstlane(head[k] + count);
+    };
+
+    const int chunks = (n + kWave - 1) / kWave;
+    for (int chunk = 0; chunk < chunks; ++chunk) {
+        const int i = chunk * kWave + lane;
+        const bool valid = i < n;
+        const float4 p = pts32[valid ? i : n - 1];
+#pragma unroll
+        for (int k = 0; k < HPW; ++k) {
+            const bool pass = valid && !filter_rejects(f[k], T, p.x, p.y, p.z, p.w);
+            const unsigned long long mask = __ballot(pass);
+            if (mask != 0ull) {  // wave-uniform
+                const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                             __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                if (pass) ring[wave_in_block][k][(tail[k] + before) & (kRing - 1)] = i;
+                tail[k] = __builtin_amdgcn_readfirstlane(tail[k] + (int)__popcll(mask));
+                __builtin_amdgcn_wave_barrier();
+                if (tail[k] - head[k] >= kWave) drain(k, kWave);  // wave-uniform
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < HPW; ++k) {
+        const int left = tail[k] - head[k];
+        if (left > 0) drain(k, left);
+    }
+
+#pragma unroll
+    for (int k = 0; k < HPW; ++k) {
+        const int h = h0 + k;
+        if (h < h_count) {  // wave-uniform
+            double e[9];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) e[j] = Eb[(int64_t)h * 9 + j];
+            const int64_t o = b * (int64_t)h_count + h;
+            finish_hypothesis(pts, Sb + (int64_t)h * 8, e, thr, lane, c[k], a1[k], a2[k], cnt + o, s1 + o, s2 + o);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t sfm_score_workspace_bytes(int64_t n, int64_t batch) {
+    if (n < 0 || batch < 0) return -1;
+    return workspace_bytes_for(n, batch);
+}
+
+int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t* S, int64_t h_count,
+                  int64_t batch, double thr, int32_t* cnt, double* s1, double* s2, void* workspace,
+                  int64_t workspace_bytes, void* stream) {
+    if (h_count < 0 || batch < 0 || n < 0) return fail(SFM_EINVAL, "sfm_score_sed: negative size");
+    if (n > 0x7FFFFFFF || h_count > 0x3FFFFFFF) return fail(SFM_EINVAL, "sfm_score_sed: size too large");
+    if (h_count == 0 || batch == 0) return SFM_OK;
+    if (!corr || !E || !S || !cnt || !s1 || !s2) return fail(SFM_EINVAL, "sfm_score_sed: null pointer");
+    if (n < 8) return fail(SFM_EINVAL, "sfm_score_sed: need at least 8 correspondences");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t waves = (h_count + kHypPerWave - 1) / kHypPerWave;
+    const dim3 grid(grid_for(waves, 256 / kWave), (unsigned)batch);
+    if (workspace == nullptr) {
+        hipLaunchKernelGGL(score_sed_exact_kernel<kHypPerWave>, grid, dim3(256), 0, st, (const Corr*)corr, (int)n,
+                           E, S, (int)h_count, thr, cnt, s1, s2);
+        return check_launch("score_sed_exact_kernel");
+    }
+    if (workspace_bytes < sfm_score_workspace_bytes(n, batch))
+        return fail(SFM_EINVAL, "sfm_score_sed: workspace smaller than sfm_score_workspace_bytes(n, batch)");
+    if ((reinterpret_cast<uintptr_t>(workspace) & 15u) != 0)
+        return fail(SFM_EINVAL, "sfm_score_sed: workspace must be 16-byte aligned");
+    unsigned char* ws = static_cast<unsigned char*>(workspace);
+    {
+        hipError_t err = hipMemsetAsync(ws, 0, 16 * batch, st);
+        if (err != hipSuccess) return fail(SFM_EHIP, hipGetErrorString(err));
+    }
+    hipLaunchKernelGGL(score_prepare_kernel, dim3(grid_for(n, 256, 256), (unsigned)batch), dim3(256), 0, st,
+                       (const Corr*)corr, n, ws);
+    int rc = check_launch("score_prepare_kernel");
+    if (rc != SFM_OK) return rc;
+    hipLaunchKernelGGL(score_sed_filtered_kernel<kHypPerWave>, grid, dim3(256), 0, st, (const Corr*)corr, ws,
+                       (int)n, E, S, (int)h_count, thr, cnt, s1, s2);
+    return check_launch("score_sed_filtered_kernel");
+}
+
+}  // extern "C"

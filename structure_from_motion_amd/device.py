@@ -6,6 +6,7 @@ host synchronisation happens where a caller reads a result back (``.cpu()`` / ``
 from __future__ import annotations
 
 import ctypes as C
+import os
 import random as _pyrandom
 from dataclasses import dataclass
 from typing import List, Optional, Tuple
@@ -100,8 +101,16 @@ def fit_eight_point(corr: torch.Tensor, S: torch.Tensor, E=None, flags=None, lam
     return E, flags
 
 
+def score_workspace(n: int, batch: int, device) -> torch.Tensor:
+    """Scratch buffer that enables the two-tier scoring kernel (see include/sfm_hip.h)."""
+    lib = _native.load()
+    return torch.empty((int(lib.sfm_score_workspace_bytes(n, batch)),), dtype=torch.uint8, device=device)
+
+
 def score_sed(corr: torch.Tensor, E: torch.Tensor, S: torch.Tensor, thr: float, cnt=None, s1=None,
-              s2=None):
+              s2=None, workspace: Optional[torch.Tensor] = None, exact_only: bool = False):
+    """Per-hypothesis (extra-inlier count, sum sed, sum sed^2).  Uses the two-tier kernel (fp32 pre-filter
+    + exact fp64) unless ``exact_only``; both give identical counts / decisions."""
     lib = _native.load()
     B, N, _ = corr.shape
     H = E.shape[1]
@@ -111,8 +120,13 @@ def score_sed(corr: torch.Tensor, E: torch.Tensor, S: torch.Tensor, thr: float, 
         s1 = torch.empty((B, H), dtype=F64, device=corr.device)
     if s2 is None:
         s2 = torch.empty((B, H), dtype=F64, device=corr.device)
+    if exact_only or os.environ.get("SFM_SCORE_KERNEL", "filtered") == "exact":
+        workspace = None
+    elif workspace is None:
+        workspace = score_workspace(N, B, corr.device)
     check(lib.sfm_score_sed(_ptr(corr), N, _ptr(E), _ptr(S), H, B, float(thr), _ptr(cnt), _ptr(s1),
-                            _ptr(s2), _stream()), "sfm_score_sed")
+                            _ptr(s2), _ptr(workspace), workspace.numel() if workspace is not None else 0,
+                            _stream()), "sfm_score_sed")
     return cnt, s1, s2
 
 
@@ -235,12 +249,13 @@ class RansacWorkspace:
         self.s2 = torch.empty((batch, h), dtype=F64, device=dev)
         self.result = torch.empty((batch, SELECT_BYTES // 8), dtype=torch.int64, device=dev)
         self.mask = torch.empty((batch, n), dtype=torch.uint8, device=dev)
+        self.score_ws = score_workspace(n, batch, dev)
 
     def run(self, corr: torch.Tensor, thr: float, min_extra: float, aggregation: int,
             h_offset: int = 0, with_mask: bool = True) -> None:
         """fit + score + select (+ mask) for the sample table currently in ``self.S``."""
         fit_eight_point(corr, self.S, self.E, self.flags)
-        score_sed(corr, self.E, self.S, thr, self.cnt, self.s1, self.s2)
+        score_sed(corr, self.E, self.S, thr, self.cnt, self.s1, self.s2, workspace=self.score_ws)
         select_best(self.cnt, self.s1, self.s2, self.flags, min_extra, aggregation, h_offset,
                     self.result)
         if with_mask:

@@ -422,3 +422,103 @@ def test_virtual_shards_equal_single_run(dev):
     ref = orc.ransac_essential(corr, orc.philox_sample_table(seed, 0, h * G, n), 1.5e-6, 10, orc.RMS)
     assert ref["best"] == want[0]
     np.testing.assert_array_equal(np.nonzero(want[4])[0], np.sort(ref["inliers"]))
+
+
+# ------------------------------------------------------------------------------------------------------
+# two-tier scoring kernel (fp32 pre-filter + exact fp64) against the all-fp64 kernel
+# ------------------------------------------------------------------------------------------------------
+def _score_both(dev, corr, E, S, thr):
+    n, h = corr.shape[0], E.shape[0]
+    args = (dev.to_device(corr).reshape(1, n, 4), dev.to_device(E.reshape(1, h, 9)),
+            dev.to_device(S, torch.int32).reshape(1, h, 8), thr)
+    exact = [t.cpu().numpy()[0] for t in dev.score_sed(*args, exact_only=True)]
+    filt = [t.cpu().numpy()[0] for t in dev.score_sed(*args)]
+    return exact, filt
+
+
+def _assert_same_scores(exact, filt):
+    np.testing.assert_array_equal(filt[0], exact[0])                      # counts: bit-exact
+    for a, b in ((filt[1], exact[1]), (filt[2], exact[2])):                # sums: summation order only
+        both_nan = np.isnan(a) & np.isnan(b)
+        np.testing.assert_allclose(a[~both_nan], b[~both_nan], rtol=1e-13, atol=0)
+
+
+@pytest.mark.parametrize("n,h", [(300, 64), (4099, 130), (20000, 515)])
+@pytest.mark.parametrize("thr", [1.5e-6, 1e-3, 0.0, 1e-12, 1e30, -1.0, float("nan"), float("inf")])
+def test_filtered_score_equals_exact(dev, n, h, thr):
+    _, _, _, corr = scene(n)
+    S = orc.philox_sample_table(13, 0, h, n)
+    E, _, _ = orc.fit_hypotheses(corr, S)
+    exact, filt = _score_both(dev, corr, E, S, thr)
+    _assert_same_scores(exact, filt)
+    if thr == 1.5e-6:
+        cnt_o, s1_o, s2_o = orc.score_hypotheses(corr, E, S, thr)
+        np.testing.assert_array_equal(filt[0], cnt_o)
+        np.testing.assert_allclose(filt[2], s2_o, rtol=1e-13)
+
+
+@pytest.mark.parametrize("scale", [1e-30, 1e-20, 1e-3, 1e3, 1e20, 1e36, 1e40, 1e150, 1e-150, 1e-300])
+def test_filtered_score_extreme_matrix_scales(dev, scale):
+    """SED is scale-free in E, but the fp32 tier over/underflows: every such pair must fall through to
+    the exact tier (same counts as the exact kernel at every scale)."""
+    n, h = 2000, 96
+    _, _, _, corr = scene(n)
+    S = orc.philox_sample_table(17, 0, h, n)
+    E, _, _ = orc.fit_hypotheses(corr, S)
+    exact, filt = _score_both(dev, corr, E * scale, S, 1.5e-6)
+    _assert_same_scores(exact, filt)
+
+
+def test_filtered_score_pixel_units_and_bad_matrices(dev):
+    """Un-normalised (pixel) coordinates -> large coordinate maxima; plus NaN / inf / zero matrices."""
+    n, h = 3000, 64
+    pa, pb, K, _ = scene(n)
+    corr = orc.pack_correspondences(pa, pb)
+    S = orc.philox_sample_table(19, 0, h, n)
+    F, _, _ = orc.fit_hypotheses(corr, S)
+    for thr in (1.0, 4.0, 1e-2):
+        _assert_same_scores(*_score_both(dev, corr, F, S, thr))
+    bad = F.copy()
+    bad[3] = np.nan
+    bad[4, 1, 1] = np.nan
+    bad[5] = np.inf
+    bad[6] = 0.0
+    bad[7, 0, 0] = np.inf
+    bad[8] = 1e-200
+    _assert_same_scores(*_score_both(dev, corr, bad, S, 1.0))
+    corr_nan = corr.copy()
+    corr_nan[17, 2] = np.nan
+    corr_nan[99] = np.inf
+    corr_nan[500] = 0.0
+    _assert_same_scores(*_score_both(dev, corr_nan, F, S, 1.0))
+
+
+def test_filtered_score_threshold_ties(dev):
+    """Thresholds placed exactly on a point's SED (<= is inclusive) and one ulp below."""
+    n, h = 1500, 32
+    _, _, _, corr = scene(n)
+    S = orc.philox_sample_table(23, 0, h, n)
+    E, _, _ = orc.fit_hypotheses(corr, S)
+    sed = orc.sed_values(E, corr)
+    rng = np.random.default_rng(0)
+    for _ in range(12):
+        k, i = rng.integers(0, h), rng.integers(0, n)
+        for thr in (sed[k, i], np.nextafter(sed[k, i], 0.0), np.nextafter(sed[k, i], np.inf)):
+            exact, filt = _score_both(dev, corr, E, S, float(thr))
+            _assert_same_scores(exact, filt)
+            cnt_o, _, _ = orc.score_hypotheses(corr, E, S, float(thr))
+            np.testing.assert_array_equal(filt[0], cnt_o)
+
+
+def test_filtered_score_full_size_equals_exact(dev):
+    """50k x 20k: the two kernels agree on every count."""
+    n, h = 50_000, 20_000
+    _, _, _, corr = scene(n)
+    corr_d = dev.to_device(corr).reshape(1, n, 4)
+    S = dev.sample_philox(5, 0, h, n)
+    E, _ = dev.fit_eight_point(corr_d, S)
+    exact = dev.score_sed(corr_d, E, S, 1.5e-6, exact_only=True)
+    filt = dev.score_sed(corr_d, E, S, 1.5e-6)
+    assert torch.equal(exact[0], filt[0])
+    torch.testing.assert_close(filt[1], exact[1], rtol=1e-13, atol=0, equal_nan=True)
+    torch.testing.assert_close(filt[2], exact[2], rtol=1e-13, atol=0, equal_nan=True)
