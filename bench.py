@@ -28,10 +28,6 @@ if REPO not in sys.path:
 
 BYTES_PER_EVAL = 32.0          # xa, ya, xb, yb as f64, read once per hypothesis
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); ~6290 measured-achievable
-# secondary (real) bound of the scoring kernel: fp64 VALU issue.  68 VALU wave-instructions per
-# evaluation (ISA count) against 256 CU x 4 SIMD x 16 fp64 lanes/clk x 2.4 GHz.
-VALU_INSTR_PER_EVAL = 68.0
-FP64_VALU_PEAK = 256 * 4 * 16 * 2.4e9
 THR, MIN_EXTRA = 1.5e-6, 10    # reference apps/config/config.yaml:6-9 (RMS aggregation)
 
 
@@ -194,7 +190,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "score_sed_kernel",
+                "kernel": "score_sed_filtered_kernel",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -202,12 +198,11 @@ def main():
                 "traffic": measured_traffic(n, h),
                 "traffic_unit": "bytes per launch (rocprofv3 PMC: 2 x FETCH_SIZE + WRITE_SIZE, profiles/)",
                 "algorithmic_bytes": evals_per_gpu * BYTES_PER_EVAL,
-                "valu_frac": (evals_per_gpu * VALU_INSTR_PER_EVAL / (score_ms * 1e-3)) / FP64_VALU_PEAK
-                if score_ms > 0 else None,
+                "kernel_variant": os.environ.get("SFM_SCORE_KERNEL", "filtered"),
                 "kernel_ms": score_ms,
                 "note": "achieved = 32 B/eval x matches x hypotheses / avg score-kernel time (HIP events); "
-                        "the 1.6 MB correspondence set is L2-resident, so physical HBM traffic is far lower "
-                        "and the kernel is fp64-VALU bound (DESIGN.md)",
+                        "the correspondence set (1.6 MB f64 + 0.8 MB f32 copy) is L2-resident, so physical HBM "
+                        "traffic is far lower and the kernel is VALU-issue bound (DESIGN.md)",
             },
             "result": {"best_h": best_h, "error": err, "inliers": int((mask != 0).sum()) if mask is not None else 0},
         }

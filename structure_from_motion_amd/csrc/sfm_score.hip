@@ -22,10 +22,11 @@
 //        data set.  The fp64 value r_fl of the exact path differs from r by <= 6 * 2^-53 * R.  With
 //        delta = 10 u Emax M (inflated for its own roundings):   |r_fl| >= s := |r32| - delta.
 //   la_j = (E a)_j : |la_j32 - la_j,fl| <= 5 u A_j,  A_j = |E_j0| Xa + |E_j1| Ya + |E_j2|, with Xa, Ya the
-//        data-set maxima of |xa|, |ya|.  Hence dA := (|la_0,32| + eta_a0)^2 + (|la_1,32| + eta_a1)^2 >= da_fl
-//        (eta = 6 u A).  Same for lb = E^T b and dB.
-//   sed_fl >= (1 - 5*2^-53) * r_fl^2 (1/da_fl + 1/db_fl) >= s^2 (dA + dB) / (dA dB).
-//   Reject  <=>  s > 0  and  s^2 (dA + dB) > T dA dB  and  T dA dB > 1e-30,  T = thr * (1 + 1e-5).
+//        data-set maxima of |xa|, |ya|; eta_j := 6 u A_j.  With (|x| + eta)^2 <= (1+k) x^2 + (1 + 1/k) eta^2:
+//        da_fl <= (1+k) (la_0,32^2 + la_1,32^2 + ca),  ca := (eta_a0^2 + eta_a1^2) / k,  k = 2^-10.
+//        Same for lb = E^T b and db.  Write dA := la_0,32^2 + la_1,32^2 + ca, dB likewise.
+//   sed_fl >= (1 - 5*2^-53) r_fl^2 (1/da_fl + 1/db_fl) >= s^2 (dA + dB) / ((1+k) dA dB).
+//   Reject  <=>  s > 0  and  s^2 (dA + dB) > T dA dB  and  T dA dB > 1e-30,  T = thr (1+k) (1 + 1e-5).
 //   The factor 1e-5 covers every rounding of the fp32 evaluation of both sides (< 30 u = 1.8e-6).
 //   NaN / inf / overflow / underflow anywhere make a comparison false (or the guard fail) and the
 //   pair goes to tier 2.  thr < 0 or NaN switches the filter off.
@@ -34,6 +35,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "sfm_common.h"
 #include "sfm_math.h"
@@ -45,7 +47,7 @@ using sfmhost::fail;
 using sfmhost::grid_for;
 
 constexpr int kHypPerWave = 4;
-constexpr int kRing = 128;  // entries per (wave, hypothesis) ring; drained in groups of 64
+constexpr int kRing = 256;  // entries per (wave, hypothesis) ring; <= 63 left + 128 pushed per step; drained in groups of 64
 
 // ------------------------------------------------------------------------------------------------
 // Epilogue shared by both kernels: fixed-order wave reduction + sample fix-up + store.
@@ -178,7 +180,7 @@ __global__ void score_prepare_kernel(const Corr* __restrict__ corr, int64_t n, u
 struct FilterConsts {
     float e[9];        // E rounded to fp32
     float delta;       // >= |r32 - r_fl|
-    float eta_a0, eta_a1, eta_b0, eta_b1;  // >= |l32 - l_fl| for the four line components used
+    float ca, cb;      // additive slack of the dA / dB upper bounds (see the bound above)
 };
 
 SFM_DEVICE FilterConsts make_filter_consts(const double (&E)[9], float Xa, float Ya, float Xb, float Yb) {
@@ -199,10 +201,11 @@ SFM_DEVICE FilterConsts make_filter_consts(const double (&E)[9], float Xa, float
     const float a1 = fabsf(f.e[3]) * Xa + fabsf(f.e[4]) * Ya + fabsf(f.e[5]);
     const float b0 = fabsf(f.e[0]) * Xb + fabsf(f.e[3]) * Yb + fabsf(f.e[6]);
     const float b1 = fabsf(f.e[1]) * Xb + fabsf(f.e[4]) * Yb + fabsf(f.e[7]);
-    f.eta_a0 = (6.0f * u) * a0 * up + poison;
-    f.eta_a1 = (6.0f * u) * a1 * up + poison;
-    f.eta_b0 = (6.0f * u) * b0 * up + poison;
-    f.eta_b1 = (6.0f * u) * b1 * up + poison;
+    constexpr float inv_k = 1024.0f;
+    const float ea0 = (6.0f * u) * a0 * up, ea1 = (6.0f * u) * a1 * up;
+    const float eb0 = (6.0f * u) * b0 * up, eb1 = (6.0f * u) * b1 * up;
+    f.ca = (ea0 * ea0 + ea1 * ea1) * (inv_k * up) + poison;
+    f.cb = (eb0 * eb0 + eb1 * eb1) * (inv_k * up) + poison;
     return f;
 }
 
@@ -217,12 +220,8 @@ SFM_DEVICE bool filter_rejects(const FilterConsts& f, float T, float xa, float y
     const float la0 = fmaf(f.e[0], xa, fmaf(f.e[1], ya, f.e[2]));
     const float la1 = fmaf(f.e[3], xa, fmaf(f.e[4], ya, f.e[5]));
     const float s = fabsf(r) - f.delta;
-    const float ua0 = fabsf(la0) + f.eta_a0;
-    const float ua1 = fabsf(la1) + f.eta_a1;
-    const float ub0 = fabsf(lb0) + f.eta_b0;
-    const float ub1 = fabsf(lb1) + f.eta_b1;
-    const float dA = fmaf(ua0, ua0, ua1 * ua1);
-    const float dB = fmaf(ub0, ub0, ub1 * ub1);
+    const float dA = fmaf(la0, la0, fmaf(la1, la1, f.ca));
+    const float dB = fmaf(lb0, lb0, fmaf(lb1, lb1, f.cb));
     const float lhs = (s * s) * (dA + dB);
     const float rhs = T * (dA * dB);
     // bitwise '&': three compares and two s_and, no control flow
@@ -232,7 +231,7 @@ SFM_DEVICE bool filter_rejects(const FilterConsts& f, float T, float xa, float y
 // ------------------------------------------------------------------------------------------------
 // Filtered kernel.
 // ------------------------------------------------------------------------------------------------
-template <int HPW>
+template <int HPW, int MODE = 0>
 __global__ __launch_bounds__(256) void score_sed_filtered_kernel(
     const Corr* __restrict__ corr, const unsigned char* __restrict__ ws, int n,
     const double* __restrict__ E, const int32_t* __restrict__ S, int h_count, double thr,
@@ -255,8 +254,8 @@ __global__ __launch_bounds__(256) void score_sed_filtered_kernel(
     const float Ya = __uint_as_float(maxima[1]) * (1.0f + 1e-6f);
     const float Xb = __uint_as_float(maxima[2]) * (1.0f + 1e-6f);
     const float Yb = __uint_as_float(maxima[3]) * (1.0f + 1e-6f);
-    // T = thr (1 + 1e-5), rounded up; a negative or NaN threshold switches the filter off
-    const float T = (thr >= 0.0) ? (float)(thr * (1.0 + 1e-5)) * (1.0f + 2e-7f) : INFINITY;
+    // T = thr (1+k)(1 + 1e-5), rounded up; a negative or NaN threshold switches the filter off
+    const float T = (thr >= 0.0) ? (float)(thr * (1.0 + 1.0 / 1024.0) * (1.0 + 1e-5)) * (1.0f + 2e-7f) : INFINITY;
 
     FilterConsts f[HPW];
 #pragma unroll
@@ -294,36 +293,93 @@ __global__ __launch_bounds__(256) void score_sed_filtered_kernel(
         double e[9];
 #pragma unroll
         for (int j = 0; j < 9; ++j) e[j] = Eb[(int64_t)h * 9 + j];
+        if (MODE == 1 || MODE == 2) {  // diagnostic ablations (SFM_SCORE_ABLATE): skip tier 2
+            head[k] += count;
+            return;
+        }
         const bool active = lane < count;
         const int slot = (head[k] + lane) & (kRing - 1);
         const int idx = active ? ring[wave_in_block][k][slot] : 0;
-        const Corr p = pts[idx];
+        Corr p;
+        if (MODE == 4) {  // diagnostic: no gather
+            p.xa = (double)idx; p.ya = 0.25; p.xb = 0.5; p.yb = 0.125;
+        } else {
+            p = pts[idx];
+        }
+        if (MODE == 3) {  // diagnostic: gather but no fp64 SED
+            a1[k] += p.xa + p.yb;
+            head[k] += count;
+            return;
+        }
         const double sed = sfm::sed_value(e, p.xa, p.ya, p.xb, p.yb);
         const bool ok = active && (sed <= thr);
         c[k] += ok ? 1 : 0;
         a1[k] += ok ? sed : 0.0;
         a2[k] += ok ? sed * sed : 0.0;
-        head[k] = __builtin_amdgcn_readfirstlane(head[k] + count);
+        head[k] += count;
     };
 
-    const int chunks = (n + kWave - 1) / kWave;
-    for (int chunk = 0; chunk < chunks; ++chunk) {
-        const int i = chunk * kWave + lane;
-        const bool valid = i < n;
-        const float4 p = pts32[valid ? i : n - 1];
+    // Append the lanes flagged in `mask` (this lane: `mine`) to the ring of hypothesis k.
+    auto push = [&](int k, unsigned long long mask, bool mine, int i) __attribute__((always_inline)) {
+        const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                     __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+        if (mine) ring[wave_in_block][k][(tail[k] + before) & (kRing - 1)] = i;
+        tail[k] += (int)__popcll(mask);  // scalar arithmetic on a wave-uniform mask
+    };
+
+    // Steady state: two full 64-point chunks per step (no validity masks), so the scalar bookkeeping and
+    // the drain test are paid once per 128 evaluations of a hypothesis.
+    auto process_pair = [&](const float4 p0, const float4 p1, int i0) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < HPW; ++k) {
-            const bool pass = valid && !filter_rejects(f[k], T, p.x, p.y, p.z, p.w);
-            const unsigned long long mask = __ballot(pass);
-            if (mask != 0ull) {  // wave-uniform
-                const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                                             __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-                if (pass) ring[wave_in_block][k][(tail[k] + before) & (kRing - 1)] = i;
-                tail[k] = __builtin_amdgcn_readfirstlane(tail[k] + (int)__popcll(mask));
+            const bool rej0 = filter_rejects(f[k], T, p0.x, p0.y, p0.z, p0.w);
+            const bool rej1 = filter_rejects(f[k], T, p1.x, p1.y, p1.z, p1.w);
+            const unsigned long long m0 = ~__builtin_amdgcn_ballot_w64(rej0);
+            const unsigned long long m1 = ~__builtin_amdgcn_ballot_w64(rej1);
+            if (MODE == 1) {  // diagnostic: filter only
+                c[k] += (rej0 ? 0 : 1) + (rej1 ? 0 : 1);
+                continue;
+            }
+            if ((m0 | m1) != 0ull) {  // wave-uniform
+                push(k, m0, !rej0, i0);
+                push(k, m1, !rej1, i0 + kWave);
                 __builtin_amdgcn_wave_barrier();
-                if (tail[k] - head[k] >= kWave) drain(k, kWave);  // wave-uniform
+                while (tail[k] - head[k] >= kWave) drain(k, kWave);  // wave-uniform, at most twice
             }
         }
+    };
+
+    // Tail: one chunk with a validity mask.
+    auto process_tail = [&](const float4 p, int i, bool valid) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < HPW; ++k) {
+            const bool pass = valid & !filter_rejects(f[k], T, p.x, p.y, p.z, p.w);
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
+            if (mask != 0ull) {
+                push(k, mask, pass, i);
+                __builtin_amdgcn_wave_barrier();
+                if (tail[k] - head[k] >= kWave) drain(k, kWave);
+            }
+        }
+    };
+
+    const int full_chunks = n / kWave;
+    const int pairs = full_chunks / 2;
+    if (pairs > 0) {
+        float4 p0 = pts32[lane], p1 = pts32[kWave + lane];
+        for (int pr = 0; pr < pairs; ++pr) {
+            const int i0 = pr * (2 * kWave) + lane;
+            // prefetch the next pair (the last prefetch re-reads valid addresses)
+            const float4 q0 = pts32[min(i0 + 2 * kWave, n - 1)];
+            const float4 q1 = pts32[min(i0 + 3 * kWave, n - 1)];
+            process_pair(p0, p1, i0);
+            p0 = q0;
+            p1 = q1;
+        }
+    }
+    for (int chunk = pairs * 2; chunk * kWave < n; ++chunk) {  // at most two iterations
+        const int i = chunk * kWave + lane;
+        process_tail(pts32[min(i, n - 1)], i, i < n);
     }
 #pragma unroll
     for (int k = 0; k < HPW; ++k) {
@@ -382,8 +438,20 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
                        (const Corr*)corr, n, ws);
     int rc = check_launch("score_prepare_kernel");
     if (rc != SFM_OK) return rc;
-    hipLaunchKernelGGL(score_sed_filtered_kernel<kHypPerWave>, grid, dim3(256), 0, st, (const Corr*)corr, ws,
-                       (int)n, E, S, (int)h_count, thr, cnt, s1, s2);
+    static const int ablate = getenv("SFM_SCORE_ABLATE") ? atoi(getenv("SFM_SCORE_ABLATE")) : 0;  // diagnostics only
+    static const int hpw = getenv("SFM_SCORE_HPW") ? atoi(getenv("SFM_SCORE_HPW")) : kHypPerWave;  // diagnostics only
+#define SFM_LAUNCH_FILTERED(H, M)                                                                              \
+    hipLaunchKernelGGL((score_sed_filtered_kernel<H, M>),                                                      \
+                       dim3(grid_for((h_count + H - 1) / H, 256 / kWave), (unsigned)batch), dim3(256), 0, st,  \
+                       (const Corr*)corr, ws, (int)n, E, S, (int)h_count, thr, cnt, s1, s2)
+    if (ablate == 1) SFM_LAUNCH_FILTERED(kHypPerWave, 1);
+    else if (ablate == 2) SFM_LAUNCH_FILTERED(kHypPerWave, 2);
+    else if (ablate == 3) SFM_LAUNCH_FILTERED(kHypPerWave, 3);
+    else if (ablate == 4) SFM_LAUNCH_FILTERED(kHypPerWave, 4);
+    else if (hpw == 2) SFM_LAUNCH_FILTERED(2, 0);
+    else if (hpw == 3) SFM_LAUNCH_FILTERED(3, 0);
+    else SFM_LAUNCH_FILTERED(4, 0);
+#undef SFM_LAUNCH_FILTERED
     return check_launch("score_sed_filtered_kernel");
 }
 
