@@ -120,6 +120,28 @@ int sfm_triangulate(const double* corr, int64_t m, const double* P1, const doubl
 int sfm_decompose_essential(const double* E, int64_t batch, double* pose_rt, int32_t* status,
                             void* stream);
 
+/* ---- batched, device-resident pose selection + triangulation (chains after sfm_inlier_mask) ---- */
+
+/* Cheirality of every correspondence of every pair under its 4 candidate poses.  corr: dev [batch,n,4]
+ * (K-normalised); pose_rt: dev [batch,4,12] as written by sfm_decompose_essential; mask: dev uint8
+ * [batch,n] inlier mask (points with 0 are reported as failing) or NULL; pass: dev uint8 [batch,4,n]. */
+int sfm_cheirality_batched(const double* corr, int64_t n, int64_t batch, const double* pose_rt,
+                           const uint8_t* mask, double distance_threshold, uint8_t* pass, void* stream);
+
+/* Pose vote of eight_point.py:213-237 per pair: votes[b,p] = #passing correspondences except the one
+ * with index skip_index[b] (the reference does not count position 0 of its list: np.count_nonzero of the
+ * index array); best[b] = first maximum, -1 if all votes are 0.  skip_index: dev int32 [batch] or NULL;
+ * votes: dev int32 [batch,4]; best: dev int32 [batch]. */
+int sfm_pose_vote(const uint8_t* pass, int64_t n, int64_t batch, const int32_t* skip_index, int32_t* votes,
+                  int32_t* best, void* stream);
+
+/* Triangulate (triangulation.py:42-62) the correspondences that pass under the chosen pose:
+ * P1 = [K|0], P2 = [K|0][R t; 0 1], pixel coordinates.  pix_a, pix_b: dev [batch,n,2]; K: HOST [9]
+ * row-major intrinsics; X: dev [batch,n,3] (zeros where valid == 0); valid: dev uint8 [batch,n]. */
+int sfm_triangulate_selected(const double* pix_a, const double* pix_b, int64_t n, int64_t batch,
+                             const double* K, const double* pose_rt, const int32_t* best,
+                             const uint8_t* pass, double* X, uint8_t* valid, void* stream);
+
 /* HOST: exact replay of CPython's random.shuffle as used by ransac.py:59-64.  `mt_state` is the 624-word
  * MT19937 state and `*mt_index` its position (random.getstate()[1]); both are advanced.  The cumulative
  * permutation of range(n) is shuffled `iterations` times; S_out[it,:] receives its first 8 entries.  If

@@ -48,6 +48,9 @@ SIGNATURES = {
     "sfm_cheirality": [_P, _I64, _P, _I64, _D, _P, _P],
     "sfm_triangulate": [_P, _I64, _P, _P, _P, _P],
     "sfm_decompose_essential": [_P, _I64, _P, _P, _P],
+    "sfm_cheirality_batched": [_P, _I64, _I64, _P, _P, _D, _P, _P],
+    "sfm_pose_vote": [_P, _I64, _I64, _P, _P, _P, _P],
+    "sfm_triangulate_selected": [_P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P],
     "sfm_pyshuffle_table": [_P, _P, _I64, _I64, _P, _P, _I64, _P],
 }
 OTHER_SYMBOLS = ["sfm_last_error", "sfm_abi_version", "sfm_score_workspace_bytes"]

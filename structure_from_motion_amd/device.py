@@ -185,12 +185,15 @@ def triangulate(corr: torch.Tensor, P1: torch.Tensor, P2: torch.Tensor) -> torch
     return out
 
 
-def decompose_essential(E: torch.Tensor):
+def decompose_essential(E: torch.Tensor, out=None):
     """E [B,9] -> pose_rt [B,4,12] (rows R(9)|t(3) in the reference's candidate order), status [B]."""
     lib = _native.load()
     B = E.shape[0]
-    poses = torch.empty((B, 4, 12), dtype=F64, device=E.device)
-    status = torch.empty((B,), dtype=torch.int32, device=E.device)
+    if out is None:
+        poses = torch.empty((B, 4, 12), dtype=F64, device=E.device)
+        status = torch.empty((B,), dtype=torch.int32, device=E.device)
+    else:
+        poses, status = out
     check(lib.sfm_decompose_essential(_ptr(E), B, _ptr(poses), _ptr(status), _stream()),
           "sfm_decompose_essential")
     return poses, status
