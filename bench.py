@@ -112,9 +112,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
+    # SFM_DIST_BACKEND=gloo lets several ranks share one GPU for a rehearsal (collective staged through the host)
+    backend = os.environ.get("SFM_DIST_BACKEND", "nccl")
+    local_device = local_rank % max(torch.cuda.device_count(), 1) if backend == "gloo" else local_rank
+    torch.cuda.set_device(local_device)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_device))
+        else:
+            dist.init_process_group(backend)
 
     from structure_from_motion_amd import device, distributed, synthetic
     from structure_from_motion_amd._native import AGG_RMS
@@ -157,7 +163,7 @@ def main():
     elapsed = time.perf_counter() - t0
     state["i"] = -1
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.cpu()[0])
 

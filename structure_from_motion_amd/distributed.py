@@ -31,13 +31,26 @@ def reduce_best(key: torch.Tensor, best_h: torch.Tensor, group=None) -> Tuple[to
     rank found no model).  Returns the global (key, best_h), identical on every rank."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return key.clone(), best_h.clone()
-    gkey = key.clone()
-    dist.all_reduce(gkey, op=dist.ReduceOp.MIN, group=group)
+    gkey = _all_reduce_min(key, group)
     sentinel = torch.full_like(best_h, INT64_MAX)
     cand = torch.where((key == gkey) & (best_h >= 0), best_h, sentinel)
-    dist.all_reduce(cand, op=dist.ReduceOp.MIN, group=group)
+    cand = _all_reduce_min(cand, group)
     gbest = torch.where(cand == sentinel, torch.full_like(cand, -1), cand)
     return gkey, gbest
+
+
+def _all_reduce_min(t: torch.Tensor, group=None) -> torch.Tensor:
+    """MIN all-reduce of a small int64 tensor.  With the "nccl" backend (RCCL) the device tensor is reduced in
+    place over xGMI; with "gloo" (CPU tests, or a rehearsal with several ranks sharing one GPU) device tensors
+    are staged through the host."""
+    out = t.clone()
+    if out.is_cuda and dist.get_backend(group) == "gloo":
+        host = out.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.MIN, group=group)
+        out.copy_(host)
+    else:
+        dist.all_reduce(out, op=dist.ReduceOp.MIN, group=group)
+    return out
 
 
 def reduce_flagged(first_flagged: torch.Tensor, n_flagged: torch.Tensor, group=None):
@@ -90,11 +103,15 @@ class ShardedRansac:
         d = self.device_api
         begin = self.rank * self.h
         d.sample_philox(seed, begin, self.h, self.n, out=self.ws.S)
-        single = self.world == 1
-        self.ws.run(self.corr, self.thr, self.min_extra, self.aggregation, h_offset=begin,
-                    with_mask=False)
+        if self.world == 1:
+            # single GPU: the winner is local — mask straight from the shard's own E / S
+            self.ws.run(self.corr, self.thr, self.min_extra, self.aggregation, h_offset=0, with_mask=True)
+            self.global_key.copy_(self.ws.result[:, 0])
+            self.global_best.copy_(self.ws.result[:, 1])
+            return
+        self.ws.run(self.corr, self.thr, self.min_extra, self.aggregation, h_offset=begin, with_mask=False)
         key, best = self.ws.result[:, 0].contiguous(), self.ws.result[:, 1].contiguous()
-        gkey, gbest = (key, best) if single else reduce_best(key, best, self.group)
+        gkey, gbest = reduce_best(key, best, self.group)
         self.global_key.copy_(gkey)
         self.global_best.copy_(gbest)
         # every rank re-derives the winner from (seed, h*): same code path -> bit-identical E
@@ -112,5 +129,10 @@ class ShardedRansac:
         if best < 0:
             return -1, float("inf"), None, None, None
         err = float(self.global_key.view(torch.float64).cpu()[0])
-        E = self.win_E.cpu().numpy().reshape(3, 3)
-        return best, err, E, self.win_S.cpu().numpy().reshape(8).astype(np.int64), self.ws.mask.cpu().numpy()[0]
+        if self.world == 1:
+            E = self.ws.E[0, best].cpu().numpy().reshape(3, 3)
+            sample = self.ws.S[0, best].cpu().numpy().astype(np.int64)
+        else:
+            E = self.win_E.cpu().numpy().reshape(3, 3)
+            sample = self.win_S.cpu().numpy().reshape(8).astype(np.int64)
+        return best, err, E, sample, self.ws.mask.cpu().numpy()[0]

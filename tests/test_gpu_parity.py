@@ -405,7 +405,8 @@ def test_virtual_shards_equal_single_run(dev):
         shard.rank = r  # hypotheses [r*h, (r+1)*h) of the same Philox stream
         shard.step(seed)
         keys.append(int(shard.ws.result[0, 0].cpu()))
-        bests.append(int(shard.ws.result[0, 1].cpu()))
+        local = int(shard.ws.result[0, 1].cpu())  # world == 1 reports shard-local indices
+        bests.append(local + r * h if local >= 0 else -1)
     # the two MIN reductions of distributed.reduce_best, done by hand over the virtual ranks
     gkey = min(keys)
     gbest = min([b for k, b in zip(keys, bests) if k == gkey and b >= 0] or [-1])
