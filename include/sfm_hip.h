@@ -75,6 +75,25 @@ int sfm_sample_philox_at(uint64_t seed, uint64_t seed_stride, const int64_t* h_i
 int sfm_fit_eight_point(const double* corr, int64_t n, const int32_t* S, int64_t h_count, int64_t batch,
                         double* E, int32_t* flags, double* lambda2, void* stream);
 
+/* The same fit with its intermediates written out, for parity checks of the fused stages against the
+ * reference's private helpers (_normalize_coords :308-338, _get_yT_y :363-375, _compute_f_est :396-427,
+ * _enforce_fundamental_mat_constraints :430-446).  trace: dev [batch,h_count,sfm_fit_trace_doubles()] doubles:
+ * normalised coords a [8][2] | b [8][2] | T1 {scale,cx,cy} | T2 {scale,cx,cy} | Y^T Y [9][9] |
+ * eigenvalues [9] | f_est [9] | rank-2 F [9]. */
+int sfm_fit_trace_doubles(void);
+int sfm_fit_eight_point_traced(const double* corr, int64_t n, const int32_t* S, int64_t h_count, int64_t batch,
+                               double* E, int32_t* flags, double* trace, void* stream);
+
+/* Single-problem stages of the fit (device pointers):
+ *   stage 0  Y^T Y of 8 coordinate pairs as given   in [8][4] {xa,ya,xb,yb}  out [81]
+ *   stage 1  _compute_f_est                          in [81]                  out f_est[9] | eigenvalues[9] | flag
+ *   stage 2  _enforce_fundamental_mat_constraints    in [9]                   out [9] */
+int sfm_fit_stage(int stage, const double* in, double* out, void* stream);
+
+/* _normalize_coords (eight_point.py:308-338) for n points.  coords: dev [n,2]; out: dev [2n+3] =
+ * normalised coords [n][2] then {scale, centroid x, centroid y} of the forward transform. */
+int sfm_hartley_normalize(const double* coords, int64_t n, double* out, void* stream);
+
 /* Symmetric-epipolar-distance scoring of all n correspondences under all hypotheses
  * (ransac.py:66-82 with epipolar_ransac.py:18-25 / sed.py:7-30 as the scorer).
  * cnt[b,h] = #non-sample points with sed <= thr; s1 / s2 = sum of sed / sed^2 over the 8 sample points

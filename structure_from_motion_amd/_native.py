@@ -41,6 +41,9 @@ SIGNATURES = {
     "sfm_sample_philox": [_U64, _U64, _I64, _I64, _I64, _I64, _P, _P],
     "sfm_sample_philox_at": [_U64, _U64, _P, _I64, _I64, _P, _P],
     "sfm_fit_eight_point": [_P, _I64, _P, _I64, _I64, _P, _P, _P, _P],
+    "sfm_fit_eight_point_traced": [_P, _I64, _P, _I64, _I64, _P, _P, _P, _P],
+    "sfm_fit_stage": [C.c_int, _P, _P, _P],
+    "sfm_hartley_normalize": [_P, _I64, _P, _P],
     "sfm_score_sed": [_P, _I64, _P, _P, _I64, _I64, _D, _P, _P, _P, _P, _I64, _P],
     "sfm_select_best": [_P, _P, _P, _P, _I64, _I64, _D, C.c_int, _I64, _P, _P],
     "sfm_inlier_mask": [_P, _I64, _P, _P, _I64, _I64, _P, _D, _P, _P],
@@ -53,7 +56,7 @@ SIGNATURES = {
     "sfm_triangulate_selected": [_P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P],
     "sfm_pyshuffle_table": [_P, _P, _I64, _I64, _P, _P, _I64, _P],
 }
-OTHER_SYMBOLS = ["sfm_last_error", "sfm_abi_version", "sfm_score_workspace_bytes"]
+OTHER_SYMBOLS = ["sfm_last_error", "sfm_abi_version", "sfm_score_workspace_bytes", "sfm_fit_trace_doubles"]
 
 _lib = None
 
@@ -81,6 +84,8 @@ def load() -> C.CDLL:
     lib.sfm_last_error.argtypes = []
     lib.sfm_abi_version.restype = C.c_int
     lib.sfm_abi_version.argtypes = []
+    lib.sfm_fit_trace_doubles.restype = C.c_int
+    lib.sfm_fit_trace_doubles.argtypes = []
     lib.sfm_score_workspace_bytes.restype = C.c_int64
     lib.sfm_score_workspace_bytes.argtypes = [_I64, _I64]
     if lib.sfm_abi_version() != ABI_VERSION:

@@ -118,9 +118,81 @@ SFM_DEVICE Hartley hartley8(double (&x)[8], double (&y)[8]) {
     return h;
 }
 
+// The four stages of the fit as device routines (shared by the hypothesis kernel and the single-problem
+// stage kernel that backs the reference's private helpers).
+
+// Y^T Y, upper triangle, accumulated in point order (eight_point.py:363-393)
+SFM_DEVICE void build_yty(const double (&xa)[8], const double (&ya)[8], const double (&xb)[8],
+                          const double (&yb)[8], double (&a)[45]) {
+#pragma unroll
+    for (int i = 0; i < 45; ++i) a[i] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const double col[9] = {xb[k] * xa[k], xb[k] * ya[k], xb[k], yb[k] * xa[k], yb[k] * ya[k],
+                               yb[k],         xa[k],         ya[k], 1.0};
+        int idx = 0;
+#pragma unroll
+        for (int p = 0; p < 9; ++p)
+#pragma unroll
+            for (int q = p; q < 9; ++q) a[idx++] += col[p] * col[q];
+    }
+}
+
+// eight_point.py:396-427: eigen-decomposition, degeneracy predicate (any but the smallest eigenvalue
+// <= 1e-10), eigenvector of the eigenvalue of smallest magnitude.  `a` is destroyed.
+SFM_DEVICE int null_vector_of_yty(double (&a)[45], double (&f)[9], double (&w)[9], double& second) {
+    double v[81];
+    sfm::jacobi_eig9(a, v, w);
+    double smallest = w[0];
+    second = INFINITY;
+    double best_abs = fabs(w[0]);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) f[k] = v[k * 9 + 0];
+#pragma unroll
+    for (int j = 1; j < 9; ++j) {
+        const bool lt = w[j] < smallest;
+        second = lt ? smallest : fmin(second, w[j]);
+        smallest = lt ? w[j] : smallest;
+        const bool closer = fabs(w[j]) < best_abs;
+        best_abs = closer ? fabs(w[j]) : best_abs;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) f[k] = closer ? v[k * 9 + j] : f[k];
+    }
+    return (second <= 1e-10) ? SFM_FIT_DEGENERATE : 0;
+}
+
+// rank-2 enforcement (eight_point.py:430-446): drop the smallest singular direction of f (row-major 3x3)
+SFM_DEVICE void enforce_rank2(const double (&f)[9], double (&fr)[3][3]) {
+    double g[3][3], vv[3][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) g[c][r] = f[r * 3 + c];
+    sfm::hestenes_svd<3>(g, vv);
+    double n2[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) n2[c] = g[c][0] * g[c][0] + g[c][1] * g[c][1] + g[c][2] * g[c][2];
+    const int drop = (n2[0] <= n2[1] && n2[0] <= n2[2]) ? 0 : ((n2[1] <= n2[2]) ? 1 : 2);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) acc += (k == drop) ? 0.0 : g[k][r] * vv[k][c];
+            fr[r][c] = acc;
+        }
+}
+
+// Trace record written by the traced fit (doubles): normalised coords a [8][2] | b [8][2] | T1 {scale,cx,cy} |
+// T2 {scale,cx,cy} | Y^T Y full [9][9] | eigenvalues [9] | f_est [9] | rank-2 F [9]
+constexpr int kTraceDoubles = 16 + 16 + 3 + 3 + 81 + 9 + 9 + 9;
+
+template <bool TRACE>
 __global__ __launch_bounds__(kWave) void fit_eight_point_kernel(
     const Corr* __restrict__ corr, int64_t n, const int32_t* __restrict__ S, int64_t h_count,
-    double* __restrict__ E, int32_t* __restrict__ flags, double* __restrict__ lambda2) {
+    double* __restrict__ E, int32_t* __restrict__ flags, double* __restrict__ lambda2,
+    double* __restrict__ trace) {
     const int64_t b = blockIdx.y;
     const int64_t h_raw = (int64_t)blockIdx.x * kWave + threadIdx.x;
     const bool active = h_raw < h_count;
@@ -138,63 +210,45 @@ __global__ __launch_bounds__(kWave) void fit_eight_point_kernel(
     const Hartley t1 = hartley8(xa, ya);
     const Hartley t2 = hartley8(xb, yb);
 
-    // Y^T Y, upper triangle, accumulated in point order (eight_point.py:363-393)
     double a[45];
+    build_yty(xa, ya, xb, yb, a);
+    double* tr = nullptr;
+    if constexpr (TRACE) {
+        tr = trace + (b * h_count + h) * kTraceDoubles;
+        if (active) {
 #pragma unroll
-    for (int i = 0; i < 45; ++i) a[i] = 0.0;
+            for (int k = 0; k < 8; ++k) {
+                tr[2 * k] = xa[k]; tr[2 * k + 1] = ya[k];
+                tr[16 + 2 * k] = xb[k]; tr[16 + 2 * k + 1] = yb[k];
+            }
+            tr[32] = t1.scale; tr[33] = t1.cx; tr[34] = t1.cy;
+            tr[35] = t2.scale; tr[36] = t2.cx; tr[37] = t2.cy;
+            int idx = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const double col[9] = {xb[k] * xa[k], xb[k] * ya[k], xb[k], yb[k] * xa[k], yb[k] * ya[k],
-                               yb[k],         xa[k],         ya[k], 1.0};
-        int idx = 0;
+            for (int p = 0; p < 9; ++p)
 #pragma unroll
-        for (int p = 0; p < 9; ++p)
-#pragma unroll
-            for (int q = p; q < 9; ++q) a[idx++] += col[p] * col[q];
-    }
-
-    double v[81], w[9];
-    sfm::jacobi_eig9(a, v, w);
-
-    // eight_point.py:413-424: flag if any but the smallest eigenvalue is <= 1e-10; take argmin |w|
-    double smallest = w[0], second = INFINITY;
-    double best_abs = fabs(w[0]);
-    double f[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) f[k] = v[k * 9 + 0];
-#pragma unroll
-    for (int j = 1; j < 9; ++j) {
-        const bool lt = w[j] < smallest;
-        second = lt ? smallest : fmin(second, w[j]);
-        smallest = lt ? w[j] : smallest;
-        const bool closer = fabs(w[j]) < best_abs;
-        best_abs = closer ? fabs(w[j]) : best_abs;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) f[k] = closer ? v[k * 9 + j] : f[k];
-    }
-    const int flag = (second <= 1e-10) ? SFM_FIT_DEGENERATE : 0;
-
-    // rank-2 enforcement (eight_point.py:440-445): drop the smallest singular direction
-    double g[3][3], vv[3][3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int r = 0; r < 3; ++r) g[c][r] = f[r * 3 + c];
-    sfm::hestenes_svd<3>(g, vv);
-    double n2[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) n2[c] = g[c][0] * g[c][0] + g[c][1] * g[c][1] + g[c][2] * g[c][2];
-    const int drop = (n2[0] <= n2[1] && n2[0] <= n2[2]) ? 0 : ((n2[1] <= n2[2]) ? 1 : 2);
-    double fr[3][3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            double acc = 0.0;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) acc += (k == drop) ? 0.0 : g[k][r] * vv[k][c];
-            fr[r][c] = acc;
+                for (int q = p; q < 9; ++q) {
+                    tr[38 + p * 9 + q] = a[idx];
+                    tr[38 + q * 9 + p] = a[idx];
+                    ++idx;
+                }
         }
+    }
+
+    double f[9], w[9], second;
+    const int flag = null_vector_of_yty(a, f, w, second);
+    double fr[3][3];
+    enforce_rank2(f, fr);
+    if constexpr (TRACE) {
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                tr[119 + k] = w[k];
+                tr[128 + k] = f[k];
+                tr[137 + k] = fr[k / 3][k % 3];
+            }
+        }
+    }
 
     // E = T2^T F T1 (eight_point.py:163), then divide by E[2][2] (:166, unguarded)
     const double tx1 = -t1.scale * t1.cx, ty1 = -t1.scale * t1.cy;
@@ -220,6 +274,92 @@ __global__ __launch_bounds__(kWave) void fit_eight_point_kernel(
         for (int k = 0; k < 9; ++k) out[k] = e[k] / e22;
         flags[b * h_count + h] = flag;
         if (lambda2 != nullptr) lambda2[b * h_count + h] = second;
+    }
+}
+
+// Single-problem stages behind the reference's private helpers (one lane does the work; the other lanes
+// of the wave run the same problem so the wave-uniform Jacobi loops behave):
+//   stage 0: Y^T Y of 8 coordinate pairs taken as they are        in: corr8 [8][4]      out: [81]
+//   stage 1: _compute_f_est (eight_point.py:396-427)             in: yty [81]           out: f_est [9] | w [9] | flag
+//   stage 2: _enforce_fundamental_mat_constraints (:430-446)     in: f [9]              out: [9]
+__global__ __launch_bounds__(kWave) void fit_stage_kernel(int stage, const double* __restrict__ in,
+                                                          double* __restrict__ out) {
+    if (stage == 0) {
+        double xa[8], ya[8], xb[8], yb[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            xa[k] = in[4 * k]; ya[k] = in[4 * k + 1]; xb[k] = in[4 * k + 2]; yb[k] = in[4 * k + 3];
+        }
+        double a[45];
+        build_yty(xa, ya, xb, yb, a);
+        if (threadIdx.x == 0) {
+            int idx = 0;
+#pragma unroll
+            for (int p = 0; p < 9; ++p)
+#pragma unroll
+                for (int q = p; q < 9; ++q) {
+                    out[p * 9 + q] = a[idx];
+                    out[q * 9 + p] = a[idx];
+                    ++idx;
+                }
+        }
+    } else if (stage == 1) {
+        double a[45];
+        int idx = 0;
+#pragma unroll
+        for (int p = 0; p < 9; ++p)
+#pragma unroll
+            for (int q = p; q < 9; ++q) a[idx++] = in[p * 9 + q];
+        double f[9], w[9], second;
+        const int flag = null_vector_of_yty(a, f, w, second);
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                out[k] = f[k];
+                out[9 + k] = w[k];
+            }
+            out[18] = (double)flag;
+        }
+    } else {
+        double f[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) f[k] = in[k];
+        double fr[3][3];
+        enforce_rank2(f, fr);
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) out[k] = fr[k / 3][k % 3];
+        }
+    }
+}
+
+// Hartley normalisation of n points (eight_point.py:308-338) for the `_normalize_coords` helper:
+// centroid = sequential sum / n, scale = sqrt(2) / mean distance; out: normalised [n][2] then {scale,cx,cy}.
+__global__ void hartley_normalize_kernel(const double* __restrict__ coords, int64_t n, double* __restrict__ out) {
+    __shared__ double sh[3];
+    if (threadIdx.x == 0) {
+        double sx = 0.0, sy = 0.0;
+        for (int64_t i = 0; i < n; ++i) {
+            sx += coords[2 * i];
+            sy += coords[2 * i + 1];
+        }
+        const double cx = sx / (double)n, cy = sy / (double)n;
+        double total = 0.0;
+        for (int64_t i = 0; i < n; ++i) {
+            const double dx = coords[2 * i] - cx, dy = coords[2 * i + 1] - cy;
+            total += sqrt(dx * dx + dy * dy);
+        }
+        sh[0] = sqrt(2.0) / (total / (double)n);
+        sh[1] = cx;
+        sh[2] = cy;
+        out[2 * n] = sh[0];
+        out[2 * n + 1] = cx;
+        out[2 * n + 2] = cy;
+    }
+    __syncthreads();
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        out[2 * i] = (coords[2 * i] - sh[1]) * sh[0];
+        out[2 * i + 1] = (coords[2 * i + 1] - sh[2]) * sh[0];
     }
 }
 
@@ -564,10 +704,38 @@ int sfm_fit_eight_point(const double* corr, int64_t n, const int32_t* S, int64_t
     if (n < 8) return fail(SFM_EINVAL, "sfm_fit_eight_point: need at least 8 correspondences");
     if (h_count == 0 || batch == 0) return SFM_OK;
     if (!corr || !S || !E || !flags) return fail(SFM_EINVAL, "sfm_fit_eight_point: null pointer");
-    hipLaunchKernelGGL(fit_eight_point_kernel, dim3(grid_for(h_count, kWave), (unsigned)batch),
+    hipLaunchKernelGGL(fit_eight_point_kernel<false>, dim3(grid_for(h_count, kWave), (unsigned)batch),
                        dim3(kWave), 0, (hipStream_t)stream, (const Corr*)corr, n, S, h_count, E, flags,
-                       lambda2);
+                       lambda2, (double*)nullptr);
     return check_launch("fit_eight_point_kernel");
+}
+
+int sfm_fit_trace_doubles(void) { return kTraceDoubles; }
+
+int sfm_fit_eight_point_traced(const double* corr, int64_t n, const int32_t* S, int64_t h_count, int64_t batch,
+                               double* E, int32_t* flags, double* trace, void* stream) {
+    if (h_count < 0 || batch < 0) return fail(SFM_EINVAL, "sfm_fit_eight_point_traced: negative size");
+    if (n < 8) return fail(SFM_EINVAL, "sfm_fit_eight_point_traced: need at least 8 correspondences");
+    if (h_count == 0 || batch == 0) return SFM_OK;
+    if (!corr || !S || !E || !flags || !trace) return fail(SFM_EINVAL, "sfm_fit_eight_point_traced: null pointer");
+    hipLaunchKernelGGL(fit_eight_point_kernel<true>, dim3(grid_for(h_count, kWave), (unsigned)batch),
+                       dim3(kWave), 0, (hipStream_t)stream, (const Corr*)corr, n, S, h_count, E, flags,
+                       (double*)nullptr, trace);
+    return check_launch("fit_eight_point_kernel<trace>");
+}
+
+int sfm_fit_stage(int stage, const double* in, double* out, void* stream) {
+    if (stage < 0 || stage > 2) return fail(SFM_EINVAL, "sfm_fit_stage: stage must be 0, 1 or 2");
+    if (!in || !out) return fail(SFM_EINVAL, "sfm_fit_stage: null pointer");
+    hipLaunchKernelGGL(fit_stage_kernel, dim3(1), dim3(kWave), 0, (hipStream_t)stream, stage, in, out);
+    return check_launch("fit_stage_kernel");
+}
+
+int sfm_hartley_normalize(const double* coords, int64_t n, double* out, void* stream) {
+    if (n <= 0) return fail(SFM_EINVAL, "sfm_hartley_normalize: need at least one point");
+    if (!coords || !out) return fail(SFM_EINVAL, "sfm_hartley_normalize: null pointer");
+    hipLaunchKernelGGL(hartley_normalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, coords, n, out);
+    return check_launch("hartley_normalize_kernel");
 }
 
 int sfm_select_best(const int32_t* cnt, const double* s1, const double* s2, const int32_t* flags,

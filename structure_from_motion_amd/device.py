@@ -101,6 +101,53 @@ def fit_eight_point(corr: torch.Tensor, S: torch.Tensor, E=None, flags=None, lam
     return E, flags
 
 
+TRACE_FIELDS = {  # name -> (offset, shape) inside one trace record of sfm_fit_eight_point_traced
+    "norm_a": (0, (8, 2)), "norm_b": (16, (8, 2)), "T1": (32, (3,)), "T2": (35, (3,)),
+    "yty": (38, (9, 9)), "eigenvalues": (119, (9,)), "f_est": (128, (3, 3)), "f_rank2": (137, (3, 3)),
+}
+
+
+def fit_eight_point_traced(corr: torch.Tensor, S: torch.Tensor):
+    """corr [B,N,4], S [B,H,8] -> E [B,H,9], flags [B,H], dict of intermediate arrays (numpy, [B,H,...])."""
+    lib = _native.load()
+    B, N, _ = corr.shape
+    H = S.shape[1]
+    nd = lib.sfm_fit_trace_doubles()
+    E = torch.empty((B, H, 9), dtype=F64, device=corr.device)
+    flags = torch.empty((B, H), dtype=torch.int32, device=corr.device)
+    trace = torch.empty((B, H, nd), dtype=F64, device=corr.device)
+    check(lib.sfm_fit_eight_point_traced(_ptr(corr), N, _ptr(S), H, B, _ptr(E), _ptr(flags), _ptr(trace),
+                                         _stream()), "sfm_fit_eight_point_traced")
+    raw = trace.cpu().numpy()
+    fields = {}
+    for name, (off, shape) in TRACE_FIELDS.items():
+        size = int(np.prod(shape))
+        fields[name] = raw[..., off:off + size].reshape((B, H) + shape)
+    return E, flags, fields
+
+
+def fit_stage(stage: int, data: np.ndarray, out_size: int) -> np.ndarray:
+    """Run one single-problem stage of the fit (see sfm_fit_stage in include/sfm_hip.h)."""
+    lib = _native.load()
+    inp = to_device(np.ascontiguousarray(data, dtype=np.float64).reshape(-1))
+    out = torch.empty((out_size,), dtype=F64, device=inp.device)
+    check(lib.sfm_fit_stage(stage, _ptr(inp), _ptr(out), _stream()), "sfm_fit_stage")
+    return out.cpu().numpy()
+
+
+def hartley_normalize(coords: np.ndarray):
+    """(n,2) -> normalised (n,2), forward transform T (3,3) (reference _normalize_coords)."""
+    lib = _native.load()
+    n = coords.shape[0]
+    inp = to_device(np.ascontiguousarray(coords, dtype=np.float64))
+    out = torch.empty((2 * n + 3,), dtype=F64, device=inp.device)
+    check(lib.sfm_hartley_normalize(_ptr(inp), n, _ptr(out), _stream()), "sfm_hartley_normalize")
+    raw = out.cpu().numpy()
+    scale, cx, cy = raw[2 * n:]
+    T = np.array([[scale, 0.0, -scale * cx], [0.0, scale, -scale * cy], [0.0, 0.0, 1.0]])
+    return raw[:2 * n].reshape(n, 2).copy(), T
+
+
 def score_workspace(n: int, batch: int, device) -> torch.Tensor:
     """Scratch buffer that enables the two-tier scoring kernel (see include/sfm_hip.h)."""
     lib = _native.load()

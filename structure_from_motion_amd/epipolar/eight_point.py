@@ -55,6 +55,58 @@ def _get_matching_coordinates(
 
 
 # ------------------------------------------------------------------------------------------------------
+# the reference's private fit helpers, each backed by the corresponding stage of the fit kernel
+# ------------------------------------------------------------------------------------------------------
+def _normalize_coords(coords: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """Translate the centroid to the origin and scale the mean distance to sqrt(2).  Returns
+    ``(normalised coords, T)`` with ``T`` the *forward* 3x3 transform (reference eight_point.py:308-338)."""
+    device.require_gpu()
+    return device.hartley_normalize(np.asarray(coords, dtype=np.float64))
+
+
+def _get_normalized_match_coordinates(features_a, features_b, matches):
+    """``(coords_a, T1, coords_b, T2)`` of the matched, Hartley-normalised coordinates (:341-360)."""
+    coords_a, coords_b = _get_matching_coordinates(features_a, features_b, matches)
+    return (*_normalize_coords(coords_a), *_normalize_coords(coords_b))
+
+
+def _get_y_col(coord_a: np.ndarray, coord_b: np.ndarray) -> np.ndarray:
+    """Row of the eight-point design matrix for one pair: [xb*xa, xb*ya, xb, yb*xa, yb*ya, yb, xa, ya, 1]
+    (reference :378-393).  Four products of two scalars each: host arithmetic, IEEE-identical to the kernel's."""
+    assert 2 == len(coord_a) and 2 == len(coord_b)
+    xa, ya = coord_a
+    xb, yb = coord_b
+    return np.array([xb * xa, xb * ya, xb, yb * xa, yb * ya, yb, xa, ya, 1.0], dtype=np.float64)
+
+
+def _get_yT_y(coords_a: np.ndarray, coords_b: np.ndarray) -> np.ndarray:
+    """Y^T Y (9x9) of eight coordinate pairs, accumulated in point order (reference :363-375)."""
+    assert len(coords_a) == len(coords_b) == 8
+    device.require_gpu()
+    return device.fit_stage(0, np.hstack([coords_a, coords_b]), 81).reshape(9, 9)
+
+
+def _compute_f_est(yT_y: np.ndarray) -> np.ndarray:
+    """Null vector of Y^T Y reshaped to 3x3; raises when more than one eigenvalue is ~0 (reference :396-427).
+    The sign of the vector is arbitrary (as with LAPACK); callers normalise by F[2,2]."""
+    assert (9, 9) == yT_y.shape
+    device.require_gpu()
+    out = device.fit_stage(1, yT_y, 19)
+    if int(out[18]) & FIT_DEGENERATE:
+        raise EightPointCalculationError(
+            "More than one eigenvalue of Y.T @ Y is small. Cannot confidently estimate"
+            " fundamental matrix."
+        )
+    return out[:9].reshape(3, 3)
+
+
+def _enforce_fundamental_mat_constraints(f_est: np.ndarray) -> np.ndarray:
+    """Closest rank-2 matrix: the smallest singular value set to zero (reference :430-446)."""
+    device.require_gpu()
+    return device.fit_stage(2, np.asarray(f_est, dtype=np.float64), 9).reshape(3, 3)
+
+
+# ------------------------------------------------------------------------------------------------------
 # fit
 # ------------------------------------------------------------------------------------------------------
 def _fit_eight(coords_a: np.ndarray, coords_b: np.ndarray) -> np.ndarray:
