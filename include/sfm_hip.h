@@ -161,6 +161,31 @@ int sfm_triangulate_selected(const double* pix_a, const double* pix_b, int64_t n
                              const double* K, const double* pose_rt, const int32_t* best,
                              const uint8_t* pass, double* X, uint8_t* valid, void* stream);
 
+/* ---- brute-force window matching (reference lib/feature_matching: matching.py, ncc.py, ssd.py, util.py) ---- */
+#define SFM_MATCH_NCC 0 /* ncc.py:7-54: 1 - normalised cross-correlation, in [0,2]; 2.0 if a window leaves the image */
+#define SFM_MATCH_SSD 1 /* ssd.py:7-36: mean squared difference; +inf if a window leaves the image */
+
+/* Windows of n features of one image (util.py:8-27).  image: dev f64 [height,width]; feats: dev f64 [n,2]
+ * (x, y); patches: dev f64 [window_size^2][stride] k-major (stride >= n), mean-removed if subtract_mean
+ * (ncc.py:33-37); ssq: dev [n] sum of squares of the stored patch; ok: dev uint8 [n] window inside the image. */
+int sfm_patch_extract(const double* image, int64_t height, int64_t width, const double* feats, int64_t n,
+                      int window_size, int subtract_mean, int64_t stride, double* patches, double* ssq,
+                      uint8_t* ok, void* stream);
+
+/* scores[a,b] for every pair of features (the score_function calls of matching.py:57-65).
+ * metric SFM_MATCH_NCC needs mean-removed patches.  scores: dev f64 [n_a,n_b]. */
+int sfm_pair_scores(int metric, const double* patches_a, int64_t stride_a, const double* patches_b,
+                    int64_t stride_b, const double* ssq_a, const double* ssq_b, const uint8_t* ok_a,
+                    const uint8_t* ok_b, int64_t n_a, int64_t n_b, int window_elements, double* scores,
+                    void* stream);
+
+/* Per A-feature, what the reference's heapq holds after pushing its row of scores in order
+ * (matching.py:60-65): best[a] / arg[a] = heap[0] score and b index (first minimum), second[a] = heap[1]
+ * score (the value the ratio test of matching.py:84-97 divides by; NaN if n_b == 1).
+ * best, second: dev f64 [n_a]; arg: dev int32 [n_a]. */
+int sfm_match_row_summary(const double* scores, int64_t n_a, int64_t n_b, double* best, int32_t* arg,
+                          double* second, void* stream);
+
 /* HOST: exact replay of CPython's random.shuffle as used by ransac.py:59-64.  `mt_state` is the 624-word
  * MT19937 state and `*mt_index` its position (random.getstate()[1]); both are advanced.  The cumulative
  * permutation of range(n) is shuffled `iterations` times; S_out[it,:] receives its first 8 entries.  If

@@ -1,2 +1,8 @@
-"""``lib.feature_matching.matching`` drop-in: only the ``Match`` value type is on the hot path."""
-from structure_from_motion_amd.feature_matching.matching import Match  # noqa: F401
+"""``lib.feature_matching.matching`` drop-in (reference lib/feature_matching/matching.py)."""
+from structure_from_motion_amd.feature_matching.matching import (  # noqa: F401
+    ImagePairScore,
+    Match,
+    ScoreFunction,
+    ValidationStrategy,
+    match_brute_force,
+)

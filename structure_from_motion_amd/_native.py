@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(HERE, "csrc", "libsfm_hip.so")
 SFM_OK = 0
 AGG_SUM, AGG_SQUARE, AGG_MEAN, AGG_RMS = 0, 1, 2, 3
 FIT_DEGENERATE = 1
+MATCH_NCC, MATCH_SSD = 0, 1
 INT64_MAX = (1 << 63) - 1
 ABI_VERSION = 2
 
@@ -54,6 +55,9 @@ SIGNATURES = {
     "sfm_cheirality_batched": [_P, _I64, _I64, _P, _P, _D, _P, _P],
     "sfm_pose_vote": [_P, _I64, _I64, _P, _P, _P, _P],
     "sfm_triangulate_selected": [_P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P],
+    "sfm_patch_extract": [_P, _I64, _I64, _P, _I64, C.c_int, C.c_int, _I64, _P, _P, _P, _P],
+    "sfm_pair_scores": [C.c_int, _P, _I64, _P, _I64, _P, _P, _P, _P, _I64, _I64, C.c_int, _P, _P],
+    "sfm_match_row_summary": [_P, _I64, _I64, _P, _P, _P, _P],
     "sfm_pyshuffle_table": [_P, _P, _I64, _I64, _P, _P, _I64, _P],
 }
 OTHER_SYMBOLS = ["sfm_last_error", "sfm_abi_version", "sfm_score_workspace_bytes", "sfm_fit_trace_doubles"]

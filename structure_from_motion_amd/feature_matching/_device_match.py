@@ -1,0 +1,67 @@
+"""Device side of the matcher: score matrices and heap summaries through the C ABI (host glue only)."""
+from __future__ import annotations
+
+from typing import Tuple
+
+import numpy as np
+import torch
+
+from .. import _native, device
+from .._native import MATCH_NCC, MATCH_SSD, check
+
+F64 = torch.float64
+
+
+def _features_tensor(features) -> torch.Tensor:
+    arr = np.empty((len(features), 2), dtype=np.float64)
+    for i, f in enumerate(features):
+        arr[i, 0] = f.x
+        arr[i, 1] = f.y
+    return device.to_device(arr)
+
+
+def _image_tensor(image: np.ndarray) -> torch.Tensor:
+    if image.ndim != 2:
+        raise ValueError("the matcher works on single-channel (2-D) images")
+    return device.to_device(np.ascontiguousarray(image, dtype=np.float64))
+
+
+def score_matrix(metric: int, image_a, image_b, feats_a, feats_b, window_size: int) -> torch.Tensor:
+    """(nA, nB) device tensor of window scores for every feature pair."""
+    if image_a.shape != image_b.shape:
+        raise ValueError("the images must have the same shape")
+    lib = _native.load()
+    dev = device.require_gpu()
+    st = device._stream()
+    side = 2 * int(window_size / 2) + 1
+    K = side * side
+    out = []
+    for image, feats in ((image_a, feats_a), (image_b, feats_b)):
+        img = _image_tensor(image)
+        ft = feats if isinstance(feats, torch.Tensor) else _features_tensor(feats)
+        n = ft.shape[0]
+        patches = torch.empty((K, max(n, 1)), dtype=F64, device=dev)
+        ssq = torch.empty((max(n, 1),), dtype=F64, device=dev)
+        ok = torch.empty((max(n, 1),), dtype=torch.uint8, device=dev)
+        check(lib.sfm_patch_extract(img.data_ptr(), img.shape[0], img.shape[1], ft.data_ptr(), n, int(window_size),
+                                    1 if metric == MATCH_NCC else 0, patches.shape[1], patches.data_ptr(),
+                                    ssq.data_ptr(), ok.data_ptr(), st), "sfm_patch_extract")
+        out.append((patches, ssq, ok, n))
+    (pa, qa, oka, nA), (pb, qb, okb, nB) = out
+    scores = torch.empty((nA, nB), dtype=F64, device=dev)
+    check(lib.sfm_pair_scores(metric, pa.data_ptr(), pa.shape[1], pb.data_ptr(), pb.shape[1], qa.data_ptr(),
+                              qb.data_ptr(), oka.data_ptr(), okb.data_ptr(), nA, nB, K, scores.data_ptr(), st),
+          "sfm_pair_scores")
+    return scores
+
+
+def row_summary(scores: torch.Tensor) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """heap[0] score / b index and heap[1] score per row (host arrays)."""
+    lib = _native.load()
+    nA, nB = scores.shape
+    best = torch.empty((nA,), dtype=F64, device=scores.device)
+    arg = torch.empty((nA,), dtype=torch.int32, device=scores.device)
+    second = torch.empty((nA,), dtype=F64, device=scores.device)
+    check(lib.sfm_match_row_summary(scores.data_ptr(), nA, nB, best.data_ptr(), arg.data_ptr(),
+                                    second.data_ptr(), device._stream()), "sfm_match_row_summary")
+    return best.cpu().numpy(), arg.cpu().numpy().astype(np.int64), second.cpu().numpy()

@@ -448,6 +448,76 @@ def g10_line_ransac():
     save("g10_line_ransac", points=all_points, model=np.array(model), inliers=np.array(inliers))
 
 
+def g11_matching():
+    """Brute-force matcher (matching.py:36-118) with the real NCC / SSD score functions on synthetic uint8
+    images, wired like apps/sfm.py:73-87 (closure around a functools.partial of calculate_ncc)."""
+    import functools
+    from lib.feature_matching import matching, ncc, ssd
+
+    rng = np.random.default_rng(42)
+    H, W = 72, 104
+    base = rng.integers(0, 256, size=(H + 8, W + 8)).astype(np.float64)
+    # smooth a little so neighbouring windows correlate, then quantise to uint8
+    k = np.array([1.0, 2.0, 1.0]) / 4.0
+    for _ in range(2):
+        base = np.apply_along_axis(lambda r: np.convolve(r, k, mode="same"), 0, base)
+        base = np.apply_along_axis(lambda r: np.convolve(r, k, mode="same"), 1, base)
+    image_a = np.clip(base[4:4 + H, 4:4 + W], 0, 255).astype(np.uint8)
+    image_b = np.clip(base[2:2 + H, 1:1 + W] + rng.normal(0, 2.0, (H, W)), 0, 255).astype(np.uint8)  # shifted + noise
+    nA, nB = 40, 50
+    fa = np.column_stack([rng.integers(0, W, nA), rng.integers(0, H, nA)]).astype(np.float64)
+    fb = np.column_stack([rng.integers(0, W, nB), rng.integers(0, H, nB)]).astype(np.float64)
+    fb[:25] = fa[:25] + np.array([3.0, 2.0])  # true correspondences for the first 25
+    fa[30] = [2.0, 40.0]   # out of bounds for window 9, in bounds for window 5
+    fb[40] = [W - 1.0, 5.0]
+    fa[31] = fa[0]          # duplicate feature -> tied scores
+    feats_a, feats_b = feats(fa), feats(fb)
+    out = dict(image_a=image_a, image_b=image_b, feats_a=fa, feats_b=fb)
+
+    def score_fn(full):
+        def score(feature_a, feature_b):  # same shape as apps/sfm.py:_create_score_function
+            return full(image_a, image_b, feature_a, feature_b)
+        return score
+
+    combos = {
+        "none": None,
+        "ratio": matching.ValidationStrategy.RATIO_TEST,
+        "cross": {matching.ValidationStrategy.CROSSCHECK},
+        "both": {matching.ValidationStrategy.RATIO_TEST, matching.ValidationStrategy.CROSSCHECK},
+    }
+    for metric, fn, ws in (("ncc", ncc.calculate_ncc, 9), ("ncc5", ncc.calculate_ncc, 5), ("ssd", ssd.calculate_ssd, 5)):
+        full = functools.partial(fn, window_size=ws)
+        if metric == "ssd":
+            # ssd.py:31-35 subtracts and squares in the image dtype: on uint8 images the reference wraps modulo
+            # 256.  The SSD vectors are therefore taken on float images (the reference's own test_ssd.py uses
+            # wide integers), where the arithmetic is the plain one.
+            ia, ib = image_a.astype(np.float64), image_b.astype(np.float64)
+            full = functools.partial(lambda A, B, a, b, _f=full, _ia=ia, _ib=ib: _f(_ia, _ib, a, b))
+        scores = np.array([[full(image_a, image_b, a, b) for b in feats_b] for a in feats_a], dtype=np.float64)
+        out[f"scores_{metric}"] = scores
+        for name, strat in combos.items():
+            for thr in (0.7, 0.95):
+                ms = matching.match_brute_force(feats_a, feats_b, score_fn(full),
+                                                validation_strategies=strat, ratio_test_threshold=thr)
+                out[f"matches_{metric}_{name}_{thr}"] = np.array(
+                    [[m.a_index, m.b_index, m.match_score] for m in ms], dtype=np.float64).reshape(-1, 3)
+    # the reference's own unit vectors (test_ncc.py, test_ssd.py, test_util.py)
+    img = np.array([[1, 2, 3, 4, 5], [6, 7, 8, 9, 10], [9, 8, 7, 6, 5], [4, 3, 2, 1, 0], [1, 2, 3, 4, 5]])
+    out["unit_ncc_perfect"] = np.array(ncc.calculate_ncc(img, img.copy(), Feature(2, 2), Feature(2, 2), 5))
+    out["unit_ncc_worst"] = np.array(ncc.calculate_ncc(img, -img, Feature(2, 2), Feature(2, 2), 5))
+    np.random.seed(55)
+    ra, rb, rs = [], [], []
+    for _ in range(20):
+        ia = np.random.rand(5, 5) + np.random.randint(-100, 100)
+        ib = np.random.rand(5, 5) + np.random.randint(-100, 100)
+        ra.append(ia); rb.append(ib)
+        rs.append(ncc.calculate_ncc(ia, ib, Feature(2, 2), Feature(2, 2), 5))
+    out["unit_ncc_random_a"] = np.array(ra)
+    out["unit_ncc_random_b"] = np.array(rb)
+    out["unit_ncc_random_scores"] = np.array(rs)
+    save("g11_matching", **out)
+
+
 if __name__ == "__main__":
     g1_eight_point_pipeline()
     g2_ransac_known_answer()
@@ -459,4 +529,5 @@ if __name__ == "__main__":
     g8_unit_vectors()
     g9_explicit_table()
     g10_line_ransac()
+    g11_matching()
     print("numpy", np.__version__)

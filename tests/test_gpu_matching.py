@@ -1,0 +1,130 @@
+"""GPU tests of the brute-force matcher: HIP score / heap-summary kernels against the oracle (bit-exact) and
+against the real reference's outputs (tests/golden/g11_matching.npz)."""
+import functools
+
+import numpy as np
+import pytest
+
+from oracle import match_oracle as mo
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu(native_lib):
+    from structure_from_motion_amd import device
+
+    device.require_gpu()
+
+
+from lib.common.feature import Feature  # noqa: E402
+from lib.feature_matching import matching, ncc, ssd  # noqa: E402
+from structure_from_motion_amd.feature_matching import _device_match  # noqa: E402
+
+COMBOS = {
+    "none": (None, None),
+    "ratio": (matching.ValidationStrategy.RATIO_TEST, {mo.RATIO_TEST}),
+    "cross": ({matching.ValidationStrategy.CROSSCHECK}, {mo.CROSSCHECK}),
+    "both": ({matching.ValidationStrategy.RATIO_TEST, matching.ValidationStrategy.CROSSCHECK}, {mo.RATIO_TEST, mo.CROSSCHECK}),
+}
+
+
+def feats(arr):
+    return [Feature(x=float(p[0]), y=float(p[1])) for p in arr]
+
+
+def images(d, metric):
+    if metric == "ssd":
+        return d["image_a"].astype(np.float64), d["image_b"].astype(np.float64)
+    return d["image_a"], d["image_b"]
+
+
+@pytest.mark.parametrize("metric,code,ws", [("ncc", 0, 9), ("ncc5", 0, 5), ("ssd", 1, 5)])
+def test_scores_bit_exact_vs_oracle_and_close_to_reference(golden, metric, code, ws):
+    d = golden("g11_matching")
+    ia, ib = images(d, metric)
+    got = _device_match.score_matrix(code, ia, ib, feats(d["feats_a"]), feats(d["feats_b"]), ws).cpu().numpy()
+    fn = mo.ssd_scores if code else mo.ncc_scores
+    np.testing.assert_array_equal(got, fn(ia, ib, d["feats_a"], d["feats_b"], ws))          # bit-exact vs oracle
+    ref = d[f"scores_{metric}"]
+    fin = np.isfinite(ref)
+    assert np.array_equal(np.isinf(got), np.isinf(ref))
+    np.testing.assert_allclose(got[fin], ref[fin], rtol=1e-13, atol=2e-15)                   # vs the real reference
+    best, arg, second = _device_match.row_summary(torch.as_tensor(ref, device="cuda"))
+    b_o, a_o, s_o = mo.row_summary(ref)
+    np.testing.assert_array_equal(best, b_o)
+    np.testing.assert_array_equal(arg, a_o)
+    np.testing.assert_array_equal(second, s_o)
+
+
+@pytest.mark.parametrize("metric,fn,ws", [("ncc", "ncc", 9), ("ncc5", "ncc", 5), ("ssd", "ssd", 5)])
+@pytest.mark.parametrize("combo", list(COMBOS))
+@pytest.mark.parametrize("thr", [0.7, 0.95])
+def test_match_lists_equal_reference(golden, metric, fn, ws, combo, thr):
+    """match_brute_force wired like apps/sfm.py:73-87 returns the real reference's match list."""
+    d = golden("g11_matching")
+    ia, ib = images(d, metric)
+    full = functools.partial(ncc.calculate_ncc if fn == "ncc" else ssd.calculate_ssd, window_size=ws)
+
+    def _create_score_function(image_a, image_b, full_score_function):
+        def ssd_score(feature_a, feature_b):
+            return full_score_function(image_a, image_b, feature_a, feature_b)
+        return ssd_score
+
+    ms = matching.match_brute_force(feats(d["feats_a"]), feats(d["feats_b"]), _create_score_function(ia, ib, full),
+                                    validation_strategies=COMBOS[combo][0], ratio_test_threshold=thr)
+    want = d[f"matches_{metric}_{combo}_{thr}"]
+    got = np.array([[m.a_index, m.b_index, m.match_score] for m in ms], dtype=np.float64).reshape(-1, 3)
+    np.testing.assert_array_equal(got[:, :2], want[:, :2])
+    np.testing.assert_allclose(got[:, 2], want[:, 2], rtol=1e-12, atol=2e-15)
+    assert all(isinstance(m, matching.Match) and isinstance(m.match_score, float) for m in ms)
+
+
+def test_reference_unit_vectors(golden):
+    """reference test_ncc.py / test_ssd.py through the single-pair API."""
+    d = golden("g11_matching")
+    img = np.array([[1, 2, 3, 4, 5], [6, 7, 8, 9, 10], [9, 8, 7, 6, 5], [4, 3, 2, 1, 0], [1, 2, 3, 4, 5]])
+    np.testing.assert_allclose(0.0, ncc.calculate_ncc(img, np.copy(img), Feature(2, 2), Feature(2, 2), 5), atol=1e-10)
+    np.testing.assert_allclose(2.0, ncc.calculate_ncc(img, -np.copy(img), Feature(2, 2), Feature(2, 2), 5))
+    for ia, ib, s in zip(d["unit_ncc_random_a"], d["unit_ncc_random_b"], d["unit_ncc_random_scores"]):
+        got = ncc.calculate_ncc(ia, ib, Feature(2, 2), Feature(2, 2), 5)
+        assert 0.0 - 1e-8 <= got < 2.0 + 1e-8
+        np.testing.assert_allclose(got, s, rtol=1e-9, atol=1e-12)
+    a = np.zeros((6, 6), dtype=int); a[:3, :3] = np.arange(1, 10).reshape(3, 3)
+    b = np.zeros((6, 6), dtype=int); b[3:, 3:] = np.arange(9, 0, -1).reshape(3, 3)
+    sq = lambda x: x ** 2
+    assert ssd.calculate_ssd(a, b, Feature(1, 1), Feature(4, 4), window_size=3) == \
+        (sq(8) + sq(6) + sq(4) + sq(2) + sq(0) + sq(2) + sq(4) + sq(6) + sq(8)) / 3 / 3
+    assert ssd.calculate_ssd(a, b, Feature(0, 0), Feature(4, 4), window_size=3) == np.inf
+    assert ssd.calculate_ssd(a, b, Feature(1, 1), Feature(5, 5), window_size=3) == np.inf
+    assert ncc.calculate_ncc(a, b, Feature(0, 0), Feature(4, 4)) == 2.0            # out of bounds
+    assert ncc.calculate_ncc(a, b, Feature(4, 1), Feature(4, 4)) == 2.0            # flat window: zero denominator
+    with pytest.raises(ValueError):
+        ncc.calculate_ncc(a, b[:, :5], Feature(1, 1), Feature(2, 2))
+
+
+@pytest.mark.parametrize("nA,nB,ws", [(1, 1, 3), (65, 64, 3), (130, 257, 9), (600, 600, 9), (1000, 1300, 7)])
+def test_large_random_vs_oracle(nA, nB, ws):
+    """Sizes around and beyond the 64x64 tile; every score, heap summary and match list against the oracle."""
+    rng = np.random.default_rng(nA * 7 + nB)
+    H, W = 120, 160
+    ia = rng.integers(0, 256, (H, W)).astype(np.uint8)
+    ib = np.roll(ia, (1, 2), axis=(0, 1))
+    ib = np.clip(ib.astype(np.int64) + rng.integers(-3, 4, (H, W)), 0, 255).astype(np.uint8)
+    fa = np.column_stack([rng.integers(-2, W + 2, nA), rng.integers(-2, H + 2, nA)]).astype(np.float64)
+    fb = np.column_stack([rng.integers(-2, W + 2, nB), rng.integers(-2, H + 2, nB)]).astype(np.float64)
+    fb[: min(nA, nB) // 2] = fa[: min(nA, nB) // 2] + [2.0, 1.0]
+    sc = _device_match.score_matrix(0, ia, ib, feats(fa), feats(fb), ws)
+    want = mo.ncc_scores(ia, ib, fa, fb, ws)
+    np.testing.assert_array_equal(sc.cpu().numpy(), want)
+    best, arg, second = _device_match.row_summary(sc)
+    b_o, a_o, s_o = mo.row_summary(want)
+    np.testing.assert_array_equal(best, b_o)
+    np.testing.assert_array_equal(arg, a_o)
+    if nB > 1:
+        np.testing.assert_array_equal(second, s_o)
+    score = matching.ImagePairScore(ia, ib, ncc.calculate_ncc, ws)
+    for name, (strat, ostrat) in COMBOS.items():
+        ms = matching.match_brute_force(feats(fa), feats(fb), score, validation_strategies=strat, ratio_test_threshold=0.7)
+        assert [(m.a_index, m.b_index, m.match_score) for m in ms] == mo.match_brute_force(want, ostrat, 0.7)
