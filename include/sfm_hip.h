@@ -186,6 +186,24 @@ int sfm_pair_scores(int metric, const double* patches_a, int64_t stride_a, const
 int sfm_match_row_summary(const double* scores, int64_t n_a, int64_t n_b, double* best, int32_t* arg,
                           double* second, void* stream);
 
+/* ---- Harris corner detector stencils (reference lib/harris/harris_detector.py, lib/common/correlate.py) ---- */
+
+/* Zero-'same' cross-correlation with an odd square kernel (correlate.py:4-39).  image, out: dev f64
+ * [height,width]; kernel: dev f64 [kernel_size,kernel_size]. */
+int sfm_cross_correlate(const double* image, int64_t height, int64_t width, const double* kernel,
+                        int kernel_size, double* out, void* stream);
+
+/* Harris cornerness det(M) - k trace(M)^2 from block sums of the Sobel products (harris_detector.py:57-86).
+ * out: dev f64 [out_height,out_width] (the reference uses height/width - round(block_size/2)); entries outside
+ * range(height-block_size) x range(width-block_size) are 0; clamp_negative applies harris_detector.py:29. */
+int sfm_harris_cornerness(const double* sobel_x, const double* sobel_y, int64_t height, int64_t width,
+                          int block_size, double k, int clamp_negative, int64_t out_height, int64_t out_width,
+                          double* out, void* stream);
+
+/* 3x3 non-maximum suppression IN PLACE in raster order, with the reference's sequential semantics
+ * (harris_detector.py:95-105): a neighbour visited earlier may already be zero.  image: dev f64 [height,width]. */
+int sfm_nms_inplace(double* image, int64_t height, int64_t width, void* stream);
+
 /* HOST: exact replay of CPython's random.shuffle as used by ransac.py:59-64.  `mt_state` is the 624-word
  * MT19937 state and `*mt_index` its position (random.getstate()[1]); both are advanced.  The cumulative
  * permutation of range(n) is shuffled `iterations` times; S_out[it,:] receives its first 8 entries.  If

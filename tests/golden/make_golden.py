@@ -518,6 +518,48 @@ def g11_matching():
     save("g11_matching", **out)
 
 
+def g12_harris():
+    """Harris detector (harris_detector.py:11-113) on small synthetic images: the filled rectangle of the
+    reference's test_harris_detector.py (drawn without OpenCV) and two random textured uint8 images."""
+    from lib.common import correlate
+    from lib.harris import harris_detector as harris
+
+    harris.tqdm.trange = lambda n, **k: range(n)
+    out = {}
+    rect = np.zeros((100, 200), dtype=float)
+    rect[25:76, 50:151] = 255.0  # cv.rectangle(background, (50, 25), (150, 75), 255, -1) fills inclusive bounds
+    rng = np.random.default_rng(7)
+    tex = rng.integers(0, 256, size=(48, 64)).astype(np.float64)
+    kern = np.array([1.0, 2.0, 1.0]) / 4.0
+    for _ in range(2):
+        tex = np.apply_along_axis(lambda r: np.convolve(r, kern, mode="same"), 0, tex)
+        tex = np.apply_along_axis(lambda r: np.convolve(r, kern, mode="same"), 1, tex)
+    tex_u8 = np.clip(tex, 0, 255).astype(np.uint8)
+    blobs = np.zeros((40, 56))
+    for (cy, cx) in rng.integers(5, 35, size=(12, 2)):
+        yy, xx = np.mgrid[0:40, 0:56]
+        blobs += 200.0 * np.exp(-((yy - cy) ** 2 + (xx - cx * 1.4) ** 2) / 6.0)
+    blobs_u8 = np.clip(blobs, 0, 255).astype(np.uint8)
+    for name, img, n in (("rect", rect, 50), ("tex", tex_u8, 60), ("blobs", blobs_u8, 25)):
+        corners = harris.detect_harris_corners(img, num_corners=n)
+        corn = harris._calculate_cornerness_image(img, 2, 0.04)
+        supp = corn.copy()
+        supp[supp < 0] = 0.0
+        harris._non_max_suppress(supp)
+        out[f"{name}_image"] = img
+        out[f"{name}_corners"] = np.array([[c.x, c.y] for c in corners]).reshape(-1, 2)
+        out[f"{name}_cornerness"] = corn
+        out[f"{name}_suppressed"] = supp
+        out[f"{name}_sobel_x"] = harris._apply_sobel_x(img)
+        out[f"{name}_sobel_y"] = harris._apply_sobel_y(img)
+        out[f"{name}_n"] = np.array(n)
+    img = np.array([[1, 5, 4, 3, 7], [2, 5, 7, 4, -10], [9, -5, 4, 3, 2]], dtype=float)  # test_correlate.py
+    ker = np.array([[1, -2, 3], [2, 1, 0], [7, -5, 1]], dtype=float)
+    out["cc_image"], out["cc_kernel"], out["cc_out"] = img, ker, correlate.cross_correlate(img, ker)
+    out["cc_ones5"] = correlate.cross_correlate(np.ones((5, 10)), np.ones((5, 5)))
+    save("g12_harris", **out)
+
+
 if __name__ == "__main__":
     g1_eight_point_pipeline()
     g2_ransac_known_answer()
@@ -530,4 +572,5 @@ if __name__ == "__main__":
     g9_explicit_table()
     g10_line_ransac()
     g11_matching()
+    g12_harris()
     print("numpy", np.__version__)

@@ -1,0 +1,91 @@
+"""GPU tests of the Harris detector stencils: bit-exact against the oracle, corner lists identical to the
+real reference (tests/golden/g12_harris.npz)."""
+import numpy as np
+import pytest
+
+from oracle import harris_oracle as ho
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu(native_lib):
+    from structure_from_motion_amd import device
+
+    device.require_gpu()
+
+
+from lib.common import correlate  # noqa: E402
+from lib.harris import harris_detector as harris  # noqa: E402
+
+
+@pytest.mark.parametrize("name", ["rect", "tex", "blobs"])
+def test_detector_equals_reference(golden, name):
+    d = golden("g12_harris")
+    img = d[f"{name}_image"]
+    np.testing.assert_array_equal(harris._apply_sobel_x(img), d[f"{name}_sobel_x"])       # bit-exact vs the reference
+    np.testing.assert_array_equal(harris._apply_sobel_y(img), d[f"{name}_sobel_y"])
+    corn = harris._calculate_cornerness_image(img, 2, 0.04)
+    np.testing.assert_array_equal(corn, ho.cornerness_image(img))                            # bit-exact vs the oracle
+    ref = d[f"{name}_cornerness"]
+    assert np.max(np.abs(corn - ref) / np.maximum(np.abs(ref), 1.0)) <= 1e-9                 # vs np.linalg.det route
+    supp = corn.copy()
+    supp[supp < 0] = 0.0
+    harris._non_max_suppress(supp)
+    np.testing.assert_array_equal(supp != 0, d[f"{name}_suppressed"] != 0)
+    corners = harris.detect_harris_corners(img, num_corners=int(d[f"{name}_n"]))
+    np.testing.assert_array_equal(np.array([[c.x, c.y] for c in corners]).reshape(-1, 2), d[f"{name}_corners"])
+
+
+def test_detect_harris_corners_rectangle(golden):
+    """reference test_harris_detector.py:13-32 (rectangle drawn without OpenCV)."""
+    image = golden("g12_harris")["rect_image"]
+    corner_coordinates = harris.detect_harris_corners(image)
+    # the order among the four exactly tied corners is pinned by the golden vector (test_detector_equals_reference)
+    expected_corners = [(75, 50), (75, 150), (25, 50), (25, 150)]
+    assert len(corner_coordinates) == 4
+    for corner in corner_coordinates:
+        assert any(np.allclose(e, (corner.y, corner.x), atol=1.0) for e in expected_corners)
+    with pytest.raises(ValueError):
+        harris.detect_harris_corners(image, num_corners=0)
+
+
+def test_cross_correlate(golden):
+    """reference test_correlate.py."""
+    d = golden("g12_harris")
+    input_image = np.ones((5, 10), dtype=float)
+    output = correlate.cross_correlate(input_image, np.ones((3, 3)))
+    assert np.allclose(output[1:-1, 1:-1], 9) and np.allclose(output[0], 0) and np.allclose(output[:, -1], 0)
+    output = correlate.cross_correlate(input_image, np.ones((5, 5)))
+    assert np.allclose(output[2:-2, 2:-2], 25)
+    np.testing.assert_array_equal(output, d["cc_ones5"])
+    np.testing.assert_array_equal(correlate.cross_correlate(d["cc_image"], d["cc_kernel"]), d["cc_out"])
+    assert correlate.cross_correlate(d["cc_image"], d["cc_kernel"])[1, 1] == \
+        1 * 1 + 5 * -2 + 4 * 3 + 2 * 2 + 5 * 1 + 7 * 0 + 9 * 7 + -5 * -5 + 4 * 1
+    with pytest.raises(ValueError):
+        correlate.cross_correlate(np.ones((5, 5)), np.ones((2, 2)))
+    with pytest.raises(ValueError):
+        correlate.cross_correlate(np.ones((2, 5)), np.ones((3, 3)))
+    with pytest.raises(ValueError):
+        correlate.cross_correlate(np.ones((5, 5, 3)), np.ones((3, 3)))
+
+
+@pytest.mark.parametrize("shape,seed", [((3, 3), 0), ((7, 300), 1), ((121, 97), 2), ((480, 640), 3)])
+def test_nms_and_detector_vs_oracle_random(shape, seed):
+    """In-place raster-order suppression (wavefront kernel) on random images with many ties, and the whole
+    detector, against the sequential oracle."""
+    rng = np.random.default_rng(seed)
+    img = rng.integers(0, 6, size=shape).astype(np.float64)       # few levels -> plenty of ties and plateaus
+    want = img.copy()
+    ho.non_max_suppress(want)
+    got = img.copy()
+    harris._non_max_suppress(got)
+    np.testing.assert_array_equal(got, want)
+    if min(shape) >= 8:
+        photo = rng.integers(0, 256, size=shape).astype(np.uint8)
+        pts, supp = ho.detect_harris_corners(photo, 200)
+        corners = harris.detect_harris_corners(photo, 200)
+        np.testing.assert_array_equal(np.array([[c.x, c.y] for c in corners]).reshape(-1, 2), pts)
+        for bs, k in ((3, 0.06), (4, 0.04)):
+            np.testing.assert_array_equal(harris._calculate_cornerness_image(photo, bs, k), ho.cornerness_image(photo, bs, k))
