@@ -394,3 +394,19 @@ def test_traced_fit_intermediates_bit_exact(golden):
     assert torch.equal(E, E_plain)                                      # tracing does not change the result
     E_o = orc.estimate_fundamental_mat(d["ca"], d["cb"])
     assert rel(E.cpu().numpy().reshape(3, 3), E_o) <= 1e-10
+
+
+def test_headless_demo_end_to_end():
+    """The whole reference pipeline (Harris -> NCC matching -> RANSAC E -> pose -> triangulation) on a rendered
+    pair, checked against the scene's ground truth (config "make demo", headless)."""
+    from apps import sfm_headless
+
+    summary = sfm_headless.run_sfm({"num_harris_corners": 400,
+                                    "ransac": {**sfm_headless.DEFAULT_CONFIG["ransac"], "max_iterations": 500}})
+    assert summary["corners"] == [400, 400]
+    assert summary["matches"] >= 60
+    assert summary["ransac_inliers"] >= 18
+    assert summary["points"] == summary["cheirality_inliers"] >= 15
+    assert summary["rotation_error_deg"] < 2.0
+    assert summary["translation_direction_error_deg"] < 12.0
+    assert summary["fraction_of_points_in_true_depth_range"] > 0.8
