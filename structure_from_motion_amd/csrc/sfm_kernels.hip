@@ -161,6 +161,67 @@ SFM_DEVICE int null_vector_of_yty(double (&a)[45], double (&f)[9], double (&w)[9
     return (second <= 1e-10) ? SFM_FIT_DEGENERATE : 0;
 }
 
+// Null vector of the 8x9 design matrix Y and the degeneracy predicate of eight_point.py:396-427, without forming
+// Y^T Y: Householder QR of Y^T gives the null vector directly (the eigenvector of Y^T Y for its ~0 eigenvalue, to
+// better accuracy than an eigen-solve of the squared matrix) and an upper-triangular R with the singular values of Y.
+// The reference's predicate "second-smallest eigenvalue of Y^T Y <= 1e-10" is sigma_min(R)^2 <= 1e-10; it is decided
+// by the rigorous bound sigma_min(R) >= 1 / ||R^-1||_F whenever that is conclusive (virtually always), and by a
+// Jacobi SVD of R otherwise or when the caller wants lambda_2 itself.  sq (if computed) = squared singular values.
+SFM_DEVICE int null_vector_of_design(const double (&xa)[8], const double (&ya)[8], const double (&xb)[8],
+                                     const double (&yb)[8], bool need_second, double (&f)[9], double& second,
+                                     double (&sq)[8]) {
+    double col[8][9];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        col[k][0] = xb[k] * xa[k]; col[k][1] = xb[k] * ya[k]; col[k][2] = xb[k];
+        col[k][3] = yb[k] * xa[k]; col[k][4] = yb[k] * ya[k]; col[k][5] = yb[k];
+        col[k][6] = xa[k];         col[k][7] = ya[k];         col[k][8] = 1.0;
+    }
+    double rdiag[8];
+    sfm::qr_null_vector(col, rdiag, f);
+    // ||R^-1||_F^2 column by column: solve R x = e_j by back substitution (x has j+1 non-zeros)
+    double fro2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        double x[8];
+#pragma unroll
+        for (int i = 7; i >= 0; --i) {
+            if (i > j) {
+                x[i] = 0.0;
+            } else {
+                double acc = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (k > i && k <= j) acc -= col[k][i] * x[k];  // R(i,k) = col[k][i] for i < k
+                x[i] = acc / rdiag[i];
+                fro2 += x[i] * x[i];
+            }
+        }
+    }
+    const double lower = 1.0 / fro2;                          // <= sigma_min(R)^2 = lambda_2
+    const bool conclusive = lower > 1e-10 * (1.0 + 1e-6);     // NaN / inf (rank-deficient R) -> not conclusive
+    int flag = 0;
+    second = lower;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sq[k] = 0.0;
+    if (need_second || !__all(conclusive)) {  // wave-uniform
+        double g[8][8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) g[c][k] = (k < c) ? col[c][k] : ((k == c) ? rdiag[c] : 0.0);
+        sfm::singular_values_sq<8>(g, sq);
+        double smallest = sq[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) smallest = fmin(smallest, sq[k]);
+        // fmin drops NaN: a NaN anywhere in the design (NaN input) must flag the sample
+        const bool poisoned = !(fro2 == fro2) && !(smallest > 1e-10);
+        second = smallest;
+        flag = (smallest <= 1e-10 || poisoned) ? SFM_FIT_DEGENERATE : 0;
+    }
+    return flag;
+}
+
 // rank-2 enforcement (eight_point.py:430-446): drop the smallest singular direction of f (row-major 3x3)
 SFM_DEVICE void enforce_rank2(const double (&f)[9], double (&fr)[3][3]) {
     double g[3][3], vv[3][3];
@@ -210,10 +271,10 @@ __global__ __launch_bounds__(kWave) void fit_eight_point_kernel(
     const Hartley t1 = hartley8(xa, ya);
     const Hartley t2 = hartley8(xb, yb);
 
-    double a[45];
-    build_yty(xa, ya, xb, yb, a);
     double* tr = nullptr;
     if constexpr (TRACE) {
+        double a[45];
+        build_yty(xa, ya, xb, yb, a);
         tr = trace + (b * h_count + h) * kTraceDoubles;
         if (active) {
 #pragma unroll
@@ -235,15 +296,16 @@ __global__ __launch_bounds__(kWave) void fit_eight_point_kernel(
         }
     }
 
-    double f[9], w[9], second;
-    const int flag = null_vector_of_yty(a, f, w, second);
+    double f[9], sq[8], second;
+    const bool need_second = TRACE || (lambda2 != nullptr);
+    const int flag = null_vector_of_design(xa, ya, xb, yb, need_second, f, second, sq);
     double fr[3][3];
     enforce_rank2(f, fr);
     if constexpr (TRACE) {
         if (active) {
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
-                tr[119 + k] = w[k];
+                tr[119 + k] = (k < 8) ? sq[k] : 0.0;  // eigenvalues of Y^T Y: sigma_k(Y)^2 and the null one
                 tr[128 + k] = f[k];
                 tr[137 + k] = fr[k / 3][k % 3];
             }

@@ -209,6 +209,106 @@ SFM_DEVICE void hestenes_svd(double (&g)[N][N], double (&v)[N][N]) {
     }
 }
 
+// One-sided Jacobi without accumulating V: on return the columns of g are orthogonal and their norms are
+// the singular values.
+template <int N, int I, int J>
+SFM_DEVICE bool hestenes_rotate_novec(double (&g)[N][N]) {
+    double alpha = 0.0, beta = 0.0, gamma = 0.0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        alpha += g[I][k] * g[I][k];
+        beta += g[J][k] * g[J][k];
+        gamma += g[I][k] * g[J][k];
+    }
+    const bool rot = fabs(gamma) > 1e-15 * sqrt(alpha * beta);
+    double c, s, t;
+    jacobi_cs(alpha, beta, rot ? gamma : 0.0, c, s, t);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const double gi = g[I][k], gj = g[J][k];
+        g[I][k] = c * gi - s * gj;
+        g[J][k] = s * gi + c * gj;
+    }
+    return rot;
+}
+
+template <int N, int I, int J>
+SFM_DEVICE bool hestenes_sweep_novec_from(double (&g)[N][N]) {
+    bool any = hestenes_rotate_novec<N, I, J>(g);
+    if constexpr (J + 1 < N) any |= hestenes_sweep_novec_from<N, I, J + 1>(g);
+    else if constexpr (I + 2 < N) any |= hestenes_sweep_novec_from<N, I + 1, I + 2>(g);
+    return any;
+}
+
+// squared singular values of the NxN matrix whose columns are g[col][.] (g is destroyed)
+template <int N>
+SFM_DEVICE void singular_values_sq(double (&g)[N][N], double (&sq)[N]) {
+#pragma unroll 1
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        const bool rotated = hestenes_sweep_novec_from<N, 0, 1>(g);
+        if (!__any(rotated)) break;
+    }
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) acc += g[c][k] * g[c][k];
+        sq[c] = acc;
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// Householder QR of the 9x8 matrix whose columns are the eight design rows y_i (9-vectors):
+//   A = Q [R; 0].  The null vector of Y = A^T is the last column of Q; the singular values of Y are those
+// of the 8x8 upper-triangular R.  No pivoting (fixed indices -> registers); backward stable.
+// On return col[j][i], i <= j, holds R(i, j); nullvec = Q e_9 (unit norm).
+// --------------------------------------------------------------------------------------------------
+SFM_DEVICE void qr_null_vector(double (&col)[8][9], double (&rdiag)[8], double (&nullvec)[9]) {
+    // Reflection J: H = I - beta v v^T with v = x - alpha e_J kept in col[J][J..8]; alpha = R(J,J) goes to rdiag.
+    // alpha takes the sign opposite to x_J, so v_J = x_J - alpha has no cancellation.
+    double beta[8];
+#pragma unroll
+    for (int J = 0; J < 8; ++J) {
+        double norm2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) norm2 += (i >= J) ? col[J][i] * col[J][i] : 0.0;
+        const double norm = sqrt(norm2);
+        const double x0 = col[J][J];
+        const double alpha = (x0 > 0.0) ? -norm : norm;
+        const double v0 = x0 - alpha;
+        const double vtv = norm2 - x0 * x0 + v0 * v0;
+        const double b = (vtv > 0.0) ? 2.0 / vtv : 0.0;
+        beta[J] = b;
+        rdiag[J] = alpha;
+        col[J][J] = v0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            if (c > J) {
+                double dot = 0.0;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) dot += (i >= J) ? col[J][i] * col[c][i] : 0.0;
+                const double scale = b * dot;
+#pragma unroll
+                for (int i = 0; i < 9; ++i)
+                    if (i >= J) col[c][i] -= scale * col[J][i];
+            }
+        }
+    }
+    // q9 = H_0 H_1 ... H_7 e_9: apply the reflections to e_9 in reverse order
+#pragma unroll
+    for (int i = 0; i < 9; ++i) nullvec[i] = (i == 8) ? 1.0 : 0.0;
+#pragma unroll
+    for (int J = 7; J >= 0; --J) {
+        double dot = 0.0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) dot += (i >= J) ? col[J][i] * nullvec[i] : 0.0;
+        const double scale = beta[J] * dot;
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+            if (i >= J) nullvec[i] -= scale * col[J][i];
+    }
+}
+
 // --------------------------------------------------------------------------------------------------
 // Right singular vector of the smallest singular value of a 4x4 matrix given by rows.
 // Replaces `np.linalg.svd(A)[2][-1]` of reference triangulation.py:34-35 (sign is irrelevant: the
