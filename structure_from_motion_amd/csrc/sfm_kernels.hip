@@ -442,37 +442,49 @@ SFM_DEVICE double aggregate_error(int aggregation, int count, double sum1, doubl
 // record is viewed as int64 (so a cross-GPU MIN all-reduce on int64 works).
 constexpr uint64_t kNoModelKey = 0x7FFFFFFFFFFFFFFFull;
 
-struct Candidate {
-    uint64_t key;
-    int64_t h;
-};
-
-SFM_DEVICE Candidate better(Candidate x, Candidate y) {
-    const bool take_y = (y.key < x.key) || (y.key == x.key && y.h < x.h);
-    return take_y ? y : x;
+// Three passes over the result record with 64-bit atomics, so that many blocks can share the scan:
+//   pass 1  key = min over gated hypotheses of the error bits; flag statistics
+//   pass 2  best_h = min index among hypotheses whose key equals the minimum (earliest wins)
+//   final   fill error / count, apply h_offset, translate "none" sentinels
+__global__ void select_init_kernel(sfm_select_result* __restrict__ result) {
+    sfm_select_result r;
+    r.key = kNoModelKey;
+    r.best_h = INT64_MAX;
+    r.best_err = INFINITY;
+    r.first_flagged = INT64_MAX;
+    r.n_flagged = 0;
+    r.best_cnt = 0;
+    result[blockIdx.x] = r;
 }
 
-__global__ __launch_bounds__(1024) void select_best_kernel(
+SFM_DEVICE uint64_t hypothesis_key(const int32_t* cnt, const double* s1, const double* s2, const int32_t* flags,
+                                   int64_t h, double min_extra, int aggregation, bool& flagged) {
+    const int ch = cnt[h];
+    const double err = aggregate_error(aggregation, ch, s1[h], s2[h]);
+    // Hypotheses whose sample was flagged degenerate never compete (the reference aborts on them).
+    flagged = flags != nullptr && flags[h] != 0;
+    // ransac.py:75 gate and :83 strict compare against an initial +inf: NaN and inf never win.
+    const bool ok = ((double)ch >= min_extra) && (err < INFINITY) && !flagged;
+    uint64_t bits = (uint64_t)__double_as_longlong(err);
+    if (bits == 0x8000000000000000ull) bits = 0;  // -0.0 orders as +0.0
+    return ok ? bits : kNoModelKey;
+}
+
+__global__ __launch_bounds__(256) void select_pass1_kernel(
     const int32_t* __restrict__ cnt, const double* __restrict__ s1, const double* __restrict__ s2,
     const int32_t* __restrict__ flags, int64_t h_count, double min_extra, int aggregation,
-    int64_t h_offset, sfm_select_result* __restrict__ result) {
-    const int64_t b = blockIdx.x;
+    sfm_select_result* __restrict__ result) {
+    const int64_t b = blockIdx.y;
     cnt += b * h_count; s1 += b * h_count; s2 += b * h_count;
     if (flags != nullptr) flags += b * h_count;
-    Candidate best = {kNoModelKey, INT64_MAX};
+    uint64_t key = kNoModelKey;
     int64_t first_flag = INT64_MAX;
     int n_flag = 0;
-    for (int64_t h = threadIdx.x; h < h_count; h += blockDim.x) {
-        const int ch = cnt[h];
-        const double err = aggregate_error(aggregation, ch, s1[h], s2[h]);
-        // ransac.py:75 gate and :83 strict compare against an initial +inf: NaN and inf never win.
-        // Hypotheses whose sample was flagged degenerate never compete (the reference aborts on them).
-        const bool flagged = flags != nullptr && flags[h] != 0;
-        const bool ok = ((double)ch >= min_extra) && (err < INFINITY) && !flagged;
-        uint64_t bits = (uint64_t)__double_as_longlong(err);
-        if (bits == 0x8000000000000000ull) bits = 0;  // -0.0 orders as +0.0
-        Candidate cand = {ok ? bits : kNoModelKey, ok ? h : INT64_MAX};
-        best = better(best, cand);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t h = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; h < h_count; h += stride) {
+        bool flagged;
+        const uint64_t k = hypothesis_key(cnt, s1, s2, flags, h, min_extra, aggregation, flagged);
+        key = k < key ? k : key;
         if (flagged) {
             first_flag = h < first_flag ? h : first_flag;
             ++n_flag;
@@ -480,41 +492,57 @@ __global__ __launch_bounds__(1024) void select_best_kernel(
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-        Candidate o;
-        o.key = __shfl_xor(best.key, off, 64);
-        o.h = __shfl_xor(best.h, off, 64);
-        best = better(best, o);
+        const uint64_t ok = __shfl_xor(key, off, 64);
+        key = ok < key ? ok : key;
         const int64_t of = __shfl_xor(first_flag, off, 64);
         first_flag = of < first_flag ? of : first_flag;
         n_flag += __shfl_xor(n_flag, off, 64);
     }
-    __shared__ Candidate sh_best[16];
-    __shared__ int64_t sh_first[16];
-    __shared__ int sh_n[16];
-    const int wave = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
-    if (lane == 0) {
-        sh_best[wave] = best;
-        sh_first[wave] = first_flag;
-        sh_n[wave] = n_flag;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int waves = blockDim.x / kWave;
-        for (int k = 1; k < waves; ++k) {
-            best = better(best, sh_best[k]);
-            first_flag = sh_first[k] < first_flag ? sh_first[k] : first_flag;
-            n_flag += sh_n[k];
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        if (key != kNoModelKey) atomicMin((unsigned long long*)&result[b].key, (unsigned long long)key);
+        if (n_flag) {
+            atomicMin((long long*)&result[b].first_flagged, (long long)first_flag);
+            atomicAdd(&result[b].n_flagged, n_flag);
         }
-        sfm_select_result r;
-        const bool found = best.key != kNoModelKey;
-        r.key = best.key;
-        r.best_h = found ? best.h + h_offset : -1;
-        r.best_err = found ? __longlong_as_double((long long)best.key) : INFINITY;
-        r.first_flagged = (first_flag == INT64_MAX) ? INT64_MAX : first_flag + h_offset;
-        r.n_flagged = n_flag;
-        r.best_cnt = found ? cnt[best.h] : 0;
-        result[b] = r;
     }
+}
+
+__global__ __launch_bounds__(256) void select_pass2_kernel(
+    const int32_t* __restrict__ cnt, const double* __restrict__ s1, const double* __restrict__ s2,
+    const int32_t* __restrict__ flags, int64_t h_count, double min_extra, int aggregation,
+    sfm_select_result* __restrict__ result) {
+    const int64_t b = blockIdx.y;
+    const uint64_t target = result[b].key;
+    if (target == kNoModelKey) return;
+    cnt += b * h_count; s1 += b * h_count; s2 += b * h_count;
+    if (flags != nullptr) flags += b * h_count;
+    int64_t best = INT64_MAX;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t h = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; h < h_count; h += stride) {
+        bool flagged;
+        const uint64_t k = hypothesis_key(cnt, s1, s2, flags, h, min_extra, aggregation, flagged);
+        if (k == target && h < best) best = h;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int64_t o = __shfl_xor(best, off, 64);
+        best = o < best ? o : best;
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0 && best != INT64_MAX)
+        atomicMin((long long*)&result[b].best_h, (long long)best);
+}
+
+__global__ void select_final_kernel(const int32_t* __restrict__ cnt, int64_t h_count, int64_t h_offset,
+                                    sfm_select_result* __restrict__ result) {
+    const int64_t b = blockIdx.x;
+    sfm_select_result r = result[b];
+    const bool found = r.key != kNoModelKey && r.best_h != INT64_MAX;
+    r.best_cnt = found ? cnt[b * h_count + r.best_h] : 0;
+    r.best_err = found ? __longlong_as_double((long long)r.key) : INFINITY;
+    r.best_h = found ? r.best_h + h_offset : -1;
+    if (!found) r.key = kNoModelKey;
+    if (r.first_flagged != INT64_MAX) r.first_flagged += h_offset;
+    result[b] = r;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -807,10 +835,19 @@ int sfm_select_best(const int32_t* cnt, const double* s1, const double* s2, cons
     if (aggregation < SFM_AGG_SUM || aggregation > SFM_AGG_RMS)
         return fail(SFM_EINVAL, "sfm_select_best: unknown aggregation");
     if (batch == 0) return SFM_OK;
+    if (batch > 65535) return fail(SFM_EINVAL, "sfm_select_best: batch > 65535");
     if (!result || (h_count > 0 && (!cnt || !s1 || !s2)))
         return fail(SFM_EINVAL, "sfm_select_best: null pointer");
-    hipLaunchKernelGGL(select_best_kernel, dim3((unsigned)batch), dim3(1024), 0, (hipStream_t)stream, cnt,
-                       s1, s2, flags, h_count, min_extra, aggregation, h_offset, result);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(select_init_kernel, dim3((unsigned)batch), dim3(1), 0, st, result);
+    if (h_count > 0) {
+        const dim3 grid(grid_for(h_count, 256, 64), (unsigned)batch);
+        hipLaunchKernelGGL(select_pass1_kernel, grid, dim3(256), 0, st, cnt, s1, s2, flags, h_count, min_extra,
+                           aggregation, result);
+        hipLaunchKernelGGL(select_pass2_kernel, grid, dim3(256), 0, st, cnt, s1, s2, flags, h_count, min_extra,
+                           aggregation, result);
+    }
+    hipLaunchKernelGGL(select_final_kernel, dim3((unsigned)batch), dim3(1), 0, st, cnt, h_count, h_offset, result);
     return check_launch("select_best_kernel");
 }
 

@@ -168,11 +168,17 @@ __global__ void score_prepare_kernel(const Corr* __restrict__ corr, int64_t n, u
         m2 = fmaxf(m2, __shfl_xor(m2, off, 64));
         m3 = fmaxf(m3, __shfl_xor(m3, off, 64));
     }
+    // one atomic per block and coordinate (all blocks hit the same cache line: keep the count low)
+    __shared__ float part[4][4];
+    const int wave = threadIdx.x / kWave;
     if ((threadIdx.x & (kWave - 1)) == 0) {
-        atomicMax(maxima + 0, __float_as_uint(m0));
-        atomicMax(maxima + 1, __float_as_uint(m1));
-        atomicMax(maxima + 2, __float_as_uint(m2));
-        atomicMax(maxima + 3, __float_as_uint(m3));
+        part[wave][0] = m0; part[wave][1] = m1; part[wave][2] = m2; part[wave][3] = m3;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const float m = fmaxf(fmaxf(part[0][threadIdx.x], part[1][threadIdx.x]),
+                              fmaxf(part[2][threadIdx.x], part[3][threadIdx.x]));
+        atomicMax(maxima + threadIdx.x, __float_as_uint(m));
     }
 }
 
@@ -434,7 +440,7 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
         hipError_t err = hipMemsetAsync(ws, 0, 16 * batch, st);
         if (err != hipSuccess) return fail(SFM_EHIP, hipGetErrorString(err));
     }
-    hipLaunchKernelGGL(score_prepare_kernel, dim3(grid_for(n, 256, 256), (unsigned)batch), dim3(256), 0, st,
+    hipLaunchKernelGGL(score_prepare_kernel, dim3(grid_for(n, 256, 64), (unsigned)batch), dim3(256), 0, st,
                        (const Corr*)corr, n, ws);
     int rc = check_launch("score_prepare_kernel");
     if (rc != SFM_OK) return rc;
