@@ -204,6 +204,15 @@ int sfm_harris_cornerness(const double* sobel_x, const double* sobel_y, int64_t 
  * (harris_detector.py:95-105): a neighbour visited earlier may already be zero.  image: dev f64 [height,width]. */
 int sfm_nms_inplace(double* image, int64_t height, int64_t width, void* stream);
 
+/* The same suppression as a parallel fixpoint (fast path): call sfm_nms_round repeatedly on a zero-initialised
+ * state array (dev uint8 [height,width]: 0 unknown, 1 survives, 2 suppressed) until *unresolved (dev int32, zeroed
+ * by the caller before each round) stays 0, then sfm_nms_finalize zeroes the suppressed pixels of `image` in place.
+ * The number of rounds is the longest chain of strictly increasing raster-earlier neighbours (a handful on natural
+ * images); the result is identical to sfm_nms_inplace. */
+int sfm_nms_round(const double* image, uint8_t* state, int64_t height, int64_t width, int32_t* unresolved,
+                  void* stream);
+int sfm_nms_finalize(double* image, const uint8_t* state, int64_t height, int64_t width, void* stream);
+
 /* HOST: exact replay of CPython's random.shuffle as used by ransac.py:59-64.  `mt_state` is the 624-word
  * MT19937 state and `*mt_index` its position (random.getstate()[1]); both are advanced.  The cumulative
  * permutation of range(n) is shuffled `iterations` times; S_out[it,:] receives its first 8 entries.  If

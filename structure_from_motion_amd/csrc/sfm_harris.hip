@@ -78,6 +78,61 @@ __global__ __launch_bounds__(1024) void nms_inplace_kernel(double* image, int64_
     }
 }
 
+// The same in-place raster-order suppression as a parallel fixpoint.  A pixel p is suppressed iff some neighbour
+// holds a larger value at the moment p is visited: a raster-LATER neighbour still has its original value; a
+// raster-EARLIER neighbour q counts only if it survived itself (otherwise it already reads 0).  So
+//   dead(p)  <=> exists later q: orig(q) > orig(p),  or  exists earlier q: orig(q) > orig(p) and alive(q)
+//   alive(p) <=> no later q is larger, and every larger earlier q is dead.
+// Dependencies only point to strictly larger earlier neighbours, so they form a DAG; each round resolves every
+// pixel whose larger earlier neighbours are resolved (states only move unknown -> alive/dead, so reading a stale
+// "unknown" merely postpones a decision).  Rounds needed = longest such chain: a handful on natural images.
+// state: 0 unknown, 1 alive, 2 dead.  unresolved[0] receives the number of pixels still unknown after the round.
+__global__ void nms_round_kernel(const double* __restrict__ image, uint8_t* state, int64_t h, int64_t w,
+                                 int32_t* __restrict__ unresolved) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t r = blockIdx.y;
+    int pending = 0;
+    if (c < w && state[r * w + c] == 0) {
+        const double v = image[r * w + c];
+        bool dead = false;
+        // raster-later neighbours: original values
+        if (c + 1 < w && image[r * w + c + 1] > v) dead = true;
+        if (r + 1 < h) {
+            if (c > 0 && image[(r + 1) * w + c - 1] > v) dead = true;
+            if (image[(r + 1) * w + c] > v) dead = true;
+            if (c + 1 < w && image[(r + 1) * w + c + 1] > v) dead = true;
+        }
+        // raster-earlier neighbours: only survivors count
+        auto earlier = [&](int64_t rr, int64_t cc) {
+            if (image[rr * w + cc] > v) {
+                const uint8_t st = state[rr * w + cc];
+                if (st == 1) dead = true;
+                else if (st == 0) pending = 1;
+            }
+        };
+        if (c > 0) earlier(r, c - 1);
+        if (r > 0) {
+            if (c > 0) earlier(r - 1, c - 1);
+            earlier(r - 1, c);
+            if (c + 1 < w) earlier(r - 1, c + 1);
+        }
+        if (dead) {
+            state[r * w + c] = 2;
+            pending = 0;
+        } else if (!pending) {
+            state[r * w + c] = 1;
+        }
+    }
+    // count what is left
+    const unsigned long long mask = __ballot(pending != 0);
+    if ((threadIdx.x & (kWave - 1)) == 0 && mask != 0ull) atomicAdd(unresolved, (int)__popcll(mask));
+}
+
+__global__ void nms_finalize_kernel(double* __restrict__ image, const uint8_t* __restrict__ state, int64_t count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count && state[i] != 1) image[i] = 0.0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -114,6 +169,24 @@ int sfm_nms_inplace(double* image, int64_t height, int64_t width, void* stream) 
     if (!image) return fail(SFM_EINVAL, "sfm_nms_inplace: null pointer");
     hipLaunchKernelGGL(nms_inplace_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, image, height, width);
     return check_launch("nms_inplace_kernel");
+}
+
+int sfm_nms_round(const double* image, uint8_t* state, int64_t height, int64_t width, int32_t* unresolved,
+                  void* stream) {
+    if (height <= 0 || width <= 0 || height > 65535) return fail(SFM_EINVAL, "sfm_nms_round: bad size");
+    if (!image || !state || !unresolved) return fail(SFM_EINVAL, "sfm_nms_round: null pointer");
+    hipLaunchKernelGGL(nms_round_kernel, dim3(grid_for(width, 256), (unsigned)height), dim3(256), 0,
+                       (hipStream_t)stream, image, state, height, width, unresolved);
+    return check_launch("nms_round_kernel");
+}
+
+int sfm_nms_finalize(double* image, const uint8_t* state, int64_t height, int64_t width, void* stream) {
+    if (height < 0 || width < 0) return fail(SFM_EINVAL, "sfm_nms_finalize: negative size");
+    if (height == 0 || width == 0) return SFM_OK;
+    if (!image || !state) return fail(SFM_EINVAL, "sfm_nms_finalize: null pointer");
+    hipLaunchKernelGGL(nms_finalize_kernel, dim3(grid_for(height * width, 256)), dim3(256), 0, (hipStream_t)stream,
+                       image, state, height * width);
+    return check_launch("nms_finalize_kernel");
 }
 
 }  // extern "C"

@@ -427,7 +427,8 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
     const int64_t waves = (h_count + kHypPerWave - 1) / kHypPerWave;
     const dim3 grid(grid_for(waves, 256 / kWave), (unsigned)batch);
     if (workspace == nullptr) {
-        hipLaunchKernelGGL(score_sed_exact_kernel<kHypPerWave>, grid, dim3(256), 0, st, (const Corr*)corr, (int)n,
+        static const int exact_dynlds = getenv("SFM_SCORE_DYNLDS") ? atoi(getenv("SFM_SCORE_DYNLDS")) : 0;  // diagnostics only
+        hipLaunchKernelGGL(score_sed_exact_kernel<kHypPerWave>, grid, dim3(256), exact_dynlds, st, (const Corr*)corr, (int)n,
                            E, S, (int)h_count, thr, cnt, s1, s2);
         return check_launch("score_sed_exact_kernel");
     }

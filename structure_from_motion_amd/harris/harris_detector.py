@@ -28,13 +28,31 @@ def detect_harris_corners(
     if num_corners <= 0:
         raise ValueError("num_corners needs to be at least 1")
     suppressed = _suppressed_cornerness(image, block_size, k).cpu().numpy()
-    # same NumPy selection as the reference (harris_detector.py:32-42): descending argsort, cut, drop zeros
-    order = np.flip(np.argsort(suppressed, axis=None))[:num_corners]
-    order = [i for i in order if suppressed[np.unravel_index(i, suppressed.shape)] != 0]
+    order = _strongest_indices(suppressed, num_corners)
     y_indices, x_indices = np.unravel_index(order, suppressed.shape)
     ys = y_indices.astype(float) + float(block_size) / 2.0
     xs = x_indices.astype(float) + float(block_size) / 2.0
     return [feature.Feature(x=x, y=y) for y, x in zip(ys, xs)]
+
+
+def _strongest_indices(suppressed: np.ndarray, num_corners: int) -> np.ndarray:
+    """Flat indices the reference selects (harris_detector.py:32-42): ``np.flip(np.argsort(all pixels))``, cut to
+    ``num_corners``, zeros dropped.  After suppression almost every pixel is zero, so only the non-zero pixels
+    are sorted; when two of the values that matter are exactly equal their order depends on NumPy's (unstable)
+    sort of the full array, and the reference's literal expression is evaluated instead."""
+    flat = suppressed.ravel()
+    nonzero = np.flatnonzero(flat)
+    if len(nonzero) == 0:
+        return np.zeros(0, dtype=np.int64)
+    values = flat[nonzero]
+    by_value = np.argsort(-values, kind="stable")
+    keep = min(num_corners, len(nonzero))
+    head = values[by_value[:min(keep + 1, len(nonzero))]]
+    ties = bool(np.any(head[1:] == head[:-1]))
+    if ties:
+        order = np.flip(np.argsort(suppressed, axis=None))[:num_corners]
+        return np.array([i for i in order if flat[i] != 0], dtype=np.int64)
+    return nonzero[by_value[:keep]].astype(np.int64)
 
 
 def _image_tensor(image: np.ndarray) -> torch.Tensor:
@@ -57,10 +75,35 @@ def _cornerness_device(image_t: torch.Tensor, block_size: int, k: float, clamp: 
     return out
 
 
-def _suppressed_cornerness(image: np.ndarray, block_size: int, k: float) -> torch.Tensor:
+_ROUNDS_PER_CHECK = 12
+_MAX_ROUNDS = 96
+
+
+def _nms_device(t: torch.Tensor) -> None:
+    """In-place raster-order suppression of a device image.  Fast path: parallel fixpoint rounds
+    (``nms_round_kernel``), checked every few rounds; images with very long dependency chains fall back to the
+    single-block wavefront sweep (``nms_inplace_kernel``).  Both reproduce the reference's sequential result."""
     lib = _native.load()
+    h, w = t.shape
+    if h == 0 or w == 0:
+        return
+    st = device._stream()
+    state = torch.zeros((h, w), dtype=torch.uint8, device=t.device)
+    left = torch.zeros((_MAX_ROUNDS,), dtype=torch.int32, device=t.device)
+    done = 0
+    while done < _MAX_ROUNDS:
+        for i in range(done, done + _ROUNDS_PER_CHECK):
+            check(lib.sfm_nms_round(t.data_ptr(), state.data_ptr(), h, w, left[i:].data_ptr(), st), "sfm_nms_round")
+        done += _ROUNDS_PER_CHECK
+        if int(left[done - 1].cpu()) == 0:
+            check(lib.sfm_nms_finalize(t.data_ptr(), state.data_ptr(), h, w, st), "sfm_nms_finalize")
+            return
+    check(lib.sfm_nms_inplace(t.data_ptr(), h, w, st), "sfm_nms_inplace")  # `t` is still untouched here
+
+
+def _suppressed_cornerness(image: np.ndarray, block_size: int, k: float) -> torch.Tensor:
     corn = _cornerness_device(_image_tensor(image), block_size, k, clamp=True)
-    check(lib.sfm_nms_inplace(corn.data_ptr(), corn.shape[0], corn.shape[1], device._stream()), "sfm_nms_inplace")
+    _nms_device(corn)
     return corn
 
 
@@ -71,9 +114,8 @@ def _calculate_cornerness_image(image: np.ndarray, block_size: int = 2, k: float
 
 def _non_max_suppress(image: np.ndarray):
     """Zero, IN PLACE and in raster order, every pixel smaller than the maximum of its 3x3 neighbourhood."""
-    lib = _native.load()
     t = _image_tensor(image)
-    check(lib.sfm_nms_inplace(t.data_ptr(), t.shape[0], t.shape[1], device._stream()), "sfm_nms_inplace")
+    _nms_device(t)
     image[...] = t.cpu().numpy()
 
 

@@ -89,3 +89,26 @@ def test_nms_and_detector_vs_oracle_random(shape, seed):
         np.testing.assert_array_equal(np.array([[c.x, c.y] for c in corners]).reshape(-1, 2), pts)
         for bs, k in ((3, 0.06), (4, 0.04)):
             np.testing.assert_array_equal(harris._calculate_cornerness_image(photo, bs, k), ho.cornerness_image(photo, bs, k))
+
+
+def test_nms_fixpoint_equals_wavefront_and_oracle():
+    """Both device formulations of the in-place raster-order suppression agree with the sequential oracle,
+    including adversarial monotone ramps (dependency chains as long as the image) that force the wavefront fallback."""
+    import torch
+    from structure_from_motion_amd import _native, device
+    from structure_from_motion_amd._native import check
+
+    lib = _native.load()
+    rng = np.random.default_rng(5)
+    cases = [rng.integers(0, 4, (37, 53)).astype(float), rng.random((64, 200)),
+             np.add.outer(np.arange(40.0), np.arange(150.0))[::-1, ::-1].copy(),      # increasing towards the origin
+             np.add.outer(np.arange(40.0), np.arange(150.0)), np.zeros((5, 7)), np.ones((9, 9))]
+    for img in cases:
+        want = img.copy()
+        ho.non_max_suppress(want)
+        a = img.copy()
+        harris._non_max_suppress(a)                       # fixpoint path (with its built-in fallback)
+        np.testing.assert_array_equal(a, want)
+        t = device.to_device(img)
+        check(lib.sfm_nms_inplace(t.data_ptr(), t.shape[0], t.shape[1], device._stream()), "sfm_nms_inplace")
+        np.testing.assert_array_equal(t.cpu().numpy(), want)   # wavefront kernel on its own
