@@ -581,3 +581,39 @@ def test_batched_pipeline_status_codes(dev):
     res = pipe.results()
     assert res[1].status == batched.NO_MODEL
     assert res[0].status in (batched.OK, batched.NO_MODEL)
+
+
+def test_filtered_score_randomized_sweep(dev):
+    """200 random (matrix family, scale, threshold, size) combinations: the two-tier kernel's counts equal the
+    all-fp64 kernel's bit for bit, sums to summation-order accuracy."""
+    rng = np.random.default_rng(2024)
+    _, _, _, corr_full = scene(6000)
+    total_checked = 0
+    for trial in range(200):
+        n = int(rng.integers(8, 6000))
+        h = int(rng.integers(1, 70))
+        corr = corr_full[rng.permutation(len(corr_full))[:n]].copy()
+        family = trial % 5
+        if family == 0:      # fitted hypotheses (the realistic case)
+            S = orc.philox_sample_table(trial, 0, h, n)
+            E, _, _ = orc.fit_hypotheses(corr, S)
+        else:
+            S = orc.philox_sample_table(trial, 0, h, n)
+            E = rng.normal(size=(h, 3, 3))
+            if family == 1:  # random dense matrices
+                pass
+            elif family == 2:  # rank-1-ish / tiny third column: loose bounds, heavy cancellation
+                E[:, :, 2] *= 1e-6
+            elif family == 3:  # huge dynamic range between entries
+                E *= 10.0 ** rng.integers(-8, 9, size=(h, 3, 3))
+            else:            # nearly singular rows
+                E[:, 1] = E[:, 0] * (1.0 + 1e-9 * rng.normal(size=(h, 1)))
+            E[:, 2, 2] = 1.0
+        E = E * 10.0 ** float(rng.integers(-40, 41))
+        if trial % 7 == 0:
+            corr[:, :] *= 50.0  # far outside the normalised range (larger coordinate maxima)
+        thr = float(10.0 ** rng.uniform(-12, 2)) if trial % 11 else 0.0
+        exact, filt = _score_both(dev, corr, E, S, thr)
+        _assert_same_scores(exact, filt)
+        total_checked += n * h
+    assert total_checked > 5e6
