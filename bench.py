@@ -49,7 +49,8 @@ def cpu_baseline(corr: np.ndarray, seed: int, target_seconds: float):
     bounded number of hypotheses of the same workload.  The oracle is only the thing timed here."""
     from oracle import sfm_oracle as orc
 
-    subprocess.run(["make", "-s", "-C", os.path.join(REPO, "oracle")], check=True)
+    # build output (if any) goes to stderr: stdout carries exactly one JSON line
+    subprocess.run(["make", "-s", "-C", os.path.join(REPO, "oracle")], check=True, stdout=sys.stderr)
     lib = C.CDLL(os.path.join(REPO, "oracle", "libsfm_oracle.so"))
     lib.sfm_oracle_score.restype = C.c_int
     lib.sfm_oracle_score.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_double,
