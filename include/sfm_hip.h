@@ -98,10 +98,10 @@ int sfm_hartley_normalize(const double* coords, int64_t n, double* out, void* st
  * (ransac.py:66-82 with epipolar_ransac.py:18-25 / sed.py:7-30 as the scorer).
  * cnt[b,h] = #non-sample points with sed <= thr; s1 / s2 = sum of sed / sed^2 over the 8 sample points
  * plus those survivors.  cnt: dev int32 [batch,h_count]; s1, s2: dev [batch,h_count].
- * workspace: dev scratch of at least sfm_score_workspace_bytes(n, batch) bytes, 16-byte aligned; it
- * enables the two-tier kernel (conservative fp32 pre-filter + exact fp64 evaluation of the survivors;
- * identical counts and inlier decisions).  NULL selects the all-fp64 kernel. */
-int64_t sfm_score_workspace_bytes(int64_t n, int64_t batch);
+ * workspace: dev scratch of at least sfm_score_workspace_bytes(n, h_count, batch) bytes, 16-byte aligned; it
+ * enables the two-tier kernel (conservative fp32 pre-filter + exact fp64 evaluation of the survivors, hypotheses
+ * processed longest-first; identical counts and inlier decisions).  NULL selects the all-fp64 kernel. */
+int64_t sfm_score_workspace_bytes(int64_t n, int64_t h_count, int64_t batch);
 int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t* S, int64_t h_count,
                   int64_t batch, double thr, int32_t* cnt, double* s1, double* s2, void* workspace,
                   int64_t workspace_bytes, void* stream);

@@ -15,7 +15,7 @@ AGG_SUM, AGG_SQUARE, AGG_MEAN, AGG_RMS = 0, 1, 2, 3
 FIT_DEGENERATE = 1
 MATCH_NCC, MATCH_SSD = 0, 1
 INT64_MAX = (1 << 63) - 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class SelectResult(C.Structure):
@@ -96,7 +96,7 @@ def load() -> C.CDLL:
     lib.sfm_fit_trace_doubles.restype = C.c_int
     lib.sfm_fit_trace_doubles.argtypes = []
     lib.sfm_score_workspace_bytes.restype = C.c_int64
-    lib.sfm_score_workspace_bytes.argtypes = [_I64, _I64]
+    lib.sfm_score_workspace_bytes.argtypes = [_I64, _I64, _I64]
     if lib.sfm_abi_version() != ABI_VERSION:
         raise NativeLibraryError(
             f"libsfm_hip.so ABI {lib.sfm_abi_version()} != expected {ABI_VERSION}; rebuild it")

@@ -138,16 +138,27 @@ __global__ __launch_bounds__(256) void score_sed_exact_kernel(
 // ------------------------------------------------------------------------------------------------
 // Workspace preparation for the filtered kernel: fp32 copy of the correspondences and the data-set
 // maxima of |xa|, |ya|, |xb|, |yb| (as fp32 bit patterns: non-negative floats order like unsigned ints).
-// Workspace layout: [batch x 4 uint32 maxima][batch x n float4].
+// Workspace layout: [batch x 4 uint32 maxima][batch x n float4][batch x kBuckets int32][batch x h_count int32].
 // ------------------------------------------------------------------------------------------------
-__host__ __device__ inline int64_t workspace_bytes_for(int64_t n, int64_t batch) { return 16 * batch + 16 * n * batch; }
+constexpr int kEstimatePoints = 1024;             // points scanned by the cost pre-pass
+constexpr int kClasses = 12;                      // coarse cost classes: 10 - floor(log2(survivors)), 0 survivors last
+constexpr int kClassStride = 16;                  // ints between class counters: one 64-byte line each
+constexpr int kBuckets = 16 * kClassStride;       // ints reserved per batch entry
+__host__ __device__ inline int64_t ws_points_offset(int64_t batch) { return 16 * batch; }
+__host__ __device__ inline int64_t ws_buckets_offset(int64_t n, int64_t batch) { return 16 * batch + 16 * n * batch; }
+__host__ __device__ inline int64_t ws_order_offset(int64_t n, int64_t batch) {
+    return ws_buckets_offset(n, batch) + ((4 * (int64_t)kBuckets * batch + 15) / 16) * 16;
+}
+__host__ __device__ inline int64_t workspace_bytes_for(int64_t n, int64_t h_count, int64_t batch) {
+    return ws_order_offset(n, batch) + 4 * h_count * batch;
+}
 
 __global__ void score_prepare_kernel(const Corr* __restrict__ corr, int64_t n, unsigned char* __restrict__ ws) {
     const int64_t b = blockIdx.y;
     const int64_t batch = gridDim.y;
     const Corr* pts = corr + b * n;
     uint32_t* maxima = reinterpret_cast<uint32_t*>(ws + 16 * b);
-    float4* out = reinterpret_cast<float4*>(ws + 16 * batch) + b * n;
+    float4* out = reinterpret_cast<float4*>(ws + ws_points_offset(batch)) + b * n;
     float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -235,25 +246,161 @@ SFM_DEVICE bool filter_rejects(const FilterConsts& f, float T, float xa, float y
 }
 
 // ------------------------------------------------------------------------------------------------
+// Load balancing.  A hypothesis that fits the scene keeps ~half of the points in tier 2 and costs several
+// times the average; with only a few generations of waves per launch, such waves starting late leave the chip
+// idle at the end.  A pre-pass estimates every hypothesis' tier-2 load (filter survivors among the first 1024
+// points), a counting sort orders hypotheses by decreasing estimate, and the scoring kernel walks that order
+// (longest first).  Results are still written at each hypothesis' own index: the order only affects speed.
+// ------------------------------------------------------------------------------------------------
+template <int HPW>
+__global__ __launch_bounds__(256) void score_estimate_kernel(const unsigned char* __restrict__ ws, int n,
+                                                             const double* __restrict__ E, int h_count, double thr,
+                                                             int32_t* __restrict__ estimate) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = blockIdx.x * (256 / kWave) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    const int h0 = wave * HPW;
+    if (h0 >= h_count) return;
+    const int64_t b = blockIdx.y;
+    const double* __restrict__ Eb = E + b * (int64_t)h_count * 9;
+    const uint32_t* maxima = reinterpret_cast<const uint32_t*>(ws + 16 * b);
+    const float4* __restrict__ pts32 =
+        reinterpret_cast<const float4*>(ws + ws_points_offset(gridDim.y)) + b * (int64_t)n;
+    const float Xa = __uint_as_float(maxima[0]) * (1.0f + 1e-6f);
+    const float Ya = __uint_as_float(maxima[1]) * (1.0f + 1e-6f);
+    const float Xb = __uint_as_float(maxima[2]) * (1.0f + 1e-6f);
+    const float Yb = __uint_as_float(maxima[3]) * (1.0f + 1e-6f);
+    const float T = (thr >= 0.0) ? (float)(thr * (1.0 + 1.0 / 1024.0) * (1.0 + 1e-5)) * (1.0f + 2e-7f) : INFINITY;
+    FilterConsts f[HPW];
+    int c[HPW];
+#pragma unroll
+    for (int k = 0; k < HPW; ++k) {
+        const int h = min(h0 + k, h_count - 1);
+        double e[9];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) e[j] = Eb[(int64_t)h * 9 + j];
+        f[k] = make_filter_consts(e, Xa, Ya, Xb, Yb);
+        c[k] = 0;
+    }
+    const int limit = min(n, kEstimatePoints);
+    for (int i = lane; i < limit; i += kWave) {
+        const float4 p = pts32[i];
+#pragma unroll
+        for (int k = 0; k < HPW; ++k) c[k] += filter_rejects(f[k], T, p.x, p.y, p.z, p.w) ? 0 : 1;
+    }
+#pragma unroll
+    for (int k = 0; k < HPW; ++k) {
+        const int total = sfm::wave_sum(c[k]);
+        const int h = h0 + k;
+        if (h < h_count && lane == 0) estimate[b * (int64_t)h_count + h] = total;
+    }
+}
+
+SFM_DEVICE int cost_class(int survivors) {  // 0 = heaviest ... kClasses-1 = no survivors at all
+    return survivors <= 0 ? kClasses - 1 : max(0, 10 - (31 - __builtin_clz((unsigned)survivors)));
+}
+
+// Histogram of the cost classes: waves combine through LDS, one global atomic per block and class, and every
+// class counter sits on its own cache line (atomics on one line serialise at ~10 ns each).
+__global__ __launch_bounds__(256) void score_class_count_kernel(const int32_t* __restrict__ estimate, int h_count,
+                                                                int32_t* __restrict__ buckets) {
+    __shared__ int block_count[kClasses];
+    const int64_t b = blockIdx.y;
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    const int cls = h < h_count ? cost_class(estimate[b * (int64_t)h_count + h]) : -1;
+    const int lane = threadIdx.x & (kWave - 1);
+    if (threadIdx.x < kClasses) block_count[threadIdx.x] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < kClasses; ++c) {
+        const unsigned long long mask = __ballot(cls == c);
+        if (lane == 0 && mask != 0ull) atomicAdd(&block_count[c], (int)__popcll(mask));
+    }
+    __syncthreads();
+    if (threadIdx.x < kClasses && block_count[threadIdx.x] != 0)
+        atomicAdd(buckets + b * kBuckets + threadIdx.x * kClassStride, block_count[threadIdx.x]);
+}
+
+// counts -> start offsets (heaviest class first); one thread per batch entry
+__global__ void score_class_scan_kernel(int32_t* __restrict__ buckets, int64_t batch) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    int run = 0;
+    for (int c = 0; c < kClasses; ++c) {
+        const int v = buckets[b * kBuckets + c * kClassStride];
+        buckets[b * kBuckets + c * kClassStride] = run;
+        run += v;
+    }
+}
+
+// order[...] = hypothesis indices grouped by class, heaviest first (arbitrary order inside a class)
+__global__ __launch_bounds__(256) void score_class_scatter_kernel(const int32_t* __restrict__ estimate, int h_count,
+                                                                  int32_t* __restrict__ buckets,
+                                                                  int32_t* __restrict__ order) {
+    __shared__ int wave_count[256 / kWave][kClasses];
+    __shared__ int wave_base[256 / kWave][kClasses];
+    const int64_t b = blockIdx.y;
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    const int cls = h < h_count ? cost_class(estimate[b * (int64_t)h_count + h]) : -1;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    int before_me = 0;
+#pragma unroll
+    for (int c = 0; c < kClasses; ++c) {
+        const unsigned long long mask = __ballot(cls == c);
+        if (lane == 0) wave_count[wave][c] = (int)__popcll(mask);
+        if (cls == c)
+            before_me = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+    }
+    __syncthreads();
+    if (threadIdx.x < kClasses) {
+        const int c = threadIdx.x;
+        int total = 0;
+        for (int w = 0; w < 256 / kWave; ++w) total += wave_count[w][c];
+        int base = total ? atomicAdd(buckets + b * kBuckets + c * kClassStride, total) : 0;
+        for (int w = 0; w < 256 / kWave; ++w) {
+            wave_base[w][c] = base;
+            base += wave_count[w][c];
+        }
+    }
+    __syncthreads();
+    if (cls >= 0) order[b * (int64_t)h_count + wave_base[wave][cls] + before_me] = h;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Filtered kernel.
 // ------------------------------------------------------------------------------------------------
 template <int HPW, int MODE = 0>
 __global__ __launch_bounds__(256) void score_sed_filtered_kernel(
     const Corr* __restrict__ corr, const unsigned char* __restrict__ ws, int n,
     const double* __restrict__ E, const int32_t* __restrict__ S, int h_count, double thr,
-    int32_t* __restrict__ cnt, double* __restrict__ s1, double* __restrict__ s2) {
+    const int32_t* __restrict__ order, int32_t* __restrict__ cnt, double* __restrict__ s1,
+    double* __restrict__ s2) {
     __shared__ int32_t ring[256 / kWave][HPW][kRing];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     const int wave = blockIdx.x * (256 / kWave) + wave_in_block;
-    const int h0 = wave * HPW;
+    const int h0 = wave * HPW;  // first of this wave's HPW slots in the processing order
     if (h0 >= h_count) return;
     const int64_t b = blockIdx.y;
+    // slot -> hypothesis index (longest-first order from the pre-pass, or the identity)
+    // With an order, the list (heaviest first) is dealt column-major over the waves: wave w takes entries
+    // w, W + w, 2W + w, 3W + w (W = number of waves), i.e. one heavy and progressively lighter hypotheses, so
+    // all waves carry about the same load.  Without an order the wave takes HPW consecutive hypotheses.
+    const int waves_total = (h_count + HPW - 1) / HPW;
+    int hyp[HPW];
+    bool slot_valid[HPW];
+#pragma unroll
+    for (int k = 0; k < HPW; ++k) {
+        const int slot = order != nullptr ? k * waves_total + wave : h0 + k;
+        slot_valid[k] = slot < h_count;
+        const int s = min(slot, h_count - 1);
+        hyp[k] = order != nullptr ? __builtin_amdgcn_readfirstlane(order[b * (int64_t)h_count + s]) : s;
+    }
     const Corr* __restrict__ pts = corr + b * (int64_t)n;
     const double* __restrict__ Eb = E + b * (int64_t)h_count * 9;
     const int32_t* __restrict__ Sb = S + b * (int64_t)h_count * 8;
     const uint32_t* maxima = reinterpret_cast<const uint32_t*>(ws + 16 * b);
-    const float4* __restrict__ pts32 = reinterpret_cast<const float4*>(ws + 16 * (int64_t)gridDim.y) + b * (int64_t)n;
+    const float4* __restrict__ pts32 =
+        reinterpret_cast<const float4*>(ws + ws_points_offset(gridDim.y)) + b * (int64_t)n;
 
     // data-set coordinate maxima, inflated so they also bound the unrounded fp64 coordinates
     const float Xa = __uint_as_float(maxima[0]) * (1.0f + 1e-6f);
@@ -266,7 +413,7 @@ __global__ __launch_bounds__(256) void score_sed_filtered_kernel(
     FilterConsts f[HPW];
 #pragma unroll
     for (int k = 0; k < HPW; ++k) {
-        const int h = min(h0 + k, h_count - 1);
+        const int h = hyp[k];
         double e[9];
 #pragma unroll
         for (int j = 0; j < 9; ++j) e[j] = Eb[(int64_t)h * 9 + j];
@@ -295,7 +442,7 @@ __global__ __launch_bounds__(256) void score_sed_filtered_kernel(
 
     // tier 2: exact fp64 evaluation of `count` (<= 64) queued points of hypothesis k
     auto drain = [&](int k, int count) __attribute__((always_inline)) {
-        const int h = min(h0 + k, h_count - 1);
+        const int h = hyp[k];
         double e[9];
 #pragma unroll
         for (int j = 0; j < 9; ++j) e[j] = Eb[(int64_t)h * 9 + j];
@@ -395,8 +542,8 @@ __global__ __launch_bounds__(256) void score_sed_filtered_kernel(
 
 #pragma unroll
     for (int k = 0; k < HPW; ++k) {
-        const int h = h0 + k;
-        if (h < h_count) {  // wave-uniform
+        const int h = hyp[k];
+        if (slot_valid[k]) {  // wave-uniform: this slot exists
             double e[9];
 #pragma unroll
             for (int j = 0; j < 9; ++j) e[j] = Eb[(int64_t)h * 9 + j];
@@ -410,9 +557,9 @@ __global__ __launch_bounds__(256) void score_sed_filtered_kernel(
 
 extern "C" {
 
-int64_t sfm_score_workspace_bytes(int64_t n, int64_t batch) {
-    if (n < 0 || batch < 0) return -1;
-    return workspace_bytes_for(n, batch);
+int64_t sfm_score_workspace_bytes(int64_t n, int64_t h_count, int64_t batch) {
+    if (n < 0 || h_count < 0 || batch < 0) return -1;
+    return workspace_bytes_for(n, h_count, batch);
 }
 
 int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t* S, int64_t h_count,
@@ -432,25 +579,47 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
                            E, S, (int)h_count, thr, cnt, s1, s2);
         return check_launch("score_sed_exact_kernel");
     }
-    if (workspace_bytes < sfm_score_workspace_bytes(n, batch))
-        return fail(SFM_EINVAL, "sfm_score_sed: workspace smaller than sfm_score_workspace_bytes(n, batch)");
+    if (workspace_bytes < sfm_score_workspace_bytes(n, h_count, batch))
+        return fail(SFM_EINVAL, "sfm_score_sed: workspace smaller than sfm_score_workspace_bytes(n, h_count, batch)");
     if ((reinterpret_cast<uintptr_t>(workspace) & 15u) != 0)
         return fail(SFM_EINVAL, "sfm_score_sed: workspace must be 16-byte aligned");
     unsigned char* ws = static_cast<unsigned char*>(workspace);
+    int32_t* buckets = reinterpret_cast<int32_t*>(ws + ws_buckets_offset(n, batch));
+    int32_t* order = reinterpret_cast<int32_t*>(ws + ws_order_offset(n, batch));
     {
         hipError_t err = hipMemsetAsync(ws, 0, 16 * batch, st);
+        if (err == hipSuccess) err = hipMemsetAsync(buckets, 0, 4 * (size_t)kBuckets * batch, st);
         if (err != hipSuccess) return fail(SFM_EHIP, hipGetErrorString(err));
     }
     hipLaunchKernelGGL(score_prepare_kernel, dim3(grid_for(n, 256, 64), (unsigned)batch), dim3(256), 0, st,
                        (const Corr*)corr, n, ws);
     int rc = check_launch("score_prepare_kernel");
     if (rc != SFM_OK) return rc;
+    // longest-first processing order (cost pre-pass + counting sort); SFM_SCORE_ORDER=0 keeps index order
+    // It pays only when the launch has few generations of waves (a long wave starting late then idles the chip at
+    // the end): 256 CUs x 20 resident waves = 5120 per generation; beyond ~12 generations the tail is negligible
+    // and the pre-pass would cost more than it saves.
+    static const int order_env = getenv("SFM_SCORE_ORDER") ? atoi(getenv("SFM_SCORE_ORDER")) : -1;
+    const bool use_order = order_env >= 0 ? order_env != 0 : (waves * batch <= 12 * 5120 && n >= 4096);
+    const int32_t* order_arg = nullptr;
+    if (use_order) {
+        // `cnt` doubles as the estimate buffer: it is rewritten by the scoring kernel afterwards
+        hipLaunchKernelGGL(score_estimate_kernel<kHypPerWave>, grid, dim3(256), 0, st, ws, (int)n, E, (int)h_count, thr,
+                           cnt);
+        const dim3 per_hyp(grid_for(h_count, 256), (unsigned)batch);
+        hipLaunchKernelGGL(score_class_count_kernel, per_hyp, dim3(256), 0, st, cnt, (int)h_count, buckets);
+        hipLaunchKernelGGL(score_class_scan_kernel, dim3(grid_for(batch, 64)), dim3(64), 0, st, buckets, batch);
+        hipLaunchKernelGGL(score_class_scatter_kernel, per_hyp, dim3(256), 0, st, cnt, (int)h_count, buckets, order);
+        rc = check_launch("score order kernels");
+        if (rc != SFM_OK) return rc;
+        order_arg = order;
+    }
     static const int ablate = getenv("SFM_SCORE_ABLATE") ? atoi(getenv("SFM_SCORE_ABLATE")) : 0;  // diagnostics only
     static const int hpw = getenv("SFM_SCORE_HPW") ? atoi(getenv("SFM_SCORE_HPW")) : kHypPerWave;  // diagnostics only
 #define SFM_LAUNCH_FILTERED(H, M)                                                                              \
     hipLaunchKernelGGL((score_sed_filtered_kernel<H, M>),                                                      \
                        dim3(grid_for((h_count + H - 1) / H, 256 / kWave), (unsigned)batch), dim3(256), 0, st,  \
-                       (const Corr*)corr, ws, (int)n, E, S, (int)h_count, thr, cnt, s1, s2)
+                       (const Corr*)corr, ws, (int)n, E, S, (int)h_count, thr, order_arg, cnt, s1, s2)
     if (ablate == 1) SFM_LAUNCH_FILTERED(kHypPerWave, 1);
     else if (ablate == 2) SFM_LAUNCH_FILTERED(kHypPerWave, 2);
     else if (ablate == 3) SFM_LAUNCH_FILTERED(kHypPerWave, 3);

@@ -148,10 +148,10 @@ def hartley_normalize(coords: np.ndarray):
     return raw[:2 * n].reshape(n, 2).copy(), T
 
 
-def score_workspace(n: int, batch: int, device) -> torch.Tensor:
+def score_workspace(n: int, h_count: int, batch: int, device) -> torch.Tensor:
     """Scratch buffer that enables the two-tier scoring kernel (see include/sfm_hip.h)."""
     lib = _native.load()
-    return torch.empty((int(lib.sfm_score_workspace_bytes(n, batch)),), dtype=torch.uint8, device=device)
+    return torch.empty((int(lib.sfm_score_workspace_bytes(n, h_count, batch)),), dtype=torch.uint8, device=device)
 
 
 def score_sed(corr: torch.Tensor, E: torch.Tensor, S: torch.Tensor, thr: float, cnt=None, s1=None,
@@ -170,7 +170,7 @@ def score_sed(corr: torch.Tensor, E: torch.Tensor, S: torch.Tensor, thr: float, 
     if exact_only or os.environ.get("SFM_SCORE_KERNEL", "filtered") == "exact":
         workspace = None
     elif workspace is None:
-        workspace = score_workspace(N, B, corr.device)
+        workspace = score_workspace(N, H, B, corr.device)
     check(lib.sfm_score_sed(_ptr(corr), N, _ptr(E), _ptr(S), H, B, float(thr), _ptr(cnt), _ptr(s1),
                             _ptr(s2), _ptr(workspace), workspace.numel() if workspace is not None else 0,
                             _stream()), "sfm_score_sed")
@@ -299,7 +299,7 @@ class RansacWorkspace:
         self.s2 = torch.empty((batch, h), dtype=F64, device=dev)
         self.result = torch.empty((batch, SELECT_BYTES // 8), dtype=torch.int64, device=dev)
         self.mask = torch.empty((batch, n), dtype=torch.uint8, device=dev)
-        self.score_ws = score_workspace(n, batch, dev)
+        self.score_ws = score_workspace(n, h, batch, dev)
 
     def run(self, corr: torch.Tensor, thr: float, min_extra: float, aggregation: int,
             h_offset: int = 0, with_mask: bool = True) -> None:

@@ -35,7 +35,7 @@ def test_argument_validation_without_gpu(native_lib):
     assert b"n" in native_lib.sfm_last_error()
     assert native_lib.sfm_fit_eight_point(None, 5, None, 4, 1, None, None, None, None) == -1
     assert native_lib.sfm_score_sed(None, -1, None, None, 4, 1, 0.0, None, None, None, None, 0, None) == -1
-    assert native_lib.sfm_score_workspace_bytes(1000, 2) == 2 * 16 + 2 * 1000 * 16
+    assert native_lib.sfm_score_workspace_bytes(1000, 50, 2) >= 2 * 16 + 2 * 1000 * 16 + 2 * 50 * 4
     assert native_lib.sfm_cheirality_batched(None, 0, 3, None, None, 50.0, None, None) == 0
     assert native_lib.sfm_pose_vote(None, 5, 2, None, None, None, None) == -1
     assert native_lib.sfm_select_best(None, None, None, None, 4, 1, 0.0, 9, 0, None, None) == -1

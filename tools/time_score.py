@@ -8,7 +8,7 @@ pa, pb, K, *_ = synthetic.two_view_scene(n, seed=6)
 corr = dev.normalize_correspondences(dev.to_device(pa), dev.to_device(pb), K).reshape(1, n, 4)
 S = dev.sample_philox(5, 0, h, n)
 E, flags = dev.fit_eight_point(corr, S)
-ws = dev.score_workspace(n, 1, corr.device)
+ws = dev.score_workspace(n, h, 1, corr.device)
 out = [torch.empty((1, h), dtype=torch.int32, device="cuda"), torch.empty((1, h), dtype=torch.float64, device="cuda"), torch.empty((1, h), dtype=torch.float64, device="cuda")]
 for name, kw in [("exact", dict(exact_only=True)), ("filtered", dict(workspace=ws))]:
     for _ in range(2):
