@@ -574,7 +574,7 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
     const int64_t waves = (h_count + kHypPerWave - 1) / kHypPerWave;
     const dim3 grid(grid_for(waves, 256 / kWave), (unsigned)batch);
     if (workspace == nullptr) {
-        static const int exact_dynlds = getenv("SFM_SCORE_DYNLDS") ? atoi(getenv("SFM_SCORE_DYNLDS")) : 0;  // diagnostics only
+        const int exact_dynlds = getenv("SFM_SCORE_DYNLDS") ? atoi(getenv("SFM_SCORE_DYNLDS")) : 0;  // diagnostics only
         hipLaunchKernelGGL(score_sed_exact_kernel<kHypPerWave>, grid, dim3(256), exact_dynlds, st, (const Corr*)corr, (int)n,
                            E, S, (int)h_count, thr, cnt, s1, s2);
         return check_launch("score_sed_exact_kernel");
@@ -599,7 +599,7 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
     // It pays only when the launch has few generations of waves (a long wave starting late then idles the chip at
     // the end): 256 CUs x 20 resident waves = 5120 per generation; beyond ~12 generations the tail is negligible
     // and the pre-pass would cost more than it saves.
-    static const int order_env = getenv("SFM_SCORE_ORDER") ? atoi(getenv("SFM_SCORE_ORDER")) : -1;
+    const int order_env = getenv("SFM_SCORE_ORDER") ? atoi(getenv("SFM_SCORE_ORDER")) : -1;
     const bool use_order = order_env >= 0 ? order_env != 0 : (waves * batch <= 12 * 5120 && n >= 4096);
     const int32_t* order_arg = nullptr;
     if (use_order) {
@@ -614,8 +614,8 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
         if (rc != SFM_OK) return rc;
         order_arg = order;
     }
-    static const int ablate = getenv("SFM_SCORE_ABLATE") ? atoi(getenv("SFM_SCORE_ABLATE")) : 0;  // diagnostics only
-    static const int hpw = getenv("SFM_SCORE_HPW") ? atoi(getenv("SFM_SCORE_HPW")) : kHypPerWave;  // diagnostics only
+    const int ablate = getenv("SFM_SCORE_ABLATE") ? atoi(getenv("SFM_SCORE_ABLATE")) : 0;  // diagnostics only
+    const int hpw = getenv("SFM_SCORE_HPW") ? atoi(getenv("SFM_SCORE_HPW")) : kHypPerWave;  // diagnostics only
 #define SFM_LAUNCH_FILTERED(H, M)                                                                              \
     hipLaunchKernelGGL((score_sed_filtered_kernel<H, M>),                                                      \
                        dim3(grid_for((h_count + H - 1) / H, 256 / kWave), (unsigned)batch), dim3(256), 0, st,  \

@@ -617,3 +617,30 @@ def test_filtered_score_randomized_sweep(dev):
         _assert_same_scores(exact, filt)
         total_checked += n * h
     assert total_checked > 5e6
+
+
+@pytest.mark.parametrize("order", ["1", "0"])
+def test_score_hypothesis_ordering_does_not_change_results(dev, monkeypatch, order):
+    """The longest-first processing order (forced on / off) only affects speed: identical outputs on odd sizes,
+    tiny hypothesis counts and batches."""
+    monkeypatch.setenv("SFM_SCORE_ORDER", order)
+    rng = np.random.default_rng(3)
+    for n, h in [(64, 1), (100, 3), (999, 5), (2000, 4), (4099, 130), (300, 257)]:
+        _, _, _, corr = scene(n)
+        S = orc.philox_sample_table(31, 0, h, n)
+        E, _, _ = orc.fit_hypotheses(corr, S)
+        exact, filt = _score_both(dev, corr, E, S, 1.5e-6)
+        _assert_same_scores(exact, filt)
+        cnt_o, _, s2_o = orc.score_hypotheses(corr, E, S, 1.5e-6)
+        np.testing.assert_array_equal(filt[0], cnt_o)
+    # batched: every pair gets its own order
+    B, n, h = 3, 1500, 37
+    corr_all = np.stack([scene(n, seed=60 + b)[3] for b in range(B)])
+    S_all = np.stack([orc.philox_sample_table(70 + b, 0, h, n) for b in range(B)])
+    E_all = np.stack([orc.fit_hypotheses(corr_all[b], S_all[b])[0] for b in range(B)])
+    cnt, s1, s2 = dev.score_sed(dev.to_device(corr_all), dev.to_device(E_all.reshape(B, h, 9)),
+                                dev.to_device(S_all, torch.int32), 1.5e-6)
+    for b in range(B):
+        cnt_o, s1_o, s2_o = orc.score_hypotheses(corr_all[b], E_all[b], S_all[b], 1.5e-6)
+        np.testing.assert_array_equal(cnt.cpu().numpy()[b], cnt_o)
+        np.testing.assert_allclose(s2.cpu().numpy()[b], s2_o, rtol=1e-13)
