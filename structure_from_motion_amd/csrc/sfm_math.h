@@ -311,34 +311,96 @@ SFM_DEVICE void qr_null_vector(double (&col)[8][9], double (&rdiag)[8], double (
 
 // --------------------------------------------------------------------------------------------------
 // Right singular vector of the smallest singular value of a 4x4 matrix given by rows.
-// Replaces `np.linalg.svd(A)[2][-1]` of reference triangulation.py:34-35 (sign is irrelevant: the
+// Replaces `np.linalg.svd(A)[2][-1]` of reference triangulation.py:34-35 (sign and scale are irrelevant: the
 // caller divides by the last component).
 // --------------------------------------------------------------------------------------------------
+// Rotation parameters for one-sided Jacobi from the Gram entries alpha = |g_i|^2, beta = |g_j|^2,
+// gamma = g_i . g_j, with one square root, one division and one reciprocal square root:
+//   t = 2 gamma sign(beta - alpha) / (|beta - alpha| + sqrt((beta - alpha)^2 + 4 gamma^2)),  c = rsqrt(1 + t^2), s = t c.
+// (Same t as jacobi_cs; c^2 + s^2 = 1 to a couple of ulps, which only rescales the rotated pair uniformly.)
+SFM_DEVICE void jacobi_cs_gram(double alpha, double beta, double gamma, bool rot, double& c, double& s) {
+    const double diff = beta - alpha;
+    const double den = fabs(diff) + sqrt(diff * diff + 4.0 * (gamma * gamma));
+    double t = (2.0 * gamma) / den;
+    t = (diff < 0.0) ? -t : t;
+    t = (rot && t == t) ? t : 0.0;  // no rotation (or 0/0): identity
+    c = rsqrt(1.0 + t * t);
+    s = t * c;
+}
+
+template <int I, int J>
+SFM_DEVICE bool rotate_rows4(double (&g)[4][4]) {
+    double alpha = 0.0, beta = 0.0, gamma = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        alpha += g[I][k] * g[I][k];
+        beta += g[J][k] * g[J][k];
+        gamma += g[I][k] * g[J][k];
+    }
+    const bool rot = fabs(gamma) > 1e-15 * sqrt(alpha * beta);
+    double c, s;
+    jacobi_cs_gram(alpha, beta, gamma, rot, c, s);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double gi = g[I][k], gj = g[J][k];
+        g[I][k] = c * gi - s * gj;
+        g[J][k] = s * gi + c * gj;
+    }
+    return rot;
+}
+
 SFM_DEVICE void null_vector4(const double rows[4][4], double x[4]) {
-    double g[4][4], v[4][4];
+    // One-sided Jacobi on the ROWS of A.  Orthogonalising rows is a left multiplication by an orthogonal matrix
+    // (A = U S V^T  =>  U^T A = S V^T), so at convergence the rows are sigma_k v_k^T: nothing has to be
+    // accumulated.  The wanted vector v_4 is then formed as the 4-D cross product of the three dominant rows,
+    // which stays exact when sigma_4 is 0 and the fourth row itself has vanished.
+    double g[4][4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) g[c][r] = rows[r][c];
-    hestenes_svd<4>(g, v);
-    double best = 0.0;
+        for (int c = 0; c < 4; ++c) g[r][c] = rows[r][c];
+#pragma unroll 1
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        bool rotated = rotate_rows4<0, 1>(g);
+        rotated |= rotate_rows4<0, 2>(g);
+        rotated |= rotate_rows4<0, 3>(g);
+        rotated |= rotate_rows4<1, 2>(g);
+        rotated |= rotate_rows4<1, 3>(g);
+        rotated |= rotate_rows4<2, 3>(g);
+        if (!__any(rotated)) break;
+    }
     double n2[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        n2[c] = 0.0;
+    for (int r = 0; r < 4; ++r) {
+        double acc = 0.0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) n2[c] += g[c][r] * g[c][r];
+        for (int c = 0; c < 4; ++c) acc += g[r][c] * g[r][c];
+        n2[r] = acc;
     }
-    best = n2[0];
+    int m = 0;
+    double best = n2[0];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) x[k] = v[0][k];
-#pragma unroll
-    for (int c = 1; c < 4; ++c) {
-        const bool smaller = n2[c] < best;
-        best = smaller ? n2[c] : best;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) x[k] = smaller ? v[c][k] : x[k];
+    for (int r = 1; r < 4; ++r) {
+        const bool smaller = n2[r] < best;
+        best = smaller ? n2[r] : best;
+        m = smaller ? r : m;
     }
+    // the other three rows (a, b, c), selected without dynamic indexing
+    double a[4], b[4], c[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        a[k] = (m == 0) ? g[1][k] : g[0][k];
+        b[k] = (m <= 1) ? g[2][k] : g[1][k];
+        c[k] = (m <= 2) ? g[3][k] : g[2][k];
+    }
+    // 4-D cross product: x_i = (-1)^i det of the 3x3 minor without column i
+    auto det3 = [](double a0, double a1, double a2, double b0, double b1, double b2, double c0, double c1, double c2) {
+        return a0 * (b1 * c2 - b2 * c1) - a1 * (b0 * c2 - b2 * c0) + a2 * (b0 * c1 - b1 * c0);
+    };
+    x[0] = det3(a[1], a[2], a[3], b[1], b[2], b[3], c[1], c[2], c[3]);
+    x[1] = -det3(a[0], a[2], a[3], b[0], b[2], b[3], c[0], c[2], c[3]);
+    x[2] = det3(a[0], a[1], a[3], b[0], b[1], b[3], c[0], c[1], c[3]);
+    x[3] = -det3(a[0], a[1], a[2], b[0], b[1], b[2], c[0], c[1], c[2]);
 }
 
 // DLT triangulation of one pair (reference triangulation.py:9-39).  P1, P2: rows 0..2 of the camera
