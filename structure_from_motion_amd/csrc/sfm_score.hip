@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void score_class_scatter_kernel(const int32_t*
 // ------------------------------------------------------------------------------------------------
 // Filtered kernel.
 // ------------------------------------------------------------------------------------------------
-template <int HPW, int MODE = 0>
+template <int HPW>
 __global__ __launch_bounds__(256) void score_sed_filtered_kernel(
     const Corr* __restrict__ corr, const unsigned char* __restrict__ ws, int n,
     const double* __restrict__ E, const int32_t* __restrict__ S, int h_count, double thr,
@@ -446,24 +446,10 @@ __global__ __launch_bounds__(256) void score_sed_filtered_kernel(
         double e[9];
 #pragma unroll
         for (int j = 0; j < 9; ++j) e[j] = Eb[(int64_t)h * 9 + j];
-        if (MODE == 1 || MODE == 2) {  // diagnostic ablations (SFM_SCORE_ABLATE): skip tier 2
-            head[k] += count;
-            return;
-        }
         const bool active = lane < count;
         const int slot = (head[k] + lane) & (kRing - 1);
         const int idx = active ? ring[wave_in_block][k][slot] : 0;
-        Corr p;
-        if (MODE == 4) {  // diagnostic: no gather
-            p.xa = (double)idx; p.ya = 0.25; p.xb = 0.5; p.yb = 0.125;
-        } else {
-            p = pts[idx];
-        }
-        if (MODE == 3) {  // diagnostic: gather but no fp64 SED
-            a1[k] += p.xa + p.yb;
-            head[k] += count;
-            return;
-        }
+        const Corr p = pts[idx];
         const double sed = sfm::sed_value(e, p.xa, p.ya, p.xb, p.yb);
         const bool ok = active && (sed <= thr);
         c[k] += ok ? 1 : 0;
@@ -489,10 +475,6 @@ __global__ __launch_bounds__(256) void score_sed_filtered_kernel(
             const bool rej1 = filter_rejects(f[k], T, p1.x, p1.y, p1.z, p1.w);
             const unsigned long long m0 = ~__builtin_amdgcn_ballot_w64(rej0);
             const unsigned long long m1 = ~__builtin_amdgcn_ballot_w64(rej1);
-            if (MODE == 1) {  // diagnostic: filter only
-                c[k] += (rej0 ? 0 : 1) + (rej1 ? 0 : 1);
-                continue;
-            }
             if ((m0 | m1) != 0ull) {  // wave-uniform
                 push(k, m0, !rej0, i0);
                 push(k, m1, !rej1, i0 + kWave);
@@ -574,8 +556,7 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
     const int64_t waves = (h_count + kHypPerWave - 1) / kHypPerWave;
     const dim3 grid(grid_for(waves, 256 / kWave), (unsigned)batch);
     if (workspace == nullptr) {
-        const int exact_dynlds = getenv("SFM_SCORE_DYNLDS") ? atoi(getenv("SFM_SCORE_DYNLDS")) : 0;  // diagnostics only
-        hipLaunchKernelGGL(score_sed_exact_kernel<kHypPerWave>, grid, dim3(256), exact_dynlds, st, (const Corr*)corr, (int)n,
+        hipLaunchKernelGGL(score_sed_exact_kernel<kHypPerWave>, grid, dim3(256), 0, st, (const Corr*)corr, (int)n,
                            E, S, (int)h_count, thr, cnt, s1, s2);
         return check_launch("score_sed_exact_kernel");
     }
@@ -614,20 +595,8 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
         if (rc != SFM_OK) return rc;
         order_arg = order;
     }
-    const int ablate = getenv("SFM_SCORE_ABLATE") ? atoi(getenv("SFM_SCORE_ABLATE")) : 0;  // diagnostics only
-    const int hpw = getenv("SFM_SCORE_HPW") ? atoi(getenv("SFM_SCORE_HPW")) : kHypPerWave;  // diagnostics only
-#define SFM_LAUNCH_FILTERED(H, M)                                                                              \
-    hipLaunchKernelGGL((score_sed_filtered_kernel<H, M>),                                                      \
-                       dim3(grid_for((h_count + H - 1) / H, 256 / kWave), (unsigned)batch), dim3(256), 0, st,  \
-                       (const Corr*)corr, ws, (int)n, E, S, (int)h_count, thr, order_arg, cnt, s1, s2)
-    if (ablate == 1) SFM_LAUNCH_FILTERED(kHypPerWave, 1);
-    else if (ablate == 2) SFM_LAUNCH_FILTERED(kHypPerWave, 2);
-    else if (ablate == 3) SFM_LAUNCH_FILTERED(kHypPerWave, 3);
-    else if (ablate == 4) SFM_LAUNCH_FILTERED(kHypPerWave, 4);
-    else if (hpw == 2) SFM_LAUNCH_FILTERED(2, 0);
-    else if (hpw == 3) SFM_LAUNCH_FILTERED(3, 0);
-    else SFM_LAUNCH_FILTERED(4, 0);
-#undef SFM_LAUNCH_FILTERED
+    hipLaunchKernelGGL(score_sed_filtered_kernel<kHypPerWave>, grid, dim3(256), 0, st, (const Corr*)corr, ws, (int)n, E,
+                       S, (int)h_count, thr, order_arg, cnt, s1, s2);
     return check_launch("score_sed_filtered_kernel");
 }
 
