@@ -62,6 +62,11 @@ int sfm_normalize_correspondences(const double* pix_a, const double* pix_b, int6
 int sfm_sample_philox(uint64_t seed, uint64_t seed_stride, int64_t h_begin, int64_t h_count, int64_t n,
                       int64_t batch, int32_t* S, void* stream);
 
+/* Same sampler with the 64-bit seed read from device memory (seed_dev[0]) at kernel run time: a captured
+ * hipGraph of sample -> fit -> score -> select can be replayed with a new seed by rewriting that word. */
+int sfm_sample_philox_dev(const uint64_t* seed_dev, uint64_t seed_stride, int64_t h_begin, int64_t h_count,
+                          int64_t n, int64_t batch, int32_t* S, void* stream);
+
 /* Same sampler for ONE hypothesis per batch entry whose index is read from device memory:
  * S[b,:] = sample of hypothesis h_index[b] (0..7 if h_index[b] < 0).  Lets the multi-GPU winner be
  * re-derived on every rank without a host round trip.  h_index: dev int64 [batch]; S: dev int32 [batch,8]. */

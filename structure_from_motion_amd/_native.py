@@ -40,6 +40,7 @@ _D = C.c_double
 SIGNATURES = {
     "sfm_normalize_correspondences": [_P, _P, _I64, _D, _D, _D, _D, _P, _P],
     "sfm_sample_philox": [_U64, _U64, _I64, _I64, _I64, _I64, _P, _P],
+    "sfm_sample_philox_dev": [_P, _U64, _I64, _I64, _I64, _I64, _P, _P],
     "sfm_sample_philox_at": [_U64, _U64, _P, _I64, _I64, _P, _P],
     "sfm_fit_eight_point": [_P, _I64, _P, _I64, _I64, _P, _P, _P, _P],
     "sfm_fit_eight_point_traced": [_P, _I64, _P, _I64, _I64, _P, _P, _P, _P],

@@ -67,6 +67,21 @@ __global__ void sample_philox_kernel(uint64_t seed, uint64_t seed_stride, int64_
     dst[1] = make_int4(idx[4], idx[5], idx[6], idx[7]);
 }
 
+// The same sampler with the seed read from device memory, so a captured hipGraph of a whole RANSAC pass
+// can be replayed with a new seed (kernel arguments are frozen at capture; device memory is not).
+__global__ void sample_philox_dev_kernel(const uint64_t* __restrict__ seed_dev, uint64_t seed_stride,
+                                         int64_t h_begin, int64_t h_count, uint32_t n,
+                                         int32_t* __restrict__ S) {
+    const int64_t h = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= h_count) return;
+    const int64_t b = blockIdx.y;
+    int32_t idx[8];
+    sfm::philox_sample8(seed_dev[0] + (uint64_t)b * seed_stride, (uint64_t)(h_begin + h), n, idx);
+    int4* dst = reinterpret_cast<int4*>(S + (b * h_count + h) * 8);
+    dst[0] = make_int4(idx[0], idx[1], idx[2], idx[3]);
+    dst[1] = make_int4(idx[4], idx[5], idx[6], idx[7]);
+}
+
 // Re-derive the sample of one given hypothesis per batch entry (index read from device memory, so the
 // multi-GPU winner can be finalised without a host round trip).  Negative index -> 0..7.
 __global__ void sample_philox_at_kernel(uint64_t seed, uint64_t seed_stride,
@@ -775,6 +790,17 @@ int sfm_sample_philox(uint64_t seed, uint64_t seed_stride, int64_t h_begin, int6
     hipLaunchKernelGGL(sample_philox_kernel, dim3(grid_for(h_count, 256), (unsigned)batch), dim3(256), 0,
                        (hipStream_t)stream, seed, seed_stride, h_begin, h_count, (uint32_t)n, S);
     return check_launch("sample_philox_kernel");
+}
+
+int sfm_sample_philox_dev(const uint64_t* seed_dev, uint64_t seed_stride, int64_t h_begin, int64_t h_count,
+                          int64_t n, int64_t batch, int32_t* S, void* stream) {
+    if (h_count < 0 || batch < 0 || h_begin < 0) return fail(SFM_EINVAL, "sfm_sample_philox_dev: negative size");
+    if (n < 8 || n > 0x7FFFFFFF) return fail(SFM_EINVAL, "sfm_sample_philox_dev: need 8 <= n < 2^31");
+    if (h_count == 0 || batch == 0) return SFM_OK;
+    if (!S || !seed_dev) return fail(SFM_EINVAL, "sfm_sample_philox_dev: null pointer");
+    hipLaunchKernelGGL(sample_philox_dev_kernel, dim3(grid_for(h_count, 256), (unsigned)batch), dim3(256), 0,
+                       (hipStream_t)stream, seed_dev, seed_stride, h_begin, h_count, (uint32_t)n, S);
+    return check_launch("sample_philox_dev_kernel");
 }
 
 int sfm_sample_philox_at(uint64_t seed, uint64_t seed_stride, const int64_t* h_index, int64_t n,

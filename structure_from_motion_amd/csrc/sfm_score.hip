@@ -153,6 +153,16 @@ __host__ __device__ inline int64_t workspace_bytes_for(int64_t n, int64_t h_coun
     return ws_order_offset(n, batch) + 4 * h_count * batch;
 }
 
+// Zero the per-batch maxima and class counters.  A kernel rather than hipMemsetAsync: one launch instead of
+// two, and a captured hipGraph of the pass then holds kernel nodes only (with hipMemsetAsync nodes in it, replaying
+// the graph while a second captured graph was alive faulted on ROCm 7.2 — profiles/r01/README.md).
+__global__ __launch_bounds__(256) void score_reset_kernel(unsigned char* __restrict__ ws, int32_t* __restrict__ buckets) {
+    const int64_t b = blockIdx.x;
+    static_assert(kBuckets == 256, "one thread per counter word");
+    buckets[b * kBuckets + threadIdx.x] = 0;
+    if (threadIdx.x < 4) reinterpret_cast<uint32_t*>(ws + 16 * b)[threadIdx.x] = 0u;
+}
+
 __global__ void score_prepare_kernel(const Corr* __restrict__ corr, int64_t n, unsigned char* __restrict__ ws) {
     const int64_t b = blockIdx.y;
     const int64_t batch = gridDim.y;
@@ -567,11 +577,7 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
     unsigned char* ws = static_cast<unsigned char*>(workspace);
     int32_t* buckets = reinterpret_cast<int32_t*>(ws + ws_buckets_offset(n, batch));
     int32_t* order = reinterpret_cast<int32_t*>(ws + ws_order_offset(n, batch));
-    {
-        hipError_t err = hipMemsetAsync(ws, 0, 16 * batch, st);
-        if (err == hipSuccess) err = hipMemsetAsync(buckets, 0, 4 * (size_t)kBuckets * batch, st);
-        if (err != hipSuccess) return fail(SFM_EHIP, hipGetErrorString(err));
-    }
+    hipLaunchKernelGGL(score_reset_kernel, dim3((unsigned)batch), dim3(256), 0, st, ws, buckets);
     hipLaunchKernelGGL(score_prepare_kernel, dim3(grid_for(n, 256, 64), (unsigned)batch), dim3(256), 0, st,
                        (const Corr*)corr, n, ws);
     int rc = check_launch("score_prepare_kernel");

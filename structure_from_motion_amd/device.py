@@ -75,6 +75,17 @@ def sample_philox(seed: int, h_begin: int, h_count: int, n: int, batch: int = 1,
     return out
 
 
+def sample_philox_dev(seed_dev: torch.Tensor, h_begin: int, h_count: int, n: int, batch: int = 1,
+                      seed_stride: int = 1, out=None) -> torch.Tensor:
+    """Philox sampler whose seed is the int64 word ``seed_dev[0]`` in device memory (graph-replayable)."""
+    lib = _native.load()
+    if out is None:
+        out = torch.empty((batch, h_count, 8), dtype=torch.int32, device=seed_dev.device)
+    check(lib.sfm_sample_philox_dev(_ptr(seed_dev), seed_stride, h_begin, h_count, n, batch, _ptr(out),
+                                    _stream()), "sfm_sample_philox_dev")
+    return out
+
+
 def sample_philox_at(seed: int, h_index: torch.Tensor, n: int, seed_stride: int = 1, out=None) -> torch.Tensor:
     """h_index: int64 [B] on device -> S [B,1,8]: the sample of hypothesis h_index[b] (no host sync)."""
     lib = _native.load()

@@ -96,20 +96,56 @@ class ShardedRansac:
         self.win_E = torch.empty((1, 1, 9), dtype=torch.float64, device=dev)
         self.win_flags = torch.empty((1, 1), dtype=torch.int32, device=dev)
         self.win_record = torch.zeros((1, 5), dtype=torch.int64, device=dev)
-        self.global_key = torch.empty((1,), dtype=torch.int64, device=dev)
-        self.global_best = torch.empty((1,), dtype=torch.int64, device=dev)
+        if world == 1:  # the local record is the global one: views, no copies
+            self.global_key, self.global_best = self.ws.result[:, 0], self.ws.result[:, 1]
+        else:
+            self.global_key = torch.empty((1,), dtype=torch.int64, device=dev)
+            self.global_best = torch.empty((1,), dtype=torch.int64, device=dev)
 
-    def step(self, seed: int) -> None:
+        self.graph = None
+        self.seed_dev = None
+
+    def _local_pass(self, seed) -> None:
+        """sample -> fit -> score -> select on this rank's shard (+ mask when the winner is local).
+        ``seed=None`` reads the seed from ``self.seed_dev`` (the form a HIP graph can replay)."""
         d = self.device_api
         begin = self.rank * self.h
-        d.sample_philox(seed, begin, self.h, self.n, out=self.ws.S)
+        if seed is None:
+            d.sample_philox_dev(self.seed_dev, begin, self.h, self.n, out=self.ws.S)
+        else:
+            d.sample_philox(seed, begin, self.h, self.n, out=self.ws.S)
         if self.world == 1:
             # single GPU: the winner is local — mask straight from the shard's own E / S
             self.ws.run(self.corr, self.thr, self.min_extra, self.aggregation, h_offset=0, with_mask=True)
-            self.global_key.copy_(self.ws.result[:, 0])
-            self.global_best.copy_(self.ws.result[:, 1])
+        else:
+            self.ws.run(self.corr, self.thr, self.min_extra, self.aggregation, h_offset=begin, with_mask=False)
+
+    def capture(self) -> None:
+        """Record the local pass once into a HIP graph; later ``step`` calls rewrite one seed word in device
+        memory and replay it (one graph launch instead of ~a dozen kernel launches — what bounds small
+        problems such as the demo's N~300 x H=2000).  Only single-GPU passes are captured whole; with
+        world > 1 the graph covers the local pass and the exchange stays eager."""
+        self.seed_dev = torch.zeros(1, dtype=torch.int64, device=self.corr.device)
+        side = torch.cuda.Stream(device=self.corr.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self._local_pass(None)  # warm-up outside capture (lazy module loads, workspace sizing)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._local_pass(None)
+        self.graph = graph
+
+    def step(self, seed: int) -> None:
+        d = self.device_api
+        if self.graph is not None:
+            s = seed & (2**64 - 1)
+            self.seed_dev.fill_(s - 2**64 if s >= 2**63 else s)
+            self.graph.replay()
+        else:
+            self._local_pass(seed)
+        if self.world == 1:
             return
-        self.ws.run(self.corr, self.thr, self.min_extra, self.aggregation, h_offset=begin, with_mask=False)
         key, best = self.ws.result[:, 0].contiguous(), self.ws.result[:, 1].contiguous()
         gkey, gbest = reduce_best(key, best, self.group)
         self.global_key.copy_(gkey)

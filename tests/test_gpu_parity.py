@@ -425,6 +425,34 @@ def test_virtual_shards_equal_single_run(dev):
     np.testing.assert_array_equal(np.nonzero(want[4])[0], np.sort(ref["inliers"]))
 
 
+@pytest.mark.parametrize("n,h", [(300, 2000), (6000, 12000)])
+def test_graph_replay_equals_eager(dev, n, h):
+    """A captured HIP graph of the whole pass, replayed with the seed rewritten in device memory, gives the
+    same winner / E / sample / mask as the eager launch sequence — and as the oracle (both launch paths of
+    the scoring kernel: plain order at 300 x 2000, longest-first ordering at 6000 x 12000)."""
+    from structure_from_motion_amd import distributed
+    from structure_from_motion_amd._native import AGG_RMS
+
+    _, _, _, corr = scene(n)
+    corr_d = dev.to_device(corr)
+    eager = distributed.ShardedRansac(corr_d, h, 1.5e-6, 10, AGG_RMS)
+    graphed = distributed.ShardedRansac(corr_d, h, 1.5e-6, 10, AGG_RMS)
+    graphed.capture()
+    for seed in (5, 6, 2**63 + 11, 7):
+        eager.step(seed)
+        graphed.step(seed)
+        want, got = eager.outcome(), graphed.outcome()
+        assert got[0] == want[0] and got[1] == want[1]
+        for a, b in zip(got[2:], want[2:]):
+            np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(dev.sample_philox_dev(graphed.seed_dev, 3, 50, n).cpu().numpy(),
+                                  dev.sample_philox(7, 3, 50, n).cpu().numpy())
+    if h <= 2000:
+        ref = orc.ransac_essential(corr, orc.philox_sample_table(7, 0, h, n), 1.5e-6, 10, orc.RMS)
+        assert ref["best"] == got[0]
+        np.testing.assert_array_equal(np.nonzero(got[4])[0], np.sort(ref["inliers"]))
+
+
 # ------------------------------------------------------------------------------------------------------
 # two-tier scoring kernel (fp32 pre-filter + exact fp64) against the all-fp64 kernel
 # ------------------------------------------------------------------------------------------------------
