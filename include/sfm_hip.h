@@ -144,6 +144,26 @@ int sfm_triangulate(const double* corr, int64_t m, const double* P1, const doubl
 int sfm_decompose_essential(const double* E, int64_t batch, double* pose_rt, int32_t* status,
                             void* stream);
 
+/* ---- local optimisation of the winner (an extension, the reference has no such step) ---- */
+
+typedef struct sfm_refine_info {
+    double error;     /* aggregated error of the model left in E_out (over its `count` inliers) */
+    int32_t count;    /* inliers of that model (for an unrefined model: non-zero entries of mask_in) */
+    int32_t accepted; /* refits that were accepted (0 = E_out is E_in) */
+} sfm_refine_info;
+
+/* Per image pair, up to `iterations` times: refit E on all current inliers with the N-point form of the reference's
+ * normalised eight-point pipeline (eight_point.py:308-446 and :163-166 applied to M >= 8 pairs), re-score all n
+ * correspondences (sed.py:7-30, sed <= thr), and keep the refit iff it has more inliers, or as many and a lower
+ * aggregated error (ransac.py:96-108 over the inliers); stop at the first refit that is not kept, is degenerate
+ * (eight_point.py:415-421) or has fewer than 8 inliers to work from.
+ * corr: dev [batch,n,4]; E_in: dev [batch,9]; mask_in: dev uint8 [batch,n] (non-zero = inlier, as written by
+ * sfm_inlier_mask); err_in: dev [batch] aggregated error of E_in (sfm_select_result.best_err);
+ * E_out: dev [batch,9]; mask_out: dev uint8 [batch,n] (1 = inlier; must not alias mask_in); info: dev [batch]. */
+int sfm_refine_inliers(const double* corr, int64_t n, int64_t batch, const double* E_in, const uint8_t* mask_in,
+                       const double* err_in, double thr, int aggregation, int iterations, double* E_out,
+                       uint8_t* mask_out, sfm_refine_info* info, void* stream);
+
 /* ---- batched, device-resident pose selection + triangulation (chains after sfm_inlier_mask) ---- */
 
 /* Cheirality of every correspondence of every pair under its 4 candidate poses.  corr: dev [batch,n,4]

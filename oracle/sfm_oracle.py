@@ -252,6 +252,51 @@ def ransac_essential(corr, S, thr, min_extra=0, method=RMS):
     return out
 
 
+def refit_on_points(corr: np.ndarray, indices: np.ndarray):
+    """The reference's eight-point pipeline (estimate_fundamental_mat, eight_point.py:154-166) applied to the
+    M >= 8 correspondences ``indices`` instead of exactly 8: _normalize_coords (:308-338), the outer-product
+    accumulation of _get_y_col columns (:363-393), _compute_f_est (:396-427) and
+    _enforce_fundamental_mat_constraints (:430-446) are written for any number of points; only the entry check
+    (:151-152) and an assert in _get_yT_y (:365) pin 8.  Pinned by tests/golden/g13_refit.npz (the same composition
+    of the real helpers).  Returns (E (3,3), degenerate flag)."""
+    pts = corr[np.asarray(indices, dtype=np.int64)]
+    e, deg, _ = fit_from_sample_coords(pts[None, :, 0:2], pts[None, :, 2:4])
+    return e[0], bool(deg[0])
+
+
+def local_optimisation(corr, E0, mask0, err0, thr, method=RMS, iterations=1):
+    """Local optimisation of a RANSAC winner — an EXTENSION; the reference has no such step,
+    so this function is the definition the device kernel is held to (the fit inside it is pinned to the reference's
+    helpers by tests/golden/g13_refit.npz).  Up to ``iterations`` times: refit on all current inliers, re-score
+    all points (sed <= thr), keep the refit iff it has more inliers, or as many and a lower aggregated error
+    (ransac.py:96-108 over exactly the inliers); stop at the first refit not kept, degenerate, or with < 8 inliers.
+    Returns (E, boolean mask, count, error, accepted refits)."""
+    best_E = np.asarray(E0, dtype=np.float64).reshape(3, 3)
+    best_mask = np.asarray(mask0) != 0
+    best_cnt, best_err, accepted = int(best_mask.sum()), float(err0), 0
+    for _ in range(iterations):
+        idx = np.nonzero(best_mask)[0]
+        if len(idx) < MODEL_POINTS:
+            break
+        E, degenerate = refit_on_points(corr, idx)
+        if degenerate:
+            break
+        sed = sed_values(E, corr)
+        with np.errstate(invalid="ignore"):
+            keep = sed <= thr
+        cnt = int(keep.sum())
+        kept = sed[keep]
+        s1 = np.add.accumulate(kept)[-1] if cnt else 0.0
+        s2 = np.add.accumulate(kept * kept)[-1] if cnt else 0.0
+        with np.errstate(invalid="ignore", divide="ignore"):
+            err = {SUM: s1, SQUARE: s2, MEAN: np.float64(s1) / cnt if cnt else np.nan,
+                   RMS: np.sqrt(np.float64(s2) / cnt) if cnt else np.nan}[method]
+        if not (cnt > best_cnt or (cnt == best_cnt and err < best_err)):
+            break
+        best_E, best_mask, best_cnt, best_err, accepted = E, keep, cnt, float(err), accepted + 1
+    return best_E, best_mask, best_cnt, best_err, accepted
+
+
 def aggregate_literal(errors: Sequence[float], method: str) -> float:
     """ransac.py:96-108 verbatim semantics on a compact error list (python sum / numpy pairwise)."""
     if method == SUM:

@@ -15,7 +15,7 @@ AGG_SUM, AGG_SQUARE, AGG_MEAN, AGG_RMS = 0, 1, 2, 3
 FIT_DEGENERATE = 1
 MATCH_NCC, MATCH_SSD = 0, 1
 INT64_MAX = (1 << 63) - 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class SelectResult(C.Structure):
@@ -40,6 +40,7 @@ _D = C.c_double
 SIGNATURES = {
     "sfm_normalize_correspondences": [_P, _P, _I64, _D, _D, _D, _D, _P, _P],
     "sfm_sample_philox": [_U64, _U64, _I64, _I64, _I64, _I64, _P, _P],
+    "sfm_refine_inliers": [_P, _I64, _I64, _P, _P, _P, _D, C.c_int, C.c_int, _P, _P, _P, _P],
     "sfm_sample_philox_dev": [_P, _U64, _I64, _I64, _I64, _I64, _P, _P],
     "sfm_sample_philox_at": [_U64, _U64, _P, _I64, _I64, _P, _P],
     "sfm_fit_eight_point": [_P, _I64, _P, _I64, _I64, _P, _P, _P, _P],

@@ -57,11 +57,16 @@ class TwoViewBatch:
         self.valid = torch.empty((batch, n), dtype=torch.uint8, device=dev)
         self._pix = None
         self._K = None
+        self._mask = self.ws.mask   # inlier mask the pose stage works from (refined one with local optimisation)
+        self._refined = False
 
     def run(self, pix_a: torch.Tensor, pix_b: torch.Tensor, K, seed: int, thr: float, min_extra: float,
-            aggregation: int, distance_threshold: float = 50.0, seed_stride: int = 1) -> None:
+            aggregation: int, distance_threshold: float = 50.0, seed_stride: int = 1,
+            local_optimisation: int = 0) -> None:
         """Enqueue the whole pipeline.  pix_a, pix_b: [B,N,2] f64 device tensors (pixel coordinates);
-        pair b samples with Philox seed ``seed + b*seed_stride``."""
+        pair b samples with Philox seed ``seed + b*seed_stride``.  ``local_optimisation=k`` (extension, off by
+        default) refits every winner on all its inliers up to k times before pose recovery; the inlier lists
+        then come back in index order (a refined model has no sample to put first)."""
         lib = _native.load()
         B, N = self.batch, self.n
         st = device._stream()
@@ -74,9 +79,18 @@ class TwoViewBatch:
         best = ws.result[:, 1].clamp(min=0)
         rows = torch.arange(B, device=best.device)
         self.E_best.copy_(ws.E[rows, best])
-        self.skip.copy_(ws.S[rows, best, 0])
+        self._refined = local_optimisation > 0
+        if self._refined:
+            err = ws.result.view(F64)[:, 2]
+            E_ref, self._mask, _ = device.refine_inliers(self.corr, self.E_best, ws.mask, err, thr, aggregation,
+                                                         local_optimisation)
+            self.E_best.copy_(E_ref)
+            self.skip.copy_(self._mask.argmax(dim=1))   # list position 0 = lowest inlier index (vote quirk Q9)
+        else:
+            self._mask = ws.mask
+            self.skip.copy_(ws.S[rows, best, 0])
         device.decompose_essential(self.E_best, out=(self.poses, self.decomp_status))
-        check(lib.sfm_cheirality_batched(self.corr.data_ptr(), N, B, self.poses.data_ptr(), ws.mask.data_ptr(),
+        check(lib.sfm_cheirality_batched(self.corr.data_ptr(), N, B, self.poses.data_ptr(), self._mask.data_ptr(),
                                          float(distance_threshold), self.passes.data_ptr(), st),
               "sfm_cheirality_batched")
         check(lib.sfm_pose_vote(self.passes.data_ptr(), N, B, self.skip.data_ptr(), self.votes.data_ptr(),
@@ -91,7 +105,7 @@ class TwoViewBatch:
         recs = device.read_select(self.ws.result)
         E = self.E_best.cpu().numpy().reshape(-1, 3, 3)
         S = self.ws.S.cpu().numpy()
-        mask = self.ws.mask.cpu().numpy()
+        mask = self._mask.cpu().numpy()
         poses = self.poses.cpu().numpy()
         dstat = self.decomp_status.cpu().numpy()
         votes = self.votes.cpu().numpy()
@@ -106,8 +120,11 @@ class TwoViewBatch:
             if rec.best_h < 0:
                 out.append(PairResult(NO_MODEL, None, -1, None, None, None, None, None, None))
                 continue
-            sample = S[b, rec.best_h].astype(np.int64)
-            order = np.concatenate([sample, np.nonzero(mask[b] == 1)[0]])
+            if self._refined:
+                order = np.nonzero(mask[b])[0]
+            else:
+                sample = S[b, rec.best_h].astype(np.int64)
+                order = np.concatenate([sample, np.nonzero(mask[b] == 1)[0]])
             if dstat[b] != 0:
                 out.append(PairResult(BAD_ESSENTIAL, E[b], int(rec.best_h), order, None, None, None, None, None))
                 continue

@@ -210,6 +210,28 @@ def inlier_mask(corr, E, S, result, thr: float, out=None):
     return out
 
 
+def refine_inliers(corr, E, mask, err, thr: float, aggregation: int, iterations: int = 1):
+    """Local optimisation: refit E on all inliers, re-score, keep if better.
+    corr [B,N,4], E [B,9], mask uint8 [B,N], err f64 [B] -> (E_out [B,9], mask_out uint8 [B,N],
+    info int64 view [B,2]: {error bits, count | accepted << 32}).  No host synchronisation."""
+    lib = _native.load()
+    B, N, _ = corr.shape
+    E_out = torch.empty((B, 9), dtype=F64, device=corr.device)
+    mask_out = torch.empty((B, N), dtype=torch.uint8, device=corr.device)
+    info = torch.empty((B, 2), dtype=torch.int64, device=corr.device)
+    check(lib.sfm_refine_inliers(_ptr(corr), N, B, _ptr(E.contiguous()), _ptr(mask.contiguous()),
+                                 _ptr(err.contiguous()), float(thr), int(aggregation), int(iterations),
+                                 _ptr(E_out), _ptr(mask_out), _ptr(info), _stream()), "sfm_refine_inliers")
+    return E_out, mask_out, info
+
+
+def read_refine_info(info: torch.Tensor):
+    """Host copy of sfm_refine_info records -> list of (error, count, accepted) (synchronises)."""
+    raw = info.cpu().numpy()
+    return [(float(raw[i, 0:1].view(np.float64)[0]), int(raw[i, 1] & 0xFFFFFFFF), int(raw[i, 1] >> 32))
+            for i in range(raw.shape[0])]
+
+
 def read_select(result: torch.Tensor) -> List[SelectResult]:
     """Copy the select records to the host (synchronises)."""
     raw = result.cpu().numpy().tobytes()

@@ -7,6 +7,7 @@ import random
 from typing import Sequence
 
 import numpy as np
+import torch
 
 from .. import device
 from ..common.feature import Feature
@@ -33,6 +34,15 @@ def degenerate_policy() -> str:
     if policy not in ("raise", "skip"):
         raise ValueError(f"SFM_DEGENERATE must be 'raise' or 'skip', got {policy!r}")
     return policy
+
+
+def local_optimisation_rounds() -> int:
+    """``SFM_LOCAL_OPTIMIZATION=<k>``: after RANSAC, refit on all inliers up to k times (0 = off, the reference's
+    behaviour: it returns the eight-point model of the winning sample as is)."""
+    rounds = int(os.environ.get("SFM_LOCAL_OPTIMIZATION", "0"))
+    if rounds < 0:
+        raise ValueError("SFM_LOCAL_OPTIMIZATION must be >= 0")
+    return rounds
 
 
 def ransac_feature_pairs(data, camera_matrix, threshold, min_extra, aggregation, iterations):
@@ -74,6 +84,16 @@ def ransac_feature_pairs(data, camera_matrix, threshold, min_extra, aggregation,
         )
     if outcome.best_h < 0:
         return None, []
+    rounds = local_optimisation_rounds()
+    if rounds:
+        # extension: the refined model has no "sample", so its inliers come back in
+        # index order; an unrefined winner (no refit accepted) falls through to the reference's ordering
+        err = ws.result.view(torch.float64)[:, 2]
+        E_ref, mask_ref, info = device.refine_inliers(corr.reshape(1, n, 4), ws.E[:, outcome.best_h], ws.mask, err,
+                                                      threshold, aggregation, rounds)
+        if device.read_refine_info(info)[0][2] > 0:
+            keep = np.nonzero(mask_ref.cpu().numpy()[0])[0]
+            return E_ref.cpu().numpy().reshape(3, 3), [copy.deepcopy(data[int(i)]) for i in keep]
     survivors = outcome.mask == 1
     if sampler == "pyshuffle":
         replay = random.Random()

@@ -560,17 +560,44 @@ def g12_harris():
     save("g12_harris", **out)
 
 
+def g13_refit():
+    """N-point refit for the local-optimisation extension.  The reference itself only fits
+    8 pairs (``estimate_fundamental_mat`` raises otherwise, eight_point.py:151-152, and ``_get_yT_y`` asserts 8,
+    :365), so the M-point fit is COMPOSED here from the reference's own helpers in the order
+    ``estimate_fundamental_mat`` uses them (:154-166): ``_normalize_coords`` per image, the ``np.outer`` accumulation
+    of ``_get_y_col`` columns (the loop of ``_get_yT_y`` without its length assert), ``_compute_f_est``,
+    ``_enforce_fundamental_mat_constraints``, ``T2.T @ e @ T1``, ``e /= e[2, 2]``."""
+    out = {}
+    for name, n, m, seed in (("a", 400, 40, 11), ("b", 3000, 1500, 12), ("c", 64, 8, 13)):
+        pa, pb, K, R, t, is_out = orc.synthetic_two_view(n, seed=seed)
+        idx = np.nonzero(~is_out)[0][:m]
+        na = np.array([[f.x, f.y] for f in (eight_point.to_normalized_image_coords(f, K) for f in feats(pa[idx]))])
+        nb = np.array([[f.x, f.y] for f in (eight_point.to_normalized_image_coords(f, K) for f in feats(pb[idx]))])
+        ca, T1 = eight_point._normalize_coords(na)
+        cb, T2 = eight_point._normalize_coords(nb)
+        yty = np.zeros((9, 9), dtype=np.float64)
+        for i in range(len(ca)):
+            col = eight_point._get_y_col(ca[i, :], cb[i, :])
+            yty += np.outer(col, col)
+        e = eight_point._enforce_fundamental_mat_constraints(eight_point._compute_f_est(yty))
+        e = T2.T @ e @ T1
+        e /= e[2, 2]
+        out[f"{name}_pix_a"], out[f"{name}_pix_b"], out[f"{name}_K"] = pa, pb, K
+        out[f"{name}_idx"], out[f"{name}_E"], out[f"{name}_yty"] = idx, e, yty
+        if m == 8:  # with exactly eight pairs the composition must BE the reference's public entry point
+            E8 = eight_point.estimate_essential_mat(camera_matrix=K, features_a=feats(pa[idx]),
+                                                    features_b=feats(pb[idx]),
+                                                    matches=eight_point.create_trivial_matches(8))
+            assert np.array_equal(E8, e), np.abs(E8 - e).max()
+    save("g13_refit", **out)
+
+
 if __name__ == "__main__":
-    g1_eight_point_pipeline()
-    g2_ransac_known_answer()
-    g3_per_hypothesis()
-    g4_sed_values()
-    g5_cheirality()
-    g6_triangulate()
-    g7_degenerate()
-    g8_unit_vectors()
-    g9_explicit_table()
-    g10_line_ransac()
-    g11_matching()
-    g12_harris()
+    everything = [g1_eight_point_pipeline, g2_ransac_known_answer, g3_per_hypothesis, g4_sed_values, g5_cheirality,
+                  g6_triangulate, g7_degenerate, g8_unit_vectors, g9_explicit_table, g10_line_ransac, g11_matching,
+                  g12_harris, g13_refit]
+    wanted = sys.argv[1:]  # e.g. ``make_golden.py g13`` regenerates one fixture
+    for fn in everything:
+        if not wanted or fn.__name__.split("_")[0] in wanted:
+            fn()
     print("numpy", np.__version__)

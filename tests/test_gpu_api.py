@@ -410,3 +410,31 @@ def test_headless_demo_end_to_end():
     assert summary["rotation_error_deg"] < 2.0
     assert summary["translation_direction_error_deg"] < 12.0
     assert summary["fraction_of_points_in_true_depth_range"] > 0.8
+
+
+def test_local_optimisation_env_option(monkeypatch):
+    """SFM_LOCAL_OPTIMIZATION=k (extension): default 0 keeps the reference's result; k > 0 returns the refined
+    model with at least as many inliers, identical to the oracle's local optimisation of the same winner."""
+    n, thr = 1200, 1.5e-6
+    pa, pb, K, R, t, is_out = orc.synthetic_two_view(n, seed=4)
+    fa = [Feature(x=float(p[0]), y=float(p[1])) for p in pa]
+    fb = [Feature(x=float(p[0]), y=float(p[1])) for p in pb]
+    matches = [Match(i, i, 0.0) for i in range(n)]
+    kw = dict(sed_inlier_threshold=thr, min_num_extra_inliers=150,
+              error_aggregation_method=ErrorAggregationMethod.RMS, max_iterations=300)
+    random.seed(5)
+    E0, pairs0 = epipolar_ransac.estimate_essential_mat_with_ransac(K, fa, fb, matches, **kw)
+    monkeypatch.setenv("SFM_LOCAL_OPTIMIZATION", "5")
+    random.seed(5)
+    E1, pairs1 = epipolar_ransac.estimate_essential_mat_with_ransac(K, fa, fb, matches, **kw)
+    assert len(pairs1) > len(pairs0)
+    corr = orc.pack_correspondences(orc.to_normalized_image_coords(pa, K), orc.to_normalized_image_coords(pb, K))
+    lookup = {(f.x, f.y): i for i, f in enumerate(fa)}
+    mask0 = np.zeros(n, dtype=bool)
+    mask0[[lookup[(a.x, a.y)] for a, _ in pairs0]] = True
+    sed0 = orc.sed_values(E0, corr)[mask0]
+    err0 = float(np.sqrt(np.mean(sed0 * sed0)))
+    E_o, m_o, cnt_o, _, acc_o = orc.local_optimisation(corr, E0, mask0, err0, thr, orc.RMS, 5)
+    assert acc_o >= 1 and len(pairs1) == cnt_o
+    assert [lookup[(a.x, a.y)] for a, _ in pairs1] == list(np.nonzero(m_o)[0])
+    assert np.max(np.abs(E1 - E_o)) / np.max(np.abs(E_o)) <= 1e-9

@@ -242,3 +242,48 @@ def test_oracle_fit_against_multiprecision():
         # null-vector conditioning ~ eps * lambda_max / lambda_2 (lambda_max ~ 10 after Hartley scaling)
         assert np.max(np.abs(E[i] - truth)) / np.max(np.abs(truth)) <= 1e-13 * max(100.0, 100.0 / lam_true)
         assert abs(lam2[i] - lam_true) <= 1e-13
+
+
+# ------------------------------------------------------------------------------------------------------
+# local optimisation (extension): the N-point fit against the reference's helpers (G13)
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_refit_matches_reference_helpers(golden, case):
+    d = golden("g13_refit")
+    K = d[f"{case}_K"]
+    corr = orc.pack_correspondences(orc.to_normalized_image_coords(d[f"{case}_pix_a"], K),
+                                    orc.to_normalized_image_coords(d[f"{case}_pix_b"], K))
+    E, degenerate = orc.refit_on_points(corr, d[f"{case}_idx"])
+    assert not degenerate
+    want = d[f"{case}_E"]
+    assert np.max(np.abs(E - want)) / np.max(np.abs(want)) <= 1e-9
+
+
+def test_local_optimisation_semantics():
+    pa, pb, K, R, t, is_out = orc.synthetic_two_view(2000, seed=6)
+    corr = orc.pack_correspondences(orc.to_normalized_image_coords(pa, K), orc.to_normalized_image_coords(pb, K))
+    S = orc.philox_sample_table(5, 0, 500, 2000)
+    thr = 1.5e-6
+    ref = orc.ransac_essential(corr, S, thr, 200, orc.RMS)
+    mask = np.zeros(2000, dtype=bool)
+    mask[ref["inliers"]] = True
+    counts = []
+    for rounds in (0, 1, 2, 3, 10):
+        E, m, cnt, err, accepted = orc.local_optimisation(corr, ref["E"], mask, ref["err"], thr, orc.RMS, rounds)
+        counts.append(cnt)
+        assert accepted <= rounds and cnt == m.sum()
+        if rounds == 0:
+            np.testing.assert_array_equal(E, ref["E"])
+            np.testing.assert_array_equal(m, mask)
+        else:  # the mask is exactly the threshold set of the returned model
+            np.testing.assert_array_equal(m, orc.sed_values(E, corr) <= thr)
+    assert counts == sorted(counts) and counts[-1] > counts[0]  # never loses inliers; here it gains
+    # far fewer outliers among the inliers than in the data
+    assert (m & is_out).sum() <= 0.01 * m.sum()
+    # fewer than eight inliers, or a degenerate inlier set (all points identical): nothing happens
+    few = np.zeros(2000, dtype=bool)
+    few[:7] = True
+    assert orc.local_optimisation(corr, ref["E"], few, 1.0, thr, orc.RMS, 3)[4] == 0
+    flat = corr.copy()
+    flat[:] = corr[0]
+    assert orc.local_optimisation(flat, ref["E"], mask, 1.0, thr, orc.RMS, 3)[4] == 0
