@@ -198,7 +198,9 @@ int sfm_patch_extract(const double* image, int64_t height, int64_t width, const 
                       uint8_t* ok, void* stream);
 
 /* scores[a,b] for every pair of features (the score_function calls of matching.py:57-65).
- * metric SFM_MATCH_NCC needs mean-removed patches.  scores: dev f64 [n_a,n_b]. */
+ * metric SFM_MATCH_NCC needs mean-removed patches.  scores: dev f64 [n_a,n_b].
+ * Fast path (LDS-DMA staging) when both patch arrays are 16-byte aligned with an even `stride` >= n rounded up to a
+ * multiple of 128 (the padding may hold anything); any other layout works through a slower staging loop. */
 int sfm_pair_scores(int metric, const double* patches_a, int64_t stride_a, const double* patches_b,
                     int64_t stride_b, const double* ssq_a, const double* ssq_b, const uint8_t* ok_a,
                     const uint8_t* ok_b, int64_t n_a, int64_t n_b, int window_elements, double* scores,
@@ -210,6 +212,15 @@ int sfm_pair_scores(int metric, const double* patches_a, int64_t stride_a, const
  * best, second: dev f64 [n_a]; arg: dev int32 [n_a]. */
 int sfm_match_row_summary(const double* scores, int64_t n_a, int64_t n_b, double* best, int32_t* arg,
                           double* second, void* stream);
+
+/* sfm_pair_scores + sfm_match_row_summary in one pass that never materialises the |A| x |B| matrix: each tile of
+ * scores is reduced on chip to four numbers per row, a second small kernel walks them in b order.  Same outputs,
+ * bit for bit.  workspace: dev, 16-byte aligned, >= sfm_match_summary_workspace_bytes(n_a, n_b) bytes. */
+int64_t sfm_match_summary_workspace_bytes(int64_t n_a, int64_t n_b);
+int sfm_match_summary(int metric, const double* patches_a, int64_t stride_a, const double* patches_b,
+                      int64_t stride_b, const double* ssq_a, const double* ssq_b, const uint8_t* ok_a,
+                      const uint8_t* ok_b, int64_t n_a, int64_t n_b, int window_elements, void* workspace,
+                      int64_t workspace_bytes, double* best, int32_t* arg, double* second, void* stream);
 
 /* ---- Harris corner detector stencils (reference lib/harris/harris_detector.py, lib/common/correlate.py) ---- */
 

@@ -60,6 +60,7 @@ SIGNATURES = {
     "sfm_patch_extract": [_P, _I64, _I64, _P, _I64, C.c_int, C.c_int, _I64, _P, _P, _P, _P],
     "sfm_pair_scores": [C.c_int, _P, _I64, _P, _I64, _P, _P, _P, _P, _I64, _I64, C.c_int, _P, _P],
     "sfm_match_row_summary": [_P, _I64, _I64, _P, _P, _P, _P],
+    "sfm_match_summary": [C.c_int, _P, _I64, _P, _I64, _P, _P, _P, _P, _I64, _I64, C.c_int, _P, _I64, _P, _P, _P, _P],
     "sfm_cross_correlate": [_P, _I64, _I64, _P, C.c_int, _P, _P],
     "sfm_harris_cornerness": [_P, _P, _I64, _I64, C.c_int, _D, C.c_int, _I64, _I64, _P, _P],
     "sfm_nms_inplace": [_P, _I64, _I64, _P],
@@ -67,7 +68,8 @@ SIGNATURES = {
     "sfm_nms_finalize": [_P, _P, _I64, _I64, _P],
     "sfm_pyshuffle_table": [_P, _P, _I64, _I64, _P, _P, _I64, _P],
 }
-OTHER_SYMBOLS = ["sfm_last_error", "sfm_abi_version", "sfm_score_workspace_bytes", "sfm_fit_trace_doubles"]
+OTHER_SYMBOLS = ["sfm_last_error", "sfm_abi_version", "sfm_score_workspace_bytes", "sfm_fit_trace_doubles",
+                 "sfm_match_summary_workspace_bytes"]
 
 _lib = None
 
@@ -99,6 +101,8 @@ def load() -> C.CDLL:
     lib.sfm_fit_trace_doubles.argtypes = []
     lib.sfm_score_workspace_bytes.restype = C.c_int64
     lib.sfm_score_workspace_bytes.argtypes = [_I64, _I64, _I64]
+    lib.sfm_match_summary_workspace_bytes.restype = C.c_int64
+    lib.sfm_match_summary_workspace_bytes.argtypes = [_I64, _I64]
     if lib.sfm_abi_version() != ABI_VERSION:
         raise NativeLibraryError(
             f"libsfm_hip.so ABI {lib.sfm_abi_version()} != expected {ABI_VERSION}; rebuild it")

@@ -378,6 +378,77 @@ __global__ void select_final_kernel(const int32_t* __restrict__ cnt, int64_t h_c
     result[b] = r;
 }
 
+// The whole selection in ONE launch for moderate hypothesis counts: a 1024-thread block per batch entry takes the
+// lexicographic minimum of (error bits, index) directly — same keys, same winner as the three passes above, three
+// launches fewer (a small RANSAC pass is a chain of ~4 us kernels; profiles/r01/README.md).
+constexpr int kSelectBlock = 1024;
+__global__ __launch_bounds__(kSelectBlock) void select_block_kernel(
+    const int32_t* __restrict__ cnt, const double* __restrict__ s1, const double* __restrict__ s2,
+    const int32_t* __restrict__ flags, int64_t h_count, int64_t h_offset, double min_extra, int aggregation,
+    sfm_select_result* __restrict__ result) {
+    __shared__ uint64_t sh_key[kSelectBlock / kWave];
+    __shared__ int64_t sh_best[kSelectBlock / kWave], sh_first[kSelectBlock / kWave];
+    __shared__ int sh_flags[kSelectBlock / kWave];
+    const int64_t b = blockIdx.x;
+    cnt += b * h_count; s1 += b * h_count; s2 += b * h_count;
+    if (flags != nullptr) flags += b * h_count;
+    uint64_t key = kNoModelKey;
+    int64_t best = INT64_MAX, first_flag = INT64_MAX;
+    int n_flag = 0;
+    // four hypotheses per trip with their loads issued together (the loop is pure load latency otherwise)
+    for (int64_t h0 = threadIdx.x; h0 < h_count; h0 += 4 * kSelectBlock) {  // increasing h: strict < keeps the earliest
+        uint64_t k[4];
+        bool flagged[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t h = h0 + u * kSelectBlock;
+            flagged[u] = false;
+            k[u] = h < h_count ? hypothesis_key(cnt, s1, s2, flags, h, min_extra, aggregation, flagged[u]) : kNoModelKey;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t h = h0 + u * kSelectBlock;
+            if (k[u] < key) {
+                key = k[u];
+                best = h;
+            }
+            if (flagged[u]) {
+                first_flag = h < first_flag ? h : first_flag;
+                ++n_flag;
+            }
+        }
+    }
+    auto combine = [&](uint64_t ok, int64_t ob, int64_t of, int on) {
+        if (ok < key || (ok == key && ob < best)) {
+            key = ok;
+            best = ob;
+        }
+        first_flag = of < first_flag ? of : first_flag;
+        n_flag += on;
+    };
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        combine(__shfl_xor(key, off, 64), __shfl_xor(best, off, 64), __shfl_xor(first_flag, off, 64),
+                __shfl_xor(n_flag, off, 64));
+    const int wave = threadIdx.x / kWave;
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        sh_key[wave] = key; sh_best[wave] = best; sh_first[wave] = first_flag; sh_flags[wave] = n_flag;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kSelectBlock / kWave; ++w) combine(sh_key[w], sh_best[w], sh_first[w], sh_flags[w]);
+        const bool found = key != kNoModelKey && best != INT64_MAX;
+        sfm_select_result r;
+        r.key = found ? key : kNoModelKey;
+        r.best_h = found ? best + h_offset : -1;
+        r.best_err = found ? __longlong_as_double((long long)key) : INFINITY;
+        r.first_flagged = first_flag != INT64_MAX ? first_flag + h_offset : INT64_MAX;
+        r.n_flagged = n_flag;
+        r.best_cnt = found ? cnt[best] : 0;
+        result[b] = r;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Inlier mask of the winner (ransac.py:70-76): 1 = surviving non-sample point, 2 = sample point.
 // ------------------------------------------------------------------------------------------------
@@ -683,6 +754,11 @@ int sfm_select_best(const int32_t* cnt, const double* s1, const double* s2, cons
     if (!result || (h_count > 0 && (!cnt || !s1 || !s2)))
         return fail(SFM_EINVAL, "sfm_select_best: null pointer");
     hipStream_t st = (hipStream_t)stream;
+    if (h_count <= 32 * kSelectBlock) {  // <= 32 hypotheses per thread: one block per batch entry, one launch
+        hipLaunchKernelGGL(select_block_kernel, dim3((unsigned)batch), dim3(kSelectBlock), 0, st, cnt, s1, s2, flags,
+                           h_count, h_offset, min_extra, aggregation, result);
+        return check_launch("select_block_kernel");
+    }
     hipLaunchKernelGGL(select_init_kernel, dim3((unsigned)batch), dim3(1), 0, st, result);
     if (h_count > 0) {
         const dim3 grid(grid_for(h_count, 256, 64), (unsigned)batch);

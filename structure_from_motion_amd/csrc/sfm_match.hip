@@ -4,7 +4,7 @@
 //   patch_extract_kernel   one lane per feature: bounds test, window gather, (NCC) mean removal and sum of
 //                          squares.  Patches are stored k-major  P[k][feature]  so that the score kernel's
 //                          loads are coalesced across features.
-//   pair_scores_kernel     |A| x |B| scores, 64x64 tile per 256-thread block, 4x4 outputs per lane, window
+//   pair_scores_kernel     |A| x |B| scores, 128x128 tile per 256-thread block, 8x8 outputs per lane, window
 //                          chunks staged through LDS.  The window sum runs over k = 0..K-1 in order with
 //                          separate multiply / add roundings (no FMA), so every score is bit-identical to the
 //                          oracle's sequential evaluation whatever the tiling.  fp64 VALU bound (2K flop per
@@ -14,6 +14,9 @@
 //                          heap[0] = first minimum; heap[1] (the LEFT child, which the ratio test divides by —
 //                          not necessarily the second best) = min over pushes i landing in the left subtree of
 //                          max(score_i, running minimum before i).
+//   pair_summary_kernel +  the product path: the same tile core, but each block reduces its tile to four numbers
+//   summary_combine_kernel per row and a second small kernel walks them in B order — the |A| x |B| matrix is never
+//                          written (3.2 GB at 20k x 20k) nor re-read, with bit-identical summaries.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -27,8 +30,12 @@ using sfmhost::check_launch;
 using sfmhost::fail;
 using sfmhost::grid_for;
 
-constexpr int kTile = 64;     // features per tile side
-constexpr int kChunk = 32;    // window elements staged per LDS pass
+constexpr int kRowsPerLane = 8;                 // A-features per lane
+constexpr int kColGroups = 4;                   // B-features per lane: kColGroups groups of 2 adjacent columns
+constexpr int kColsPerLane = 2 * kColGroups;
+constexpr int kTileA = 16 * kRowsPerLane;       // 128 A-features per 256-thread block (16 x 16 lanes)
+constexpr int kTileB = 32 * kColGroups;         // 128 B-features per block
+constexpr int kChunk = 32;                      // window elements staged per LDS pass
 
 __global__ void patch_extract_kernel(const double* __restrict__ image, int64_t height, int64_t width,
                                      const double* __restrict__ feats, int64_t n, int64_t stride, int half,
@@ -69,46 +76,70 @@ __global__ void patch_extract_kernel(const double* __restrict__ image, int64_t h
     ok[i] = 1;
 }
 
-// MODE 0: NCC (patches mean-removed): score = (num / sqrt(qa qb)) * -1 + 1, 2.0 if a window is out of the image
-//         or the denominator is zero (ncc.py:24-54).
-// MODE 1: SSD: sum (a-b)^2 / K, +inf if a window is out of the image (ssd.py:24-36).
-template <int MODE>
-__global__ __launch_bounds__(256) void pair_scores_kernel(
-    const double* __restrict__ Pa, int64_t stride_a, const double* __restrict__ Pb, int64_t stride_b,
-    const double* __restrict__ qa, const double* __restrict__ qb, const uint8_t* __restrict__ oka,
-    const uint8_t* __restrict__ okb, int64_t nA, int64_t nB, int K, double* __restrict__ scores) {
-    __shared__ double sA[kChunk][kTile];
-    __shared__ double sB[kChunk][kTile];
-    const int tid = threadIdx.x;
-    const int ty = tid / 16, tx = tid % 16;  // 16 x 16 lanes, 4 x 4 outputs each
-    const int64_t a0 = (int64_t)blockIdx.y * kTile, b0 = (int64_t)blockIdx.x * kTile;
-    double acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+// Tile core shared by the score-matrix kernel and the fused summary kernel.  A 256-thread block owns a
+// kTileA x kTileB tile; lane (ty, tx) accumulates rows a0 + ty*8 + i (i < 8) against columns
+// b0 + g*32 + tx*2 + j (g < 4, j < 2): its B operands are four 16-byte LDS reads at consecutive-lane addresses
+// (conflict-free), its A operands two 32-byte broadcasts.  16 LDS doubles feed 64 multiply + 64 add per window
+// element (the 4x4 tile this replaces needed 8 for 16 + 16).  The window sum runs over k = 0..K-1 in order with
+// separate multiply / add roundings, so the result does not depend on the tiling.
+// MODE 0: NCC numerator sum a*b (patches mean-removed); MODE 1: SSD sum (a-b)^2.
+static_assert(kTileA == 2 * kWave && kTileB == 2 * kWave, "one LDS-DMA instruction (64 x 16 B) = one tile row");
+// 64 lanes x 16 bytes from per-lane global addresses to 1 KiB of LDS starting at `row` (wave-uniform)
+SFM_DEVICE void direct_row(const double* src, double* row) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)row, 16, 0, 0);
+}
 
+template <int MODE, bool DIRECT>
+SFM_DEVICE void tile_accumulate(const double* __restrict__ Pa, int64_t stride_a, const double* __restrict__ Pb,
+                                int64_t stride_b, int64_t nA, int64_t nB, int K, int64_t a0, int64_t b0,
+                                double (*sA)[kTileA], double (*sB)[kTileB],
+                                double (&acc)[kRowsPerLane][kColsPerLane]) {
+    const int tid = threadIdx.x;
+    const int ty = tid / 16, tx = tid % 16;
+#pragma unroll
+    for (int i = 0; i < kRowsPerLane; ++i)
+#pragma unroll
+        for (int j = 0; j < kColsPerLane; ++j) acc[i][j] = 0.0;
     for (int k0 = 0; k0 < K; k0 += kChunk) {
         const int kc = min(kChunk, K - k0);
         __syncthreads();
-        for (int idx = tid; idx < kc * kTile; idx += 256) {
-            const int kk = idx / kTile, f = idx % kTile;
-            const int64_t ia = a0 + f, ib = b0 + f;
-            sA[kk][f] = ia < nA ? Pa[(int64_t)(k0 + kk) * stride_a + ia] : 0.0;
-            sB[kk][f] = ib < nB ? Pb[(int64_t)(k0 + kk) * stride_b + ib] : 0.0;
+        if constexpr (DIRECT) {
+            // LDS-DMA staging: one global_load_lds_dwordx4 per window row and matrix moves 64 lanes x 16 B = the
+            // 128 features of the row straight into sA[kk] / sB[kk] — no staging registers (the kernel sits at the
+            // two-waves-per-SIMD register limit with its 8x8 accumulators), all rows of the chunk in flight at once.
+            // Needs 16-byte aligned rows padded to a multiple of 128 features (checked by the launcher).
+            const int wave = tid / kWave, lane = tid % kWave;
+            for (int kk = wave; kk < kc; kk += 256 / kWave) {
+                direct_row(Pa + (int64_t)(k0 + kk) * stride_a + a0 + 2 * lane, &sA[kk][0]);
+                direct_row(Pb + (int64_t)(k0 + kk) * stride_b + b0 + 2 * lane, &sB[kk][0]);
+            }
+        } else {
+            for (int idx = tid; idx < kc * kTileA; idx += 256) {
+                const int kk = idx / kTileA, f = idx % kTileA;
+                const int64_t ia = a0 + f;
+                sA[kk][f] = ia < nA ? Pa[(int64_t)(k0 + kk) * stride_a + ia] : 0.0;
+            }
+            for (int idx = tid; idx < kc * kTileB; idx += 256) {
+                const int kk = idx / kTileB, f = idx % kTileB;
+                const int64_t ib = b0 + f;
+                sB[kk][f] = ib < nB ? Pb[(int64_t)(k0 + kk) * stride_b + ib] : 0.0;
+            }
         }
         __syncthreads();
         for (int kk = 0; kk < kc; ++kk) {
-            double av[4], bv[4];
+            double av[kRowsPerLane], bv[kColsPerLane];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                av[i] = sA[kk][ty * 4 + i];
-                bv[i] = sB[kk][tx * 4 + i];
+            for (int i = 0; i < kRowsPerLane; ++i) av[i] = sA[kk][ty * kRowsPerLane + i];
+#pragma unroll
+            for (int g = 0; g < kColGroups; ++g) {
+                bv[2 * g] = sB[kk][g * 32 + tx * 2];
+                bv[2 * g + 1] = sB[kk][g * 32 + tx * 2 + 1];
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < kRowsPerLane; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < kColsPerLane; ++j) {
                     if (MODE == 0) {
                         acc[i][j] += av[i] * bv[j];
                     } else {
@@ -118,23 +149,41 @@ __global__ __launch_bounds__(256) void pair_scores_kernel(
                 }
         }
     }
+}
+
+// Window sum -> score.  MODE 0: (num / sqrt(qa qb)) * -1 + 1, 2.0 if a window is out of the image or the
+// denominator is zero (ncc.py:24-54).  MODE 1: sum / K, +inf if a window is out of the image (ssd.py:24-36).
+template <int MODE>
+SFM_DEVICE double finish_score(double acc, bool inside, double qa, double qb, int K) {
+    if (MODE == 0) {
+        const double den = sqrt(qa * qb);
+        return (!inside || den == 0.0) ? 2.0 : (acc / den) * -1.0 + 1.0;
+    }
+    return inside ? acc / (double)K : INFINITY;
+}
+
+template <int MODE, bool DIRECT>
+__global__ __launch_bounds__(256, 2) void pair_scores_kernel(
+    const double* __restrict__ Pa, int64_t stride_a, const double* __restrict__ Pb, int64_t stride_b,
+    const double* __restrict__ qa, const double* __restrict__ qb, const uint8_t* __restrict__ oka,
+    const uint8_t* __restrict__ okb, int64_t nA, int64_t nB, int K, double* __restrict__ scores) {
+    __shared__ double sA[kChunk][kTileA];
+    __shared__ double sB[kChunk][kTileB];
+    const int ty = threadIdx.x / 16, tx = threadIdx.x % 16;
+    const int64_t a0 = (int64_t)blockIdx.y * kTileA, b0 = (int64_t)blockIdx.x * kTileB;
+    double acc[kRowsPerLane][kColsPerLane];
+    tile_accumulate<MODE, DIRECT>(Pa, stride_a, Pb, stride_b, nA, nB, K, a0, b0, sA, sB, acc);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t ia = a0 + ty * 4 + i;
+    for (int i = 0; i < kRowsPerLane; ++i) {
+        const int64_t ia = a0 + ty * kRowsPerLane + i;
         if (ia >= nA) continue;
+        const double qai = qa[ia];
+        const bool oki = oka[ia] != 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int64_t ib = b0 + tx * 4 + j;
+        for (int j = 0; j < kColsPerLane; ++j) {
+            const int64_t ib = b0 + (j / 2) * 32 + tx * 2 + (j % 2);
             if (ib >= nB) continue;
-            const bool inside = oka[ia] && okb[ib];
-            double s;
-            if (MODE == 0) {
-                const double den = sqrt(qa[ia] * qb[ib]);
-                s = (!inside || den == 0.0) ? 2.0 : (acc[i][j] / den) * -1.0 + 1.0;
-            } else {
-                s = inside ? acc[i][j] / (double)K : INFINITY;
-            }
-            scores[ia * nB + ib] = s;
+            scores[ia * nB + ib] = finish_score<MODE>(acc[i][j], oki && okb[ib] != 0, qai, qb[ib], K);
         }
     }
 }
@@ -201,6 +250,127 @@ __global__ __launch_bounds__(256) void row_summary_kernel(const double* __restri
     }
 }
 
+// ---- fused path: scores never leave the chip ---------------------------------------------------------------
+// The heap summary of a row is a scan in B order, but it splits over column tiles: with c = minimum of everything
+// before the tile and p_i = minimum of the tile's own columns before i,
+//     max(v_i, min(c, p_i)) = min(max(v_i, p_i), max(v_i, c)),   and   min_i max(v_i, c) = max(c, min_i v_i),
+// so per (row, tile) four numbers suffice: M = tile minimum, its first column, A = min over left-subtree columns of
+// max(v_i, p_i), B = min over left-subtree columns of v_i.  All of it is selection (min / max / compare), no
+// arithmetic: the result is bit-identical to row_summary_kernel on the full matrix.  32 B per 128 scores leave
+// the kernel instead of 1 KiB, and the matrix is never re-read.
+struct TileSummary {
+    double tile_min, left_prefixed, left_min;
+    int64_t tile_arg;
+};
+static_assert(sizeof(TileSummary) == 32, "workspace sizing in sfm_match_summary_workspace_bytes");
+
+template <int MODE, bool DIRECT>
+__global__ __launch_bounds__(256, 2) void pair_summary_kernel(
+    const double* __restrict__ Pa, int64_t stride_a, const double* __restrict__ Pb, int64_t stride_b,
+    const double* __restrict__ qa, const double* __restrict__ qb, const uint8_t* __restrict__ oka,
+    const uint8_t* __restrict__ okb, int64_t nA, int64_t nB, int K, TileSummary* __restrict__ tiles) {
+    __shared__ double sA[kChunk][kTileA];
+    __shared__ double sB[kChunk][kTileB];
+    const int ty = threadIdx.x / 16, tx = threadIdx.x % 16;
+    const int64_t a0 = (int64_t)blockIdx.y * kTileA, b0 = (int64_t)blockIdx.x * kTileB;
+    double acc[kRowsPerLane][kColsPerLane];
+    tile_accumulate<MODE, DIRECT>(Pa, stride_a, Pb, stride_b, nA, nB, K, a0, b0, sA, sB, acc);
+    // per-column operands of this lane's 8 columns
+    double qbj[kColsPerLane];
+    bool okj[kColsPerLane], validj[kColsPerLane], leftj[kColsPerLane];
+#pragma unroll
+    for (int j = 0; j < kColsPerLane; ++j) {
+        const int64_t ib = b0 + (j / 2) * 32 + tx * 2 + (j % 2);
+        validj[j] = ib < nB;
+        qbj[j] = validj[j] ? qb[ib] : 0.0;
+        okj[j] = validj[j] && okb[ib] != 0;
+        leftj[j] = validj[j] && ib >= 1 && in_left_subtree(ib + 1);
+    }
+#pragma unroll
+    for (int i = 0; i < kRowsPerLane; ++i) {
+        const int64_t ia = a0 + ty * kRowsPerLane + i;
+        const bool row_valid = ia < nA;  // uniform over the 16 lanes of the row
+        const double qai = row_valid ? qa[ia] : 0.0;
+        const bool oki = row_valid && oka[ia] != 0;
+        double carry = INFINITY;  // minimum of the tile's columns before the current group
+        double left_prefixed = INFINITY, left_min = INFINITY;
+        MinAt top = {INFINITY, INT64_MAX};
+#pragma unroll
+        for (int g = 0; g < kColGroups; ++g) {
+            const int64_t c0 = b0 + g * 32 + tx * 2;
+            const double v0 = finish_score<MODE>(acc[i][2 * g], oki && okj[2 * g], qai, qbj[2 * g], K);
+            const double v1 = finish_score<MODE>(acc[i][2 * g + 1], oki && okj[2 * g + 1], qai, qbj[2 * g + 1], K);
+            const double m0 = validj[2 * g] ? v0 : INFINITY, m1 = validj[2 * g + 1] ? v1 : INFINITY;
+            // fmin drops NaN operands; the trailing fmin with +inf also clears the both-NaN case
+            double incl = fmin(fmin(m0, m1), INFINITY);
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                const double other = __shfl_up(incl, off, 16);
+                if (tx >= off) incl = fmin(incl, other);
+            }
+            double excl = __shfl_up(incl, 1, 16);
+            excl = tx == 0 ? INFINITY : excl;
+            const double p0 = fmin(carry, excl);
+            const double p1 = fmin(p0, m0);
+            if (leftj[2 * g]) {
+                left_prefixed = fmin(left_prefixed, (v0 < p0) ? p0 : v0);  // displaced root, or the new item itself
+                left_min = fmin(left_min, v0);
+            }
+            if (leftj[2 * g + 1]) {
+                left_prefixed = fmin(left_prefixed, (v1 < p1) ? p1 : v1);
+                left_min = fmin(left_min, v1);
+            }
+            if (validj[2 * g]) top = min_at(top, MinAt{v0, c0});
+            if (validj[2 * g + 1]) top = min_at(top, MinAt{v1, c0 + 1});
+            carry = fmin(carry, __shfl(incl, 15, 16));
+        }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+            MinAt o;
+            o.v = __shfl_xor(top.v, off, 16);
+            o.i = __shfl_xor(top.i, off, 16);
+            top = min_at(top, o);
+            left_prefixed = fmin(left_prefixed, __shfl_xor(left_prefixed, off, 16));
+            left_min = fmin(left_min, __shfl_xor(left_min, off, 16));
+        }
+        if (tx == 0 && row_valid) {
+            TileSummary r;
+            r.tile_min = top.v;
+            r.left_prefixed = left_prefixed;
+            r.left_min = left_min;
+            r.tile_arg = top.i;
+            tiles[(int64_t)blockIdx.x * nA + ia] = r;
+        }
+    }
+}
+
+// one thread per A-feature walks its tile summaries in B order
+__global__ void summary_combine_kernel(const TileSummary* __restrict__ tiles, int64_t nA, int64_t nB,
+                                       int64_t n_tiles, double* __restrict__ best, int32_t* __restrict__ arg,
+                                       double* __restrict__ second) {
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= nA) return;
+    double before = INFINITY, sec = INFINITY;  // `before`: minimum of all columns ahead of the tile
+    MinAt top = {INFINITY, INT64_MAX};
+    for (int64_t t = 0; t < n_tiles; ++t) {
+        const TileSummary r = tiles[t * nA + row];
+        const double via_before = (r.left_min < before) ? before : r.left_min;
+        sec = fmin(sec, fmin(r.left_prefixed, via_before));
+        top = min_at(top, MinAt{r.tile_min, r.tile_arg});
+        before = fmin(before, r.tile_min);
+    }
+    best[row] = top.v;
+    arg[row] = (int32_t)top.i;
+    second[row] = nB > 1 ? sec : NAN;
+}
+
+// LDS-DMA staging reads whole 128-feature rows: every row must be 16-byte aligned and long enough that the last
+// tile stays inside it (what it reads beyond n only feeds outputs that are never written).
+bool direct_staging_ok(const double* patches, int64_t stride, int64_t n) {
+    return (reinterpret_cast<uintptr_t>(patches) & 15u) == 0 && (stride & 1) == 0 &&
+           stride >= (n + kTileA - 1) / kTileA * kTileA;
+}
+
 }  // namespace
 
 extern "C" {
@@ -227,14 +397,58 @@ int sfm_pair_scores(int metric, const double* patches_a, int64_t stride_a, const
     if (n_a == 0 || n_b == 0) return SFM_OK;
     if (!patches_a || !patches_b || !ssq_a || !ssq_b || !ok_a || !ok_b || !scores)
         return fail(SFM_EINVAL, "sfm_pair_scores: null pointer");
-    const dim3 grid(grid_for(n_b, kTile), grid_for(n_a, kTile));
-    if (metric == SFM_MATCH_NCC)
-        hipLaunchKernelGGL(pair_scores_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, patches_a, stride_a,
-                           patches_b, stride_b, ssq_a, ssq_b, ok_a, ok_b, n_a, n_b, window_elements, scores);
-    else
-        hipLaunchKernelGGL(pair_scores_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, patches_a, stride_a,
-                           patches_b, stride_b, ssq_a, ssq_b, ok_a, ok_b, n_a, n_b, window_elements, scores);
+    const dim3 grid(grid_for(n_b, kTileB), grid_for(n_a, kTileA));
+    const bool direct = direct_staging_ok(patches_a, stride_a, n_a) && direct_staging_ok(patches_b, stride_b, n_b);
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, grid, dim3(256), 0, (hipStream_t)stream, patches_a, stride_a, patches_b, stride_b,
+                           ssq_a, ssq_b, ok_a, ok_b, n_a, n_b, window_elements, scores);
+    };
+    if (metric == SFM_MATCH_NCC) {
+        if (direct) launch(pair_scores_kernel<0, true>); else launch(pair_scores_kernel<0, false>);
+    } else {
+        if (direct) launch(pair_scores_kernel<1, true>); else launch(pair_scores_kernel<1, false>);
+    }
     return check_launch("pair_scores_kernel");
+}
+
+int64_t sfm_match_summary_workspace_bytes(int64_t n_a, int64_t n_b) {
+    if (n_a < 0 || n_b < 0) return -1;
+    return (int64_t)sizeof(TileSummary) * n_a * ((n_b + kTileB - 1) / kTileB);
+}
+
+int sfm_match_summary(int metric, const double* patches_a, int64_t stride_a, const double* patches_b,
+                      int64_t stride_b, const double* ssq_a, const double* ssq_b, const uint8_t* ok_a,
+                      const uint8_t* ok_b, int64_t n_a, int64_t n_b, int window_elements, void* workspace,
+                      int64_t workspace_bytes, double* best, int32_t* arg, double* second, void* stream) {
+    if (n_a < 0 || n_b < 0 || window_elements < 1) return fail(SFM_EINVAL, "sfm_match_summary: bad size");
+    if (metric != SFM_MATCH_NCC && metric != SFM_MATCH_SSD) return fail(SFM_EINVAL, "sfm_match_summary: unknown metric");
+    if (n_a == 0) return SFM_OK;
+    if (n_b == 0) return fail(SFM_EINVAL, "sfm_match_summary: empty rows");
+    if (n_b > 0x7FFFFFFF) return fail(SFM_EINVAL, "sfm_match_summary: rows too long");
+    if (!patches_a || !patches_b || !ssq_a || !ssq_b || !ok_a || !ok_b || !workspace || !best || !arg || !second)
+        return fail(SFM_EINVAL, "sfm_match_summary: null pointer");
+    if (workspace_bytes < sfm_match_summary_workspace_bytes(n_a, n_b))
+        return fail(SFM_EINVAL, "sfm_match_summary: workspace smaller than sfm_match_summary_workspace_bytes(n_a, n_b)");
+    if ((reinterpret_cast<uintptr_t>(workspace) & 15u) != 0)
+        return fail(SFM_EINVAL, "sfm_match_summary: workspace must be 16-byte aligned");
+    const int64_t n_tiles = (n_b + kTileB - 1) / kTileB;
+    if (grid_for(n_a, kTileA) > 65535u) return fail(SFM_EINVAL, "sfm_match_summary: too many A features");
+    const dim3 grid((unsigned)n_tiles, grid_for(n_a, kTileA));
+    TileSummary* tiles = static_cast<TileSummary*>(workspace);
+    hipStream_t st = (hipStream_t)stream;
+    const bool direct = direct_staging_ok(patches_a, stride_a, n_a) && direct_staging_ok(patches_b, stride_b, n_b);
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, grid, dim3(256), 0, st, patches_a, stride_a, patches_b, stride_b, ssq_a, ssq_b,
+                           ok_a, ok_b, n_a, n_b, window_elements, tiles);
+    };
+    if (metric == SFM_MATCH_NCC) {
+        if (direct) launch(pair_summary_kernel<0, true>); else launch(pair_summary_kernel<0, false>);
+    } else {
+        if (direct) launch(pair_summary_kernel<1, true>); else launch(pair_summary_kernel<1, false>);
+    }
+    hipLaunchKernelGGL(summary_combine_kernel, dim3(grid_for(n_a, 256)), dim3(256), 0, st, tiles, n_a, n_b, n_tiles,
+                       best, arg, second);
+    return check_launch("pair_summary_kernel");
 }
 
 int sfm_match_row_summary(const double* scores, int64_t n_a, int64_t n_b, double* best, int32_t* arg,

@@ -545,6 +545,45 @@ __global__ __launch_bounds__(256) void score_sed_filtered_kernel(
     }
 }
 
+struct FilteredLaunch {
+    const Corr* corr;
+    unsigned char* ws;
+    int n;
+    const double* E;
+    const int32_t* S;
+    int h_count;
+    double thr;
+    bool use_order;
+    int32_t* cnt;
+    double* s1;
+    double* s2;
+    int32_t* buckets;
+    int32_t* order;
+    int64_t batch;
+    hipStream_t st;
+};
+
+template <int HPW>
+int launch_filtered(const FilteredLaunch& a) {
+    const int64_t waves = (a.h_count + HPW - 1) / HPW;
+    const dim3 grid(grid_for(waves, 256 / kWave), (unsigned)a.batch);
+    const int32_t* order_arg = nullptr;
+    if (a.use_order) {
+        // `cnt` doubles as the estimate buffer: it is rewritten by the scoring kernel afterwards
+        hipLaunchKernelGGL(score_estimate_kernel<HPW>, grid, dim3(256), 0, a.st, a.ws, a.n, a.E, a.h_count, a.thr, a.cnt);
+        const dim3 per_hyp(grid_for(a.h_count, 256), (unsigned)a.batch);
+        hipLaunchKernelGGL(score_class_count_kernel, per_hyp, dim3(256), 0, a.st, a.cnt, a.h_count, a.buckets);
+        hipLaunchKernelGGL(score_class_scan_kernel, dim3(grid_for(a.batch, 64)), dim3(64), 0, a.st, a.buckets, a.batch);
+        hipLaunchKernelGGL(score_class_scatter_kernel, per_hyp, dim3(256), 0, a.st, a.cnt, a.h_count, a.buckets, a.order);
+        const int rc = check_launch("score order kernels");
+        if (rc != SFM_OK) return rc;
+        order_arg = a.order;
+    }
+    hipLaunchKernelGGL(score_sed_filtered_kernel<HPW>, grid, dim3(256), 0, a.st, a.corr, a.ws, a.n, a.E, a.S, a.h_count,
+                       a.thr, order_arg, a.cnt, a.s1, a.s2);
+    return check_launch("score_sed_filtered_kernel");
+}
+
 }  // namespace
 
 extern "C" {
@@ -587,23 +626,24 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
     // the end): 256 CUs x 20 resident waves = 5120 per generation; beyond ~12 generations the tail is negligible
     // and the pre-pass would cost more than it saves.
     const int order_env = getenv("SFM_SCORE_ORDER") ? atoi(getenv("SFM_SCORE_ORDER")) : -1;
-    const bool use_order = order_env >= 0 ? order_env != 0 : (waves * batch <= 12 * 5120 && n >= 4096);
-    const int32_t* order_arg = nullptr;
-    if (use_order) {
-        // `cnt` doubles as the estimate buffer: it is rewritten by the scoring kernel afterwards
-        hipLaunchKernelGGL(score_estimate_kernel<kHypPerWave>, grid, dim3(256), 0, st, ws, (int)n, E, (int)h_count, thr,
-                           cnt);
-        const dim3 per_hyp(grid_for(h_count, 256), (unsigned)batch);
-        hipLaunchKernelGGL(score_class_count_kernel, per_hyp, dim3(256), 0, st, cnt, (int)h_count, buckets);
-        hipLaunchKernelGGL(score_class_scan_kernel, dim3(grid_for(batch, 64)), dim3(64), 0, st, buckets, batch);
-        hipLaunchKernelGGL(score_class_scatter_kernel, per_hyp, dim3(256), 0, st, cnt, (int)h_count, buckets, order);
-        rc = check_launch("score order kernels");
-        if (rc != SFM_OK) return rc;
-        order_arg = order;
+    // ... and its fixed cost (~25 us) needs enough points per hypothesis to be won back (measured break-even ~8k).
+    const bool use_order = order_env >= 0 ? order_env != 0 : (waves * batch <= 12 * 5120 && n >= 8192);
+    // hypotheses per wave: 4 amortises the point loads best, but a launch with fewer waves than the chip holds
+    // (5120) leaves SIMDs idle — then fewer hypotheses per wave = more waves wins (SFM_SCORE_HPW overrides)
+    const int hpw_env = getenv("SFM_SCORE_HPW") ? atoi(getenv("SFM_SCORE_HPW")) : 0;
+    int hpw = kHypPerWave;
+    if (hpw_env == 1 || hpw_env == 2 || hpw_env == 4) {
+        hpw = hpw_env;
+    } else {
+        while (hpw > 1 && (h_count + hpw - 1) / hpw * batch < 5120) hpw /= 2;
     }
-    hipLaunchKernelGGL(score_sed_filtered_kernel<kHypPerWave>, grid, dim3(256), 0, st, (const Corr*)corr, ws, (int)n, E,
-                       S, (int)h_count, thr, order_arg, cnt, s1, s2);
-    return check_launch("score_sed_filtered_kernel");
+    const FilteredLaunch args{(const Corr*)corr, ws, (int)n, E, S, (int)h_count, thr, use_order, cnt, s1, s2,
+                              buckets, order, batch, st};
+    switch (hpw) {
+        case 1: return launch_filtered<1>(args);
+        case 2: return launch_filtered<2>(args);
+        default: return launch_filtered<4>(args);
+    }
 }
 
 }  // extern "C"

@@ -26,8 +26,8 @@ def _image_tensor(image: np.ndarray) -> torch.Tensor:
     return device.to_device(np.ascontiguousarray(image, dtype=np.float64))
 
 
-def score_matrix(metric: int, image_a, image_b, feats_a, feats_b, window_size: int) -> torch.Tensor:
-    """(nA, nB) device tensor of window scores for every feature pair."""
+def _extract_patches(metric: int, image_a, image_b, feats_a, feats_b, window_size: int):
+    """Window patches of both feature sets on the device: ((patches, ssq, ok, n) for a, same for b, K)."""
     if image_a.shape != image_b.shape:
         raise ValueError("the images must have the same shape")
     lib = _native.load()
@@ -40,15 +40,23 @@ def score_matrix(metric: int, image_a, image_b, feats_a, feats_b, window_size: i
         img = _image_tensor(image)
         ft = feats if isinstance(feats, torch.Tensor) else _features_tensor(feats)
         n = ft.shape[0]
-        patches = torch.empty((K, max(n, 1)), dtype=F64, device=dev)
+        # rows padded to whole 128-feature tiles: the score kernels then stage them by LDS-DMA (sfm_match.hip)
+        patches = torch.empty((K, max(-(-n // 128) * 128, 128)), dtype=F64, device=dev)
         ssq = torch.empty((max(n, 1),), dtype=F64, device=dev)
         ok = torch.empty((max(n, 1),), dtype=torch.uint8, device=dev)
         check(lib.sfm_patch_extract(img.data_ptr(), img.shape[0], img.shape[1], ft.data_ptr(), n, int(window_size),
                                     1 if metric == MATCH_NCC else 0, patches.shape[1], patches.data_ptr(),
                                     ssq.data_ptr(), ok.data_ptr(), st), "sfm_patch_extract")
         out.append((patches, ssq, ok, n))
-    (pa, qa, oka, nA), (pb, qb, okb, nB) = out
-    scores = torch.empty((nA, nB), dtype=F64, device=dev)
+    return out[0], out[1], K
+
+
+def score_matrix(metric: int, image_a, image_b, feats_a, feats_b, window_size: int) -> torch.Tensor:
+    """(nA, nB) device tensor of window scores for every feature pair."""
+    (pa, qa, oka, nA), (pb, qb, okb, nB), K = _extract_patches(metric, image_a, image_b, feats_a, feats_b, window_size)
+    lib = _native.load()
+    st = device._stream()
+    scores = torch.empty((nA, nB), dtype=F64, device=pa.device)
     check(lib.sfm_pair_scores(metric, pa.data_ptr(), pa.shape[1], pb.data_ptr(), pb.shape[1], qa.data_ptr(),
                               qb.data_ptr(), oka.data_ptr(), okb.data_ptr(), nA, nB, K, scores.data_ptr(), st),
           "sfm_pair_scores")
@@ -64,4 +72,23 @@ def row_summary(scores: torch.Tensor) -> Tuple[np.ndarray, np.ndarray, np.ndarra
     second = torch.empty((nA,), dtype=F64, device=scores.device)
     check(lib.sfm_match_row_summary(scores.data_ptr(), nA, nB, best.data_ptr(), arg.data_ptr(),
                                     second.data_ptr(), device._stream()), "sfm_match_row_summary")
+    return best.cpu().numpy(), arg.cpu().numpy().astype(np.int64), second.cpu().numpy()
+
+
+def match_summary(metric: int, image_a, image_b, feats_a, feats_b, window_size: int):
+    """heap[0] score / b index and heap[1] score per A-feature straight from the images, without materialising
+    the score matrix (``sfm_match_summary``); bit-identical to ``row_summary(score_matrix(...))``."""
+    (pa, qa, oka, nA), (pb, qb, okb, nB), K = _extract_patches(metric, image_a, image_b, feats_a, feats_b, window_size)
+    lib = _native.load()
+    dev = pa.device
+    best = torch.empty((nA,), dtype=F64, device=dev)
+    arg = torch.empty((nA,), dtype=torch.int32, device=dev)
+    second = torch.empty((nA,), dtype=F64, device=dev)
+    if nA and nB:
+        ws_bytes = int(lib.sfm_match_summary_workspace_bytes(nA, nB))
+        ws = torch.empty((ws_bytes // 8,), dtype=F64, device=dev)
+        check(lib.sfm_match_summary(metric, pa.data_ptr(), pa.shape[1], pb.data_ptr(), pb.shape[1], qa.data_ptr(),
+                                    qb.data_ptr(), oka.data_ptr(), okb.data_ptr(), nA, nB, K, ws.data_ptr(), ws_bytes,
+                                    best.data_ptr(), arg.data_ptr(), second.data_ptr(), device._stream()),
+              "sfm_match_summary")
     return best.cpu().numpy(), arg.cpu().numpy().astype(np.int64), second.cpu().numpy()

@@ -170,8 +170,7 @@ def _device_rows(spec, features_a, features_b):
     from . import _device_match
 
     metric, image_a, image_b, window_size = spec
-    scores = _device_match.score_matrix(metric, image_a, image_b, features_a, features_b, window_size)
-    return _device_match.row_summary(scores)
+    return _device_match.match_summary(metric, image_a, image_b, features_a, features_b, window_size)
 
 
 def _host_rows(features_a, features_b, score_function):

@@ -104,9 +104,11 @@ def test_reference_unit_vectors(golden):
         ncc.calculate_ncc(a, b[:, :5], Feature(1, 1), Feature(2, 2))
 
 
-@pytest.mark.parametrize("nA,nB,ws", [(1, 1, 3), (65, 64, 3), (130, 257, 9), (600, 600, 9), (1000, 1300, 7)])
+@pytest.mark.parametrize("nA,nB,ws", [(1, 1, 3), (65, 64, 3), (129, 128, 5), (130, 257, 9), (600, 600, 9),
+                                      (1000, 1300, 7)])
 def test_large_random_vs_oracle(nA, nB, ws):
-    """Sizes around and beyond the 64x64 tile; every score, heap summary and match list against the oracle."""
+    """Sizes around and beyond the 128x128 tile; every score, heap summary (from the matrix and from the fused
+    tile-summary path) and match list against the oracle."""
     rng = np.random.default_rng(nA * 7 + nB)
     H, W = 120, 160
     ia = rng.integers(0, 256, (H, W)).astype(np.uint8)
@@ -124,7 +126,85 @@ def test_large_random_vs_oracle(nA, nB, ws):
     np.testing.assert_array_equal(arg, a_o)
     if nB > 1:
         np.testing.assert_array_equal(second, s_o)
+    best_f, arg_f, second_f = _device_match.match_summary(0, ia, ib, feats(fa), feats(fb), ws)
+    np.testing.assert_array_equal(best_f, b_o)
+    np.testing.assert_array_equal(arg_f, a_o)
+    if nB > 1:
+        np.testing.assert_array_equal(second_f, s_o)
     score = matching.ImagePairScore(ia, ib, ncc.calculate_ncc, ws)
     for name, (strat, ostrat) in COMBOS.items():
         ms = matching.match_brute_force(feats(fa), feats(fb), score, validation_strategies=strat, ratio_test_threshold=0.7)
         assert [(m.a_index, m.b_index, m.match_score) for m in ms] == mo.match_brute_force(want, ostrat, 0.7)
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_fused_summary_equals_matrix_path_with_ties_and_nonfinite(metric):
+    """The tile-summary path against the full-matrix path where the scan is delicate: long runs of equal scores
+    (flat images: every NCC is 2.0), +inf scores (SSD out of bounds), NaN / inf pixels, rows longer than many
+    tiles, one-column and two-column rows."""
+    rng = np.random.default_rng(11)
+    H, W = 60, 90
+    images = []
+    base = rng.integers(0, 4, (H, W)).astype(np.float64)  # few grey levels: many exact ties
+    images.append((base, np.roll(base, 1, axis=1)))
+    flat = np.full((H, W), 7.0)
+    images.append((flat, flat))
+    bad = rng.normal(size=(H, W))
+    bad[10:14, 20:24] = np.nan
+    bad[30:33, 50:52] = np.inf
+    images.append((bad, np.roll(bad, (2, 1), axis=(0, 1))))
+    for ia, ib in images:
+        for nA, nB in [(3, 1), (5, 2), (70, 129), (40, 1000)]:
+            fa = np.column_stack([rng.integers(-1, W + 1, nA), rng.integers(-1, H + 1, nA)]).astype(np.float64)
+            fb = np.column_stack([rng.integers(-1, W + 1, nB), rng.integers(-1, H + 1, nB)]).astype(np.float64)
+            sc = _device_match.score_matrix(metric, ia, ib, feats(fa), feats(fb), 5)
+            want = _device_match.row_summary(sc)
+            got = _device_match.match_summary(metric, ia, ib, feats(fa), feats(fb), 5)
+            for g, w in zip(got, want):
+                np.testing.assert_array_equal(g, w)
+            lit = [mo.heap_top_two(row) for row in sc.cpu().numpy()]  # the literal heapq of the reference
+            finite_rows = [i for i, row in enumerate(sc.cpu().numpy()) if not np.isnan(row).any()]
+            for i in finite_rows:
+                assert got[0][i] == lit[i][0] and got[1][i] == lit[i][1]
+                if nB > 1:
+                    assert got[2][i] == lit[i][2]
+
+
+def test_unpadded_patch_layout_takes_the_fallback_staging():
+    """The C ABI accepts any stride >= n; only 128-padded, 16-byte aligned rows take the LDS-DMA staging path.
+    Same patches in a tight odd-stride layout (and at an 8-byte-offset base) must give identical scores and
+    summaries."""
+    from structure_from_motion_amd import _native, device
+
+    lib = _native.load()
+    rng = np.random.default_rng(5)
+    H, W, ws = 80, 100, 5
+    ia = rng.integers(0, 256, (H, W)).astype(np.float64)
+    ib = np.roll(ia, (1, 1), axis=(0, 1))
+    nA, nB = 131, 203
+    fa = np.column_stack([rng.integers(0, W, nA), rng.integers(0, H, nA)]).astype(np.float64)
+    fb = np.column_stack([rng.integers(0, W, nB), rng.integers(0, H, nB)]).astype(np.float64)
+    (pa, qa, oka, _), (pb, qb, okb, _), K = _device_match._extract_patches(0, ia, ib, feats(fa), feats(fb), ws)
+    want = _device_match.score_matrix(0, ia, ib, feats(fa), feats(fb), ws)
+    want_sum = _device_match.match_summary(0, ia, ib, feats(fa), feats(fb), ws)
+    st = device._stream()
+    for offset in (0, 1):  # offset 1: rows start 8 bytes off a 16-byte boundary
+        ta = torch.empty(K * nA + offset, dtype=torch.float64, device="cuda")[offset:].view(K, nA)
+        tb = torch.empty(K * nB + offset, dtype=torch.float64, device="cuda")[offset:].view(K, nB)
+        ta.copy_(pa[:, :nA])
+        tb.copy_(pb[:, :nB])
+        scores = torch.empty((nA, nB), dtype=torch.float64, device="cuda")
+        _native.check(lib.sfm_pair_scores(0, ta.data_ptr(), nA, tb.data_ptr(), nB, qa.data_ptr(), qb.data_ptr(),
+                                          oka.data_ptr(), okb.data_ptr(), nA, nB, K, scores.data_ptr(), st), "scores")
+        np.testing.assert_array_equal(scores.cpu().numpy(), want.cpu().numpy())
+        nbytes = int(lib.sfm_match_summary_workspace_bytes(nA, nB))
+        wsp = torch.empty(nbytes // 8, dtype=torch.float64, device="cuda")
+        best = torch.empty(nA, dtype=torch.float64, device="cuda")
+        arg = torch.empty(nA, dtype=torch.int32, device="cuda")
+        second = torch.empty(nA, dtype=torch.float64, device="cuda")
+        _native.check(lib.sfm_match_summary(0, ta.data_ptr(), nA, tb.data_ptr(), nB, qa.data_ptr(), qb.data_ptr(),
+                                            oka.data_ptr(), okb.data_ptr(), nA, nB, K, wsp.data_ptr(), nbytes,
+                                            best.data_ptr(), arg.data_ptr(), second.data_ptr(), st), "summary")
+        np.testing.assert_array_equal(best.cpu().numpy(), want_sum[0])
+        np.testing.assert_array_equal(arg.cpu().numpy(), want_sum[1])
+        np.testing.assert_array_equal(second.cpu().numpy(), want_sum[2])

@@ -161,10 +161,10 @@ def test_score_nan_and_inf_models_never_win(dev):
         assert res.best_h == best_o and res.best_h not in (2, 5, 6)
 
 
+@pytest.mark.parametrize("h", [5000, 70000])  # one-launch block kernel (<= 32768) / multi-block atomics path
 @pytest.mark.parametrize("method", [orc.SUM, orc.SQUARE, orc.MEAN, orc.RMS])
-def test_select_matches_oracle(dev, method):
+def test_select_matches_oracle(dev, method, h):
     rng = np.random.default_rng(5)
-    h = 5000
     cnt = rng.integers(0, 40, h).astype(np.int32)
     s1 = rng.random(h)
     s2 = rng.random(h)
@@ -192,6 +192,35 @@ def test_select_matches_oracle(dev, method):
         dev.to_device(cnt, torch.int32).reshape(1, h), dev.to_device(s1).reshape(1, h),
         dev.to_device(s2).reshape(1, h), dev.to_device(flags, torch.int32).reshape(1, h), 0, code))[0]
     assert res.n_flagged == 2 and res.first_flagged == 17
+
+
+@pytest.mark.parametrize("h", [1, 63, 1025, 33000])
+def test_select_batched_matches_oracle(dev, h):
+    """Several independent pairs in one launch (both select paths), including a pair with nothing gated, a pair
+    whose minimum is shared by the first and the last hypothesis, and flags."""
+    rng = np.random.default_rng(h)
+    B = 4
+    cnt = rng.integers(0, 30, (B, h)).astype(np.int32)
+    s1, s2 = rng.random((B, h)), rng.random((B, h))
+    cnt[1] = 0                      # pair 1: gate (>= 5) never met
+    s2[2, 0] = s2[2, -1] = 1e-12    # pair 2: tie between first and last -> first
+    cnt[2, 0] = cnt[2, -1] = 29
+    flags = np.zeros((B, h), dtype=np.int32)
+    flags[3, h // 2] = 1            # pair 3: one flagged hypothesis never competes
+    s2[3, h // 2], cnt[3, h // 2] = 0.0, 29
+    res = dev.read_select(dev.select_best(dev.to_device(cnt, torch.int32), dev.to_device(s1), dev.to_device(s2),
+                                          dev.to_device(flags, torch.int32), 5, 3, h_offset=7))
+    for b in range(B):
+        err = orc.aggregate(cnt[b], s1[b], s2[b], orc.RMS)
+        err[flags[b] != 0] = np.inf
+        best, best_err = orc.select_best(err, cnt[b], 5)
+        if best < 0:
+            assert res[b].best_h == -1 and res[b].best_err == np.inf and res[b].best_cnt == 0
+        else:
+            assert (res[b].best_h, res[b].best_err, res[b].best_cnt) == (best + 7, best_err, cnt[b, best])
+        assert res[b].n_flagged == int(flags[b].sum())
+        if flags[b].any():
+            assert res[b].first_flagged == int(np.nonzero(flags[b])[0][0]) + 7
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -425,11 +454,11 @@ def test_virtual_shards_equal_single_run(dev):
     np.testing.assert_array_equal(np.nonzero(want[4])[0], np.sort(ref["inliers"]))
 
 
-@pytest.mark.parametrize("n,h", [(300, 2000), (6000, 12000)])
+@pytest.mark.parametrize("n,h", [(300, 2000), (9000, 12000)])
 def test_graph_replay_equals_eager(dev, n, h):
     """A captured HIP graph of the whole pass, replayed with the seed rewritten in device memory, gives the
     same winner / E / sample / mask as the eager launch sequence — and as the oracle (both launch paths of
-    the scoring kernel: plain order at 300 x 2000, longest-first ordering at 6000 x 12000)."""
+    the scoring kernel: plain order at 300 x 2000, longest-first ordering at 9000 x 12000)."""
     from structure_from_motion_amd import distributed
     from structure_from_motion_amd._native import AGG_RMS
 

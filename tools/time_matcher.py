@@ -16,18 +16,23 @@ for nA, nB in [(600, 600), (20000, 20000)]:
     fa = np.column_stack([rng.integers(0, W, nA), rng.integers(0, H, nA)]).astype(np.float64)
     fb = np.column_stack([rng.integers(0, W, nB), rng.integers(0, H, nB)]).astype(np.float64)
     fa_t, fb_t = dev.to_device(fa), dev.to_device(fb)
-    def run():
+    def run_matrix():  # |A| x |B| scores to HBM, then the row scan over them
         sc = _device_match.score_matrix(0, ia, ib, fa_t, fb_t, ws)
         return _device_match.row_summary(sc)
-    run(); torch.cuda.synchronize()
+    def run():         # product path: fused tile summaries, no score matrix
+        return _device_match.match_summary(0, ia, ib, fa_t, fb_t, ws)
     reps = 5
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        run()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
+    timings = {}
+    for name, fn in (("matrix", run_matrix), ("fused", run)):
+        fn(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        timings[name] = (time.perf_counter() - t0) / reps
+    dt = timings["fused"]
     K = ws * ws
-    rec = dict(nA=nA, nB=nB, window=ws, ms=dt * 1e3, pairs_per_s=nA * nB / dt,
+    rec = dict(nA=nA, nB=nB, window=ws, ms=dt * 1e3, ms_matrix_path=timings["matrix"] * 1e3, pairs_per_s=nA * nB / dt,
                fp64_gflops=nA * nB * 2 * K / dt / 1e9, frac_of_fp64_valu_peak=nA * nB * 2 * K / dt / 78.6e12)
     # CPU oracle on a bounded sample of rows
     rows = min(nA, 300)
