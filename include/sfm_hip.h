@@ -249,6 +249,13 @@ int sfm_nms_round(const double* image, uint8_t* state, int64_t height, int64_t w
                   void* stream);
 int sfm_nms_finalize(double* image, const uint8_t* state, int64_t height, int64_t width, void* stream);
 
+/* (flat index, value) of every non-zero (or NaN) element of `image` [count], in no particular order: what the top-k
+ * selection of harris_detector.py:32-42 needs from the suppressed cornerness image.  counter: dev int32 [1], receives
+ * the number found (may exceed `capacity`; only the first `capacity` slots are written); index: dev int32 [capacity];
+ * value: dev f64 [capacity]. */
+int sfm_compact_nonzero(const double* image, int64_t count, int32_t capacity, int32_t* counter, int32_t* index,
+                        double* value, void* stream);
+
 /* HOST: exact replay of CPython's random.shuffle as used by ransac.py:59-64.  `mt_state` is the 624-word
  * MT19937 state and `*mt_index` its position (random.getstate()[1]); both are advanced.  The cumulative
  * permutation of range(n) is shuffled `iterations` times; S_out[it,:] receives its first 8 entries.  If

@@ -66,6 +66,7 @@ SIGNATURES = {
     "sfm_nms_inplace": [_P, _I64, _I64, _P],
     "sfm_nms_round": [_P, _P, _I64, _I64, _P, _P],
     "sfm_nms_finalize": [_P, _P, _I64, _I64, _P],
+    "sfm_compact_nonzero": [_P, _I64, C.c_int32, _P, _P, _P, _P],
     "sfm_pyshuffle_table": [_P, _P, _I64, _I64, _P, _P, _I64, _P],
 }
 OTHER_SYMBOLS = ["sfm_last_error", "sfm_abi_version", "sfm_score_workspace_bytes", "sfm_fit_trace_doubles",

@@ -133,6 +133,35 @@ __global__ void nms_finalize_kernel(double* __restrict__ image, const uint8_t* _
     if (i < count && state[i] != 1) image[i] = 0.0;
 }
 
+__global__ void zero_counter_kernel(int32_t* counter) { *counter = 0; }
+
+// Compaction of the suppressed cornerness image: (flat index, value) of every non-zero pixel, in no particular
+// order (one atomic per wave reserves the slots).  After suppression a few thousand of ~300 k pixels survive; only
+// they need to reach the host for the top-k selection of harris_detector.py:32-42.
+__global__ __launch_bounds__(256) void compact_nonzero_kernel(const double* __restrict__ image, int64_t count,
+                                                              int32_t capacity, int32_t* __restrict__ counter,
+                                                              int32_t* __restrict__ index,
+                                                              double* __restrict__ value) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    // whole waves iterate together (the ballot needs every lane): the bound is rounded up to the wave
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x - lane); base < count; base += stride) {
+        const int64_t i = base + lane;
+        const double v = i < count ? image[i] : 0.0;
+        const bool keep = v != 0.0;  // NaN != 0 is true: kept, as `cornerness != 0` keeps it in the reference
+        const unsigned long long votes = __ballot(keep);
+        if (votes == 0ull) continue;
+        int start = 0;
+        if (lane == 0) start = atomicAdd(counter, (int)__popcll(votes));
+        start = __shfl(start, 0, kWave);
+        const int slot = start + __builtin_amdgcn_mbcnt_hi((unsigned)(votes >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)votes, 0));
+        if (keep && slot < capacity) {
+            index[slot] = (int32_t)i;
+            value[slot] = v;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -187,6 +216,20 @@ int sfm_nms_finalize(double* image, const uint8_t* state, int64_t height, int64_
     hipLaunchKernelGGL(nms_finalize_kernel, dim3(grid_for(height * width, 256)), dim3(256), 0, (hipStream_t)stream,
                        image, state, height * width);
     return check_launch("nms_finalize_kernel");
+}
+
+int sfm_compact_nonzero(const double* image, int64_t count, int32_t capacity, int32_t* counter, int32_t* index,
+                        double* value, void* stream) {
+    if (count < 0 || capacity < 0) return fail(SFM_EINVAL, "sfm_compact_nonzero: negative size");
+    if (count > 0x7FFFFFFF) return fail(SFM_EINVAL, "sfm_compact_nonzero: image too large for int32 indices");
+    if (!counter || (count > 0 && !image) || (capacity > 0 && (!index || !value)))
+        return fail(SFM_EINVAL, "sfm_compact_nonzero: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(zero_counter_kernel, dim3(1), dim3(1), 0, st, counter);
+    if (count > 0)
+        hipLaunchKernelGGL(compact_nonzero_kernel, dim3(grid_for(count, 256, 1024)), dim3(256), 0, st, image, count,
+                           capacity, counter, index, value);
+    return check_launch("compact_nonzero_kernel");
 }
 
 }  // extern "C"

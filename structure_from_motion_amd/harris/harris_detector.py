@@ -27,9 +27,9 @@ def detect_harris_corners(
     at the centre of their ``block_size`` block.  Fewer are returned if fewer non-zero maxima exist."""
     if num_corners <= 0:
         raise ValueError("num_corners needs to be at least 1")
-    suppressed = _suppressed_cornerness(image, block_size, k).cpu().numpy()
-    order = _strongest_indices(suppressed, num_corners)
-    y_indices, x_indices = np.unravel_index(order, suppressed.shape)
+    suppressed = _suppressed_cornerness(image, block_size, k)
+    order = _strongest_indices_device(suppressed, num_corners)
+    y_indices, x_indices = np.unravel_index(order, tuple(suppressed.shape))
     ys = y_indices.astype(float) + float(block_size) / 2.0
     xs = x_indices.astype(float) + float(block_size) / 2.0
     return [feature.Feature(x=x, y=y) for y, x in zip(ys, xs)]
@@ -53,6 +53,44 @@ def _strongest_indices(suppressed: np.ndarray, num_corners: int) -> np.ndarray:
         order = np.flip(np.argsort(suppressed, axis=None))[:num_corners]
         return np.array([i for i in order if flat[i] != 0], dtype=np.int64)
     return nonzero[by_value[:keep]].astype(np.int64)
+
+
+_COMPACT_CAPACITY = 1 << 16
+
+
+def _strongest_indices_device(suppressed: torch.Tensor, num_corners: int) -> np.ndarray:
+    """``_strongest_indices`` without copying the image back: the few non-zero pixels are compacted on the device
+    (``sfm_compact_nonzero``) and only they travel.  Falls back to the full image when exact ties among the values
+    that matter make the reference's order depend on NumPy's sort of the whole array, or when more than
+    ``_COMPACT_CAPACITY`` pixels survive."""
+    lib = _native.load()
+    count = suppressed.numel()
+    capacity = min(count, _COMPACT_CAPACITY)
+    dev = suppressed.device
+    counter = torch.empty((1,), dtype=torch.int32, device=dev)
+    index = torch.empty((max(capacity, 1),), dtype=torch.int32, device=dev)
+    value = torch.empty((max(capacity, 1),), dtype=torch.float64, device=dev)
+    check(lib.sfm_compact_nonzero(suppressed.data_ptr(), count, capacity, counter.data_ptr(), index.data_ptr(),
+                                  value.data_ptr(), device._stream()), "sfm_compact_nonzero")
+    found = int(counter.cpu()[0])
+    if found == 0:
+        return np.zeros(0, dtype=np.int64)
+    if found > capacity:
+        return _strongest_indices(suppressed.cpu().numpy(), num_corners)
+    nonzero = index[:found].cpu().numpy().astype(np.int64)  # slot order is arbitrary (atomics)
+    values = value[:found].cpu().numpy()
+    if bool(np.isnan(values).any()):
+        return _strongest_indices(suppressed.cpu().numpy(), num_corners)
+    # the keep + 1 largest, ordered by (value descending, flat index ascending) — what a stable sort of the
+    # raster-ordered non-zeros gives; a selection (O(n)) instead of a full sort, then a sort of those few
+    keep = min(num_corners, found)
+    m = min(keep + 1, found)
+    cand = np.argpartition(-values, m - 1)[:m] if m < found else np.arange(found)
+    order = cand[np.lexsort((nonzero[cand], -values[cand]))]
+    head = values[order]
+    if bool(np.any(head[1:] == head[:-1])):
+        return _strongest_indices(suppressed.cpu().numpy(), num_corners)
+    return nonzero[order[:keep]]
 
 
 def _image_tensor(image: np.ndarray) -> torch.Tensor:

@@ -112,3 +112,34 @@ def test_nms_fixpoint_equals_wavefront_and_oracle():
         t = device.to_device(img)
         check(lib.sfm_nms_inplace(t.data_ptr(), t.shape[0], t.shape[1], device._stream()), "sfm_nms_inplace")
         np.testing.assert_array_equal(t.cpu().numpy(), want)   # wavefront kernel on its own
+
+
+def test_compact_nonzero_and_topk_equal_full_image_path():
+    """The device compaction feeds the same top-k as the full-image NumPy selection: random sparse images, all-zero,
+    exact ties among the leaders (fallback), more survivors than the compaction buffer (fallback), NaN."""
+    from structure_from_motion_amd import device
+    from structure_from_motion_amd.harris import harris_detector as hd
+
+    rng = np.random.default_rng(3)
+    cases = []
+    sparse = np.zeros((97, 131))
+    hits = rng.choice(sparse.size, 900, replace=False)
+    sparse.ravel()[hits] = rng.random(900) + 0.1
+    cases.append(sparse)
+    cases.append(np.zeros((40, 50)))
+    tied = sparse.copy()
+    tied.ravel()[hits[:5]] = 9.0  # five equal leaders
+    cases.append(tied)
+    cases.append(rng.random((300, 400)) + 0.5)  # 120 000 non-zeros > capacity
+    withnan = sparse.copy()
+    withnan[3, 3] = np.nan
+    cases.append(withnan)
+    one = np.zeros((5, 7))
+    one[2, 3] = 4.0
+    cases.append(one)
+    for img in cases:
+        t = device.to_device(img)
+        for k in (1, 10, 600, 5000):
+            got = hd._strongest_indices_device(t, k)
+            want = hd._strongest_indices(img, k)
+            np.testing.assert_array_equal(got, want)
