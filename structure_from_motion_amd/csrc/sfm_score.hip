@@ -30,6 +30,9 @@
 //   The factor 1e-5 covers every rounding of the fp32 evaluation of both sides (< 30 u = 1.8e-6).
 //   NaN / inf / overflow / underflow anywhere make a comparison false (or the guard fail) and the
 //   pair goes to tier 2.  thr < 0 or NaN switches the filter off.
+//   The steady-state loop uses the ONE-SIDED form of this test (drop the 1/da term: s^2 > T dB), which needs
+//   neither la nor dA — filter_rejects_one_sided below; the two-sided form serves the ragged tail and the cost
+//   pre-pass, and SFM_SCORE_ONE_SIDED=0 restores it everywhere (ablation).
 //
 // Compiled with -ffp-contract=off; the fp32 tier spells its FMAs explicitly.
 #include <hip/hip_runtime.h>
@@ -255,6 +258,24 @@ SFM_DEVICE bool filter_rejects(const FilterConsts& f, float T, float xa, float y
     return (s > 0.0f) & (lhs > rhs) & (rhs > 1e-30f);
 }
 
+// The one-sided form of the same test: sed = r^2 / da + r^2 / db >= r^2 / db, so  s > 0  and  s^2 > T dB  (and
+// T dB > 1e-30) already proves sed_fl > thr — with the bound derivation above cut short after the db term.  It needs
+// neither la = E a nor dA: 16 VALU instructions instead of 27.  It is weaker: pairs with thr < sed <~ 2 thr (where
+// da ~ db, the usual case for an essential matrix) slip through to tier 2 — about 40 % more tier-2 work, still a
+// net gain (3.33 -> 3.17 ms on 50k x 100k).  Choosing per hypothesis between the db and the da form (sed is
+// symmetric under E -> E^T, a <-> b) would guard against lopsided matrices, but the second code path costs a wave
+// of occupancy (109 VGPRs, SGPR spills) — more than the filter saves; a lopsided E only makes tier 1 weaker, never wrong.
+SFM_DEVICE bool filter_rejects_one_sided(const FilterConsts& f, float T, float xa, float ya, float xb, float yb) {
+    const float lb0 = fmaf(xb, f.e[0], fmaf(yb, f.e[3], f.e[6]));
+    const float lb1 = fmaf(xb, f.e[1], fmaf(yb, f.e[4], f.e[7]));
+    const float lb2 = fmaf(xb, f.e[2], fmaf(yb, f.e[5], f.e[8]));
+    const float r = fmaf(lb0, xa, fmaf(lb1, ya, lb2));
+    const float s = fabsf(r) - f.delta;
+    const float dB = fmaf(lb0, lb0, fmaf(lb1, lb1, f.cb));
+    const float rhs = T * dB;
+    return (s > 0.0f) & (s * s > rhs) & (rhs > 1e-30f);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Load balancing.  A hypothesis that fits the scene keeps ~half of the points in tier 2 and costs several
 // times the average; with only a few generations of waves per launch, such waves starting late leave the chip
@@ -378,8 +399,8 @@ __global__ __launch_bounds__(256) void score_class_scatter_kernel(const int32_t*
 // ------------------------------------------------------------------------------------------------
 // Filtered kernel.
 // ------------------------------------------------------------------------------------------------
-template <int HPW>
-__global__ __launch_bounds__(256) void score_sed_filtered_kernel(
+template <int HPW, bool ONE_SIDED>
+__global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
     const Corr* __restrict__ corr, const unsigned char* __restrict__ ws, int n,
     const double* __restrict__ E, const int32_t* __restrict__ S, int h_count, double thr,
     const int32_t* __restrict__ order, int32_t* __restrict__ cnt, double* __restrict__ s1,
@@ -481,8 +502,10 @@ __global__ __launch_bounds__(256) void score_sed_filtered_kernel(
     auto process_pair = [&](const float4 p0, const float4 p1, int i0) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < HPW; ++k) {
-            const bool rej0 = filter_rejects(f[k], T, p0.x, p0.y, p0.z, p0.w);
-            const bool rej1 = filter_rejects(f[k], T, p1.x, p1.y, p1.z, p1.w);
+            const bool rej0 = ONE_SIDED ? filter_rejects_one_sided(f[k], T, p0.x, p0.y, p0.z, p0.w)
+                                        : filter_rejects(f[k], T, p0.x, p0.y, p0.z, p0.w);
+            const bool rej1 = ONE_SIDED ? filter_rejects_one_sided(f[k], T, p1.x, p1.y, p1.z, p1.w)
+                                        : filter_rejects(f[k], T, p1.x, p1.y, p1.z, p1.w);
             const unsigned long long m0 = ~__builtin_amdgcn_ballot_w64(rej0);
             const unsigned long long m1 = ~__builtin_amdgcn_ballot_w64(rej1);
             if ((m0 | m1) != 0ull) {  // wave-uniform
@@ -579,8 +602,14 @@ int launch_filtered(const FilteredLaunch& a) {
         if (rc != SFM_OK) return rc;
         order_arg = a.order;
     }
-    hipLaunchKernelGGL(score_sed_filtered_kernel<HPW>, grid, dim3(256), 0, a.st, a.corr, a.ws, a.n, a.E, a.S, a.h_count,
-                       a.thr, order_arg, a.cnt, a.s1, a.s2);
+    // SFM_SCORE_ONE_SIDED=0 switches tier 1 back to the two-sided test (ablation: 3.33 vs 3.17 ms on 50k x 100k)
+    static const bool one_sided = getenv("SFM_SCORE_ONE_SIDED") ? atoi(getenv("SFM_SCORE_ONE_SIDED")) != 0 : true;
+    if (one_sided)
+        hipLaunchKernelGGL((score_sed_filtered_kernel<HPW, true>), grid, dim3(256), 0, a.st, a.corr, a.ws, a.n, a.E, a.S,
+                           a.h_count, a.thr, order_arg, a.cnt, a.s1, a.s2);
+    else
+        hipLaunchKernelGGL((score_sed_filtered_kernel<HPW, false>), grid, dim3(256), 0, a.st, a.corr, a.ws, a.n, a.E, a.S,
+                           a.h_count, a.thr, order_arg, a.cnt, a.s1, a.s2);
     return check_launch("score_sed_filtered_kernel");
 }
 
