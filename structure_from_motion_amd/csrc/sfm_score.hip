@@ -276,6 +276,22 @@ SFM_DEVICE bool filter_rejects_one_sided(const FilterConsts& f, float T, float x
     return (s > 0.0f) & (s * s > rhs) & (rhs > 1e-30f);
 }
 
+// The same test as a wave mask (bit = lane rejects).  Each compare writes its lane mask straight to a scalar
+// register pair and the masks are combined with scalar ANDs; going through a per-lane bool and a ballot makes the
+// compiler materialise 0/1 in a VGPR and compare it again (2 extra VALU instructions per evaluation out of 18).
+SFM_DEVICE unsigned long long reject_mask_one_sided(const FilterConsts& f, float T, float xa, float ya, float xb,
+                                                    float yb) {
+    const float lb0 = fmaf(xb, f.e[0], fmaf(yb, f.e[3], f.e[6]));
+    const float lb1 = fmaf(xb, f.e[1], fmaf(yb, f.e[4], f.e[7]));
+    const float lb2 = fmaf(xb, f.e[2], fmaf(yb, f.e[5], f.e[8]));
+    const float r = fmaf(lb0, xa, fmaf(lb1, ya, lb2));
+    const float s = fabsf(r) - f.delta;
+    const float dB = fmaf(lb0, lb0, fmaf(lb1, lb1, f.cb));
+    const float rhs = T * dB;
+    return __builtin_amdgcn_ballot_w64(s > 0.0f) & __builtin_amdgcn_ballot_w64(s * s > rhs) &
+           __builtin_amdgcn_ballot_w64(rhs > 1e-30f);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Load balancing.  A hypothesis that fits the scene keeps ~half of the points in tier 2 and costs several
 // times the average; with only a few generations of waves per launch, such waves starting late leave the chip
@@ -502,15 +518,17 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
     auto process_pair = [&](const float4 p0, const float4 p1, int i0) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < HPW; ++k) {
-            const bool rej0 = ONE_SIDED ? filter_rejects_one_sided(f[k], T, p0.x, p0.y, p0.z, p0.w)
-                                        : filter_rejects(f[k], T, p0.x, p0.y, p0.z, p0.w);
-            const bool rej1 = ONE_SIDED ? filter_rejects_one_sided(f[k], T, p1.x, p1.y, p1.z, p1.w)
-                                        : filter_rejects(f[k], T, p1.x, p1.y, p1.z, p1.w);
-            const unsigned long long m0 = ~__builtin_amdgcn_ballot_w64(rej0);
-            const unsigned long long m1 = ~__builtin_amdgcn_ballot_w64(rej1);
+            unsigned long long m0, m1;  // survivors of the two chunks
+            if (ONE_SIDED) {
+                m0 = ~reject_mask_one_sided(f[k], T, p0.x, p0.y, p0.z, p0.w);
+                m1 = ~reject_mask_one_sided(f[k], T, p1.x, p1.y, p1.z, p1.w);
+            } else {
+                m0 = ~__builtin_amdgcn_ballot_w64(filter_rejects(f[k], T, p0.x, p0.y, p0.z, p0.w));
+                m1 = ~__builtin_amdgcn_ballot_w64(filter_rejects(f[k], T, p1.x, p1.y, p1.z, p1.w));
+            }
             if ((m0 | m1) != 0ull) {  // wave-uniform
-                push(k, m0, !rej0, i0);
-                push(k, m1, !rej1, i0 + kWave);
+                push(k, m0, ((m0 >> lane) & 1ull) != 0ull, i0);
+                push(k, m1, ((m1 >> lane) & 1ull) != 0ull, i0 + kWave);
                 __builtin_amdgcn_wave_barrier();
                 while (tail[k] - head[k] >= kWave) drain(k, kWave);  // wave-uniform, at most twice
             }
