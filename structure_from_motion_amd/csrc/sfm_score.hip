@@ -148,7 +148,10 @@ constexpr int kClasses = 12;                      // coarse cost classes: 10 - f
 constexpr int kClassStride = 16;                  // ints between class counters: one 64-byte line each
 constexpr int kBuckets = 16 * kClassStride;       // ints reserved per batch entry
 __host__ __device__ inline int64_t ws_points_offset(int64_t batch) { return 16 * batch; }
-__host__ __device__ inline int64_t ws_buckets_offset(int64_t n, int64_t batch) { return 16 * batch + 16 * n * batch; }
+constexpr int64_t kPointsPad = 4096;  // bytes after the fp32 points: the scoring loop prefetches up to 3 KiB past a pair's last point
+__host__ __device__ inline int64_t ws_buckets_offset(int64_t n, int64_t batch) {
+    return 16 * batch + 16 * n * batch + kPointsPad;
+}
 __host__ __device__ inline int64_t ws_order_offset(int64_t n, int64_t batch) {
     return ws_buckets_offset(n, batch) + ((4 * (int64_t)kBuckets * batch + 15) / 16) * 16;
 }
@@ -288,8 +291,9 @@ SFM_DEVICE unsigned long long reject_mask_one_sided(const FilterConsts& f, float
     const float s = fabsf(r) - f.delta;
     const float dB = fmaf(lb0, lb0, fmaf(lb1, lb1, f.cb));
     const float rhs = T * dB;
-    return __builtin_amdgcn_ballot_w64(s > 0.0f) & __builtin_amdgcn_ballot_w64(s * s > rhs) &
-           __builtin_amdgcn_ballot_w64(rhs > 1e-30f);
+    // s > 0 and s^2 > rhs in one compare: rhs >= 0 whenever it is not NaN, and s |s| > rhs >= 0 forces s > 0
+    // (the |s| is an operand modifier, free)
+    return __builtin_amdgcn_ballot_w64(s * fabsf(s) > rhs) & __builtin_amdgcn_ballot_w64(rhs > 1e-30f);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -505,11 +509,30 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
         head[k] += count;
     };
 
-    // Append the lanes flagged in `mask` (this lane: `mine`) to the ring of hypothesis k.
-    auto push = [&](int k, unsigned long long mask, bool mine, int i) __attribute__((always_inline)) {
-        const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                                     __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-        if (mine) ring[wave_in_block][k][(tail[k] + before) & (kRing - 1)] = i;
+    // Append the lanes flagged in `mask` to the ring of hypothesis k: lane l of the mask writes `i` to slot
+    // (tail + number of flagged lanes below l) mod kRing.  Hand-written: the mask itself becomes the exec mask for the
+    // five address instructions and the LDS write, so no per-lane predicate has to be rebuilt from it (the compiled
+    // form spends three more VALU instructions per push on that, ~9 % of the kernel's VALU issue; a push happens for
+    // most (chunk pair, hypothesis) combinations even when the hypothesis fits nothing).
+    static_assert(kRing == 256, "slot mask in the inline assembly");
+    auto push = [&](int k, unsigned long long mask, int i) __attribute__((always_inline)) {
+        const unsigned lo = (unsigned)mask, hi = (unsigned)(mask >> 32);
+        const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) int32_t*)&ring[wave_in_block][k][0];
+        unsigned scratch;
+        unsigned long long saved;
+        asm volatile(
+            "s_mov_b64 %[saved], exec\n\t"
+            "s_mov_b64 exec, %[mask]\n\t"
+            "v_mbcnt_lo_u32_b32 %[t], %[lo], 0\n\t"
+            "v_mbcnt_hi_u32_b32 %[t], %[hi], %[t]\n\t"
+            "v_add_u32 %[t], %[tail], %[t]\n\t"
+            "v_and_b32 %[t], 0xff, %[t]\n\t"
+            "v_lshl_add_u32 %[t], %[t], 2, %[base]\n\t"
+            "ds_write_b32 %[t], %[index]\n\t"
+            "s_mov_b64 exec, %[saved]"
+            : [t] "=&v"(scratch), [saved] "=&s"(saved)
+            : [mask] "s"(mask), [lo] "s"(lo), [hi] "s"(hi), [tail] "s"(tail[k]), [base] "s"(base), [index] "v"(i)
+            : "memory");
         tail[k] += (int)__popcll(mask);  // scalar arithmetic on a wave-uniform mask
     };
 
@@ -527,8 +550,8 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
                 m1 = ~__builtin_amdgcn_ballot_w64(filter_rejects(f[k], T, p1.x, p1.y, p1.z, p1.w));
             }
             if ((m0 | m1) != 0ull) {  // wave-uniform
-                push(k, m0, ((m0 >> lane) & 1ull) != 0ull, i0);
-                push(k, m1, ((m1 >> lane) & 1ull) != 0ull, i0 + kWave);
+                push(k, m0, i0);
+                push(k, m1, i0 + kWave);
                 __builtin_amdgcn_wave_barrier();
                 while (tail[k] - head[k] >= kWave) drain(k, kWave);  // wave-uniform, at most twice
             }
@@ -542,7 +565,7 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
             const bool pass = valid & !filter_rejects(f[k], T, p.x, p.y, p.z, p.w);
             const unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
             if (mask != 0ull) {
-                push(k, mask, pass, i);
+                push(k, mask, i);
                 __builtin_amdgcn_wave_barrier();
                 if (tail[k] - head[k] >= kWave) drain(k, kWave);
             }
@@ -552,15 +575,19 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
     const int full_chunks = n / kWave;
     const int pairs = full_chunks / 2;
     if (pairs > 0) {
-        float4 p0 = pts32[lane], p1 = pts32[kWave + lane];
+        const float4* __restrict__ next = pts32 + lane;  // per-lane cursor: one 64-bit add per step, no index clamping
+        float4 p0 = next[0], p1 = next[kWave];
+        int i0 = lane;
         for (int pr = 0; pr < pairs; ++pr) {
-            const int i0 = pr * (2 * kWave) + lane;
-            // prefetch the next pair (the last prefetch re-reads valid addresses)
-            const float4 q0 = pts32[min(i0 + 2 * kWave, n - 1)];
-            const float4 q1 = pts32[min(i0 + 3 * kWave, n - 1)];
+            // prefetch the next pair; the last step reads up to 3 KiB past the pair's points, inside the workspace
+            // (the next pair's points, or the kPointsPad bytes behind the last pair's) and never uses them
+            next += 2 * kWave;
+            const float4 q0 = next[0];
+            const float4 q1 = next[kWave];
             process_pair(p0, p1, i0);
             p0 = q0;
             p1 = q1;
+            i0 += 2 * kWave;
         }
     }
     for (int chunk = pairs * 2; chunk * kWave < n; ++chunk) {  // at most two iterations
