@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
     const double* __restrict__ E, const int32_t* __restrict__ S, int h_count, double thr,
     const int32_t* __restrict__ order, int32_t* __restrict__ cnt, double* __restrict__ s1,
     double* __restrict__ s2) {
-    __shared__ int32_t ring[256 / kWave][HPW][kRing];
+    __shared__ __attribute__((aligned(1024))) int32_t ring[256 / kWave][HPW][kRing];  // each ring = one aligned KiB
     const int lane = threadIdx.x & (kWave - 1);
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     const int wave = blockIdx.x * (256 / kWave) + wave_in_block;
@@ -511,27 +511,33 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
 
     // Append the lanes flagged in `mask` to the ring of hypothesis k: lane l of the mask writes `i` to slot
     // (tail + number of flagged lanes below l) mod kRing.  Hand-written: the mask itself becomes the exec mask for the
-    // five address instructions and the LDS write, so no per-lane predicate has to be rebuilt from it (the compiled
+    // four address instructions and the LDS write, so no per-lane predicate has to be rebuilt from it (the compiled
     // form spends three more VALU instructions per push on that, ~9 % of the kernel's VALU issue; a push happens for
     // most (chunk pair, hypothesis) combinations even when the hypothesis fits nothing).
     static_assert(kRing == 256, "slot mask in the inline assembly");
+    unsigned ring_base[HPW];  // LDS byte address of each hypothesis' ring (wave-uniform, kept in a VGPR: the
+                              // and-or below already spends its one scalar operand on the wrap mask)
+#pragma unroll
+    for (int k = 0; k < HPW; ++k)
+        ring_base[k] = (unsigned)(size_t)(__attribute__((address_space(3))) int32_t*)&ring[wave_in_block][k][0];
     auto push = [&](int k, unsigned long long mask, int i) __attribute__((always_inline)) {
         const unsigned lo = (unsigned)mask, hi = (unsigned)(mask >> 32);
-        const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) int32_t*)&ring[wave_in_block][k][0];
+        const unsigned tail4 = (unsigned)tail[k] << 2;  // scalar
         unsigned scratch;
         unsigned long long saved;
+        // slot byte address = ring base | ((4 tail + 4 rank) & 0x3fc): the ring is 1 KiB-aligned, so OR is ADD
         asm volatile(
             "s_mov_b64 %[saved], exec\n\t"
             "s_mov_b64 exec, %[mask]\n\t"
             "v_mbcnt_lo_u32_b32 %[t], %[lo], 0\n\t"
             "v_mbcnt_hi_u32_b32 %[t], %[hi], %[t]\n\t"
-            "v_add_u32 %[t], %[tail], %[t]\n\t"
-            "v_and_b32 %[t], 0xff, %[t]\n\t"
-            "v_lshl_add_u32 %[t], %[t], 2, %[base]\n\t"
+            "v_lshl_add_u32 %[t], %[t], 2, %[tail4]\n\t"
+            "v_and_or_b32 %[t], %[t], %[wrap], %[base]\n\t"
             "ds_write_b32 %[t], %[index]\n\t"
             "s_mov_b64 exec, %[saved]"
             : [t] "=&v"(scratch), [saved] "=&s"(saved)
-            : [mask] "s"(mask), [lo] "s"(lo), [hi] "s"(hi), [tail] "s"(tail[k]), [base] "s"(base), [index] "v"(i)
+            : [mask] "s"(mask), [lo] "s"(lo), [hi] "s"(hi), [tail4] "s"(tail4), [wrap] "s"(0x3fcu),
+              [base] "v"(ring_base[k]), [index] "v"(i)
             : "memory");
         tail[k] += (int)__popcll(mask);  // scalar arithmetic on a wave-uniform mask
     };
