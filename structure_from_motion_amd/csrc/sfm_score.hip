@@ -292,8 +292,15 @@ SFM_DEVICE unsigned long long reject_mask_one_sided(const FilterConsts& f, float
     const float dB = fmaf(lb0, lb0, fmaf(lb1, lb1, f.cb));
     const float rhs = T * dB;
     // s > 0 and s^2 > rhs in one compare: rhs >= 0 whenever it is not NaN, and s |s| > rhs >= 0 forces s > 0
-    // (the |s| is an operand modifier, free)
-    return __builtin_amdgcn_ballot_w64(s * fabsf(s) > rhs) & __builtin_amdgcn_ballot_w64(rhs > 1e-30f);
+    // (the |s| is an operand modifier, free).  The underflow guard of the compiled-in form above is hoisted out of the
+    // loop: dB >= cb and rounding is monotone, so rhs >= fl(T cb), and the caller (arm_one_sided) has checked
+    // fl(T cb) > 1e-36 for this hypothesis or switched its filter off (delta = +inf: s = -inf, never rejects).
+    return __builtin_amdgcn_ballot_w64(s * fabsf(s) > rhs);
+}
+
+// Per-hypothesis precondition of reject_mask_one_sided (see there).  NaN fails the comparison and disarms too.
+SFM_DEVICE void arm_one_sided(FilterConsts& f, float T) {
+    if (!(T * f.cb > 1e-36f)) f.delta = INFINITY;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -469,6 +476,7 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
 #pragma unroll
         for (int j = 0; j < 9; ++j) e[j] = Eb[(int64_t)h * 9 + j];
         f[k] = make_filter_consts(e, Xa, Ya, Xb, Yb);
+        if (ONE_SIDED) arm_one_sided(f[k], T);
         // The four multiplier entries go to scalar registers (a VALU instruction takes ONE scalar operand
         // for free); the five addend entries e2, e5, e6, e7, e8 and delta / eta stay in VGPRs as
         // wave-uniform values: an FMA whose multiplier and addend were both scalar would need an extra
