@@ -31,8 +31,9 @@
 //   NaN / inf / overflow / underflow anywhere make a comparison false (or the guard fail) and the
 //   pair goes to tier 2.  thr < 0 or NaN switches the filter off.
 //   The steady-state loop uses the ONE-SIDED form of this test (drop the 1/da term: s^2 > T dB), which needs
-//   neither la nor dA — filter_rejects_one_sided below; the two-sided form serves the ragged tail and the cost
-//   pre-pass, and SFM_SCORE_ONE_SIDED=0 restores it everywhere (ablation).
+//   neither la nor dA — reject_mask_one_sided below, which also folds T into the prepared coordinates and hoists the
+//   underflow guard out of the loop (14 VALU per evaluation); SFM_SCORE_ONE_SIDED=0 restores the two-sided test
+//   everywhere (ablation).
 //
 // Compiled with -ffp-contract=off; the fp32 tier spells its FMAs explicitly.
 #include <hip/hip_runtime.h>
@@ -169,7 +170,8 @@ __global__ __launch_bounds__(256) void score_reset_kernel(unsigned char* __restr
     if (threadIdx.x < 4) reinterpret_cast<uint32_t*>(ws + 16 * b)[threadIdx.x] = 0u;
 }
 
-__global__ void score_prepare_kernel(const Corr* __restrict__ corr, int64_t n, unsigned char* __restrict__ ws) {
+__global__ void score_prepare_kernel(const Corr* __restrict__ corr, int64_t n, double a_scale,
+                                     unsigned char* __restrict__ ws) {
     const int64_t b = blockIdx.y;
     const int64_t batch = gridDim.y;
     const Corr* pts = corr + b * n;
@@ -179,7 +181,8 @@ __global__ void score_prepare_kernel(const Corr* __restrict__ corr, int64_t n, u
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const Corr p = pts[i];
-        const float4 q = make_float4((float)p.xa, (float)p.ya, (float)p.xb, (float)p.yb);
+        // a_scale: 1 for the two-sided test; c ~ 1/sqrt(T) for the one-sided one (see reject_mask_one_sided)
+        const float4 q = make_float4((float)(p.xa * a_scale), (float)(p.ya * a_scale), (float)p.xb, (float)p.yb);
         out[i] = q;
         // NaN coordinates: fmaxf ignores them; such points always fail the filter's comparisons and are
         // decided by the exact tier.
@@ -216,19 +219,25 @@ struct FilterConsts {
     float ca, cb;      // additive slack of the dA / dB upper bounds (see the bound above)
 };
 
-SFM_DEVICE FilterConsts make_filter_consts(const double (&E)[9], float Xa, float Ya, float Xb, float Yb) {
+// `a_scale` is the factor the prepared a-side coordinates carry (Xa, Ya are maxima of the scaled values): the third
+// homogeneous coordinate of a is a_scale instead of 1, i.e. the entries E_j2 that multiply it are scaled here.
+SFM_DEVICE FilterConsts make_filter_consts(const double (&E)[9], float Xa, float Ya, float Xb, float Yb,
+                                           double a_scale = 1.0) {
     constexpr float u = 5.9604644775390625e-08f;  // 2^-24
     constexpr float up = 1.0f + 1e-5f;            // absorbs the roundings of these bound computations
     FilterConsts f;
     float emax = 0.f;
+    float poison = 0.0f;
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
-        f.e[j] = (float)E[j];
-        emax = fmaxf(emax, fabsf(f.e[j]));
+        const float ej = (float)E[j];
+        emax = fmaxf(emax, fabsf(ej));
+        // NaN anywhere in E must poison the bounds (fmaxf would drop it): add the entries' NaN-ness back.
+        poison += ej * 0.0f;
+        f.e[j] = (j % 3 == 2) ? (float)(E[j] * a_scale) : ej;
     }
-    // NaN anywhere in E must poison the bounds (fmaxf would drop it): add the entries' NaN-ness back.
-    const float poison = (f.e[0] + f.e[1] + f.e[2] + f.e[3] + f.e[4] + f.e[5] + f.e[6] + f.e[7] + f.e[8]) * 0.0f;
-    const float M = (Xa + Ya + 1.0f) * (Xb + Yb + 1.0f);
+    const float w = (float)a_scale * (1.0f + 1e-6f);  // >= the third coordinate of the scaled a
+    const float M = (Xa + Ya + w) * (Xb + Yb + 1.0f);
     f.delta = (10.0f * u) * emax * M * up + poison;
     const float a0 = fabsf(f.e[0]) * Xa + fabsf(f.e[1]) * Ya + fabsf(f.e[2]);
     const float a1 = fabsf(f.e[3]) * Xa + fabsf(f.e[4]) * Ya + fabsf(f.e[5]);
@@ -261,46 +270,45 @@ SFM_DEVICE bool filter_rejects(const FilterConsts& f, float T, float xa, float y
     return (s > 0.0f) & (lhs > rhs) & (rhs > 1e-30f);
 }
 
-// The one-sided form of the same test: sed = r^2 / da + r^2 / db >= r^2 / db, so  s > 0  and  s^2 > T dB  (and
-// T dB > 1e-30) already proves sed_fl > thr — with the bound derivation above cut short after the db term.  It needs
-// neither la = E a nor dA: 16 VALU instructions instead of 27.  It is weaker: pairs with thr < sed <~ 2 thr (where
-// da ~ db, the usual case for an essential matrix) slip through to tier 2 — about 40 % more tier-2 work, still a
-// net gain (3.33 -> 3.17 ms on 50k x 100k).  Choosing per hypothesis between the db and the da form (sed is
-// symmetric under E -> E^T, a <-> b) would guard against lopsided matrices, but the second code path costs a wave
-// of occupancy (109 VGPRs, SGPR spills) — more than the filter saves; a lopsided E only makes tier 1 weaker, never wrong.
-SFM_DEVICE bool filter_rejects_one_sided(const FilterConsts& f, float T, float xa, float ya, float xb, float yb) {
-    const float lb0 = fmaf(xb, f.e[0], fmaf(yb, f.e[3], f.e[6]));
-    const float lb1 = fmaf(xb, f.e[1], fmaf(yb, f.e[4], f.e[7]));
-    const float lb2 = fmaf(xb, f.e[2], fmaf(yb, f.e[5], f.e[8]));
-    const float r = fmaf(lb0, xa, fmaf(lb1, ya, lb2));
-    const float s = fabsf(r) - f.delta;
-    const float dB = fmaf(lb0, lb0, fmaf(lb1, lb1, f.cb));
-    const float rhs = T * dB;
-    return (s > 0.0f) & (s * s > rhs) & (rhs > 1e-30f);
-}
-
-// The same test as a wave mask (bit = lane rejects).  Each compare writes its lane mask straight to a scalar
-// register pair and the masks are combined with scalar ANDs; going through a per-lane bool and a ballot makes the
-// compiler materialise 0/1 in a VGPR and compare it again (2 extra VALU instructions per evaluation out of 18).
-SFM_DEVICE unsigned long long reject_mask_one_sided(const FilterConsts& f, float T, float xa, float ya, float xb,
+// The one-sided form of the same test: sed = r^2 / da + r^2 / db >= r^2 / db, so  s > 0  and  s^2 > T dB  already
+// proves sed_fl > thr — the bound derivation above cut short after the db term.  It needs neither la = E a nor dA.
+// It is weaker: pairs with thr < sed <~ 2 thr (where da ~ db, the usual case for an essential matrix) slip through
+// to tier 2 — about 40 % more tier-2 work, still a net gain (3.33 -> 3.17 ms on 50k x 100k when first introduced).
+// Choosing per hypothesis between the db and the da form (sed is symmetric under E -> E^T, a <-> b) would guard
+// against lopsided matrices, but the second code path costs a wave of occupancy (109 VGPRs, SGPR spills) — more than
+// the filter saves; a lopsided E only makes tier 1 weaker, never wrong.
+// The loop's form of the one-sided test, as a wave mask (bit = lane rejects).
+//  * No threshold multiply: the prepared a-side coordinates (and E_j2, the entries that meet a's third coordinate)
+//    carry the factor c = (1 - 1e-6) / sqrt(T), so the bilinear form evaluates to r' = c r with the same rounding
+//    budget (every input still rounded once), delta is computed from the scaled data-set maxima, and
+//    s'^2 > dB  with  s' = |r'| - delta' <= c |r_fl|  implies  r_fl^2 > dB / c^2 >= T dB  (c^2 T < 1).  c = 0 switches
+//    the test off (thr negative, NaN, or T outside [1e-30, 1e30]): r' = 0, s' <= 0.
+//  * One compare: dB >= 0 whenever it is not NaN, and s |s| > dB >= 0 forces s > 0 (|s| is an operand modifier).
+//  * No underflow guard in the loop: dB >= cb (rounding is monotone), and arm_one_sided has checked cb > 1e-36 for
+//    this hypothesis or switched its filter off (delta = +inf: s = -inf, never rejects).
+//  * Each compare writes its lane mask straight to a scalar register pair; going through a per-lane bool and a
+//    ballot makes the compiler materialise 0/1 in a VGPR and compare it again.
+// 14 VALU instructions per evaluation: 8 FMA for r', 2 FMA for dB, subtract, signed square, compare.
+SFM_DEVICE unsigned long long reject_mask_one_sided(const FilterConsts& f, float xa_scaled, float ya_scaled, float xb,
                                                     float yb) {
     const float lb0 = fmaf(xb, f.e[0], fmaf(yb, f.e[3], f.e[6]));
     const float lb1 = fmaf(xb, f.e[1], fmaf(yb, f.e[4], f.e[7]));
     const float lb2 = fmaf(xb, f.e[2], fmaf(yb, f.e[5], f.e[8]));
-    const float r = fmaf(lb0, xa, fmaf(lb1, ya, lb2));
+    const float r = fmaf(lb0, xa_scaled, fmaf(lb1, ya_scaled, lb2));
     const float s = fabsf(r) - f.delta;
     const float dB = fmaf(lb0, lb0, fmaf(lb1, lb1, f.cb));
-    const float rhs = T * dB;
-    // s > 0 and s^2 > rhs in one compare: rhs >= 0 whenever it is not NaN, and s |s| > rhs >= 0 forces s > 0
-    // (the |s| is an operand modifier, free).  The underflow guard of the compiled-in form above is hoisted out of the
-    // loop: dB >= cb and rounding is monotone, so rhs >= fl(T cb), and the caller (arm_one_sided) has checked
-    // fl(T cb) > 1e-36 for this hypothesis or switched its filter off (delta = +inf: s = -inf, never rejects).
-    return __builtin_amdgcn_ballot_w64(s * fabsf(s) > rhs);
+    return __builtin_amdgcn_ballot_w64(s * fabsf(s) > dB);
 }
 
 // Per-hypothesis precondition of reject_mask_one_sided (see there).  NaN fails the comparison and disarms too.
-SFM_DEVICE void arm_one_sided(FilterConsts& f, float T) {
-    if (!(T * f.cb > 1e-36f)) f.delta = INFINITY;
+SFM_DEVICE void arm_one_sided(FilterConsts& f) {
+    if (!(f.cb > 1e-36f)) f.delta = INFINITY;
+}
+
+// Factor carried by the prepared a-side coordinates (host side).
+inline double one_sided_scale(double thr) {
+    const double T = thr * (1.0 + 1.0 / 1024.0) * (1.0 + 1e-5);
+    return (T > 1e-30 && T < 1e30) ? (1.0 - 1e-6) / sqrt(T) : 0.0;  // NaN compares false
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -310,10 +318,10 @@ SFM_DEVICE void arm_one_sided(FilterConsts& f, float T) {
 // points), a counting sort orders hypotheses by decreasing estimate, and the scoring kernel walks that order
 // (longest first).  Results are still written at each hypothesis' own index: the order only affects speed.
 // ------------------------------------------------------------------------------------------------
-template <int HPW>
+template <int HPW, bool ONE_SIDED>
 __global__ __launch_bounds__(256) void score_estimate_kernel(const unsigned char* __restrict__ ws, int n,
                                                              const double* __restrict__ E, int h_count, double thr,
-                                                             int32_t* __restrict__ estimate) {
+                                                             double a_scale, int32_t* __restrict__ estimate) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = blockIdx.x * (256 / kWave) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     const int h0 = wave * HPW;
@@ -336,14 +344,22 @@ __global__ __launch_bounds__(256) void score_estimate_kernel(const unsigned char
         double e[9];
 #pragma unroll
         for (int j = 0; j < 9; ++j) e[j] = Eb[(int64_t)h * 9 + j];
-        f[k] = make_filter_consts(e, Xa, Ya, Xb, Yb);
+        f[k] = make_filter_consts(e, Xa, Ya, Xb, Yb, a_scale);
+        if (ONE_SIDED) arm_one_sided(f[k]);
         c[k] = 0;
     }
     const int limit = min(n, kEstimatePoints);
     for (int i = lane; i < limit; i += kWave) {
         const float4 p = pts32[i];
 #pragma unroll
-        for (int k = 0; k < HPW; ++k) c[k] += filter_rejects(f[k], T, p.x, p.y, p.z, p.w) ? 0 : 1;
+        for (int k = 0; k < HPW; ++k) {
+            if (ONE_SIDED) {  // lanes beyond `limit` are inactive and contribute no bits
+                const unsigned long long rej = reject_mask_one_sided(f[k], p.x, p.y, p.z, p.w);
+                c[k] += (int)((~rej >> lane) & 1ull);
+            } else {
+                c[k] += filter_rejects(f[k], T, p.x, p.y, p.z, p.w) ? 0 : 1;
+            }
+        }
     }
 #pragma unroll
     for (int k = 0; k < HPW; ++k) {
@@ -429,7 +445,7 @@ __global__ __launch_bounds__(256) void score_class_scatter_kernel(const int32_t*
 template <int HPW, bool ONE_SIDED>
 __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
     const Corr* __restrict__ corr, const unsigned char* __restrict__ ws, int n,
-    const double* __restrict__ E, const int32_t* __restrict__ S, int h_count, double thr,
+    const double* __restrict__ E, const int32_t* __restrict__ S, int h_count, double thr, double a_scale,
     const int32_t* __restrict__ order, int32_t* __restrict__ cnt, double* __restrict__ s1,
     double* __restrict__ s2) {
     __shared__ __attribute__((aligned(1024))) int32_t ring[256 / kWave][HPW][kRing];  // each ring = one aligned KiB
@@ -475,8 +491,8 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
         double e[9];
 #pragma unroll
         for (int j = 0; j < 9; ++j) e[j] = Eb[(int64_t)h * 9 + j];
-        f[k] = make_filter_consts(e, Xa, Ya, Xb, Yb);
-        if (ONE_SIDED) arm_one_sided(f[k], T);
+        f[k] = make_filter_consts(e, Xa, Ya, Xb, Yb, a_scale);
+        if (ONE_SIDED) arm_one_sided(f[k]);
         // The four multiplier entries go to scalar registers (a VALU instruction takes ONE scalar operand
         // for free); the five addend entries e2, e5, e6, e7, e8 and delta / eta stay in VGPRs as
         // wave-uniform values: an FMA whose multiplier and addend were both scalar would need an extra
@@ -557,8 +573,8 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
         for (int k = 0; k < HPW; ++k) {
             unsigned long long m0, m1;  // survivors of the two chunks
             if (ONE_SIDED) {
-                m0 = ~reject_mask_one_sided(f[k], T, p0.x, p0.y, p0.z, p0.w);
-                m1 = ~reject_mask_one_sided(f[k], T, p1.x, p1.y, p1.z, p1.w);
+                m0 = ~reject_mask_one_sided(f[k], p0.x, p0.y, p0.z, p0.w);
+                m1 = ~reject_mask_one_sided(f[k], p1.x, p1.y, p1.z, p1.w);
             } else {
                 m0 = ~__builtin_amdgcn_ballot_w64(filter_rejects(f[k], T, p0.x, p0.y, p0.z, p0.w));
                 m1 = ~__builtin_amdgcn_ballot_w64(filter_rejects(f[k], T, p1.x, p1.y, p1.z, p1.w));
@@ -576,8 +592,9 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
     auto process_tail = [&](const float4 p, int i, bool valid) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < HPW; ++k) {
-            const bool pass = valid & !filter_rejects(f[k], T, p.x, p.y, p.z, p.w);
-            const unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
+            const unsigned long long mask =
+                ONE_SIDED ? ~reject_mask_one_sided(f[k], p.x, p.y, p.z, p.w) & __builtin_amdgcn_ballot_w64(valid)
+                          : __builtin_amdgcn_ballot_w64(valid & !filter_rejects(f[k], T, p.x, p.y, p.z, p.w));
             if (mask != 0ull) {
                 push(k, mask, i);
                 __builtin_amdgcn_wave_barrier();
@@ -643,6 +660,8 @@ struct FilteredLaunch {
     int32_t* order;
     int64_t batch;
     hipStream_t st;
+    bool one_sided;
+    double a_scale;
 };
 
 template <int HPW>
@@ -652,7 +671,12 @@ int launch_filtered(const FilteredLaunch& a) {
     const int32_t* order_arg = nullptr;
     if (a.use_order) {
         // `cnt` doubles as the estimate buffer: it is rewritten by the scoring kernel afterwards
-        hipLaunchKernelGGL(score_estimate_kernel<HPW>, grid, dim3(256), 0, a.st, a.ws, a.n, a.E, a.h_count, a.thr, a.cnt);
+        if (a.one_sided)
+            hipLaunchKernelGGL((score_estimate_kernel<HPW, true>), grid, dim3(256), 0, a.st, a.ws, a.n, a.E, a.h_count,
+                               a.thr, a.a_scale, a.cnt);
+        else
+            hipLaunchKernelGGL((score_estimate_kernel<HPW, false>), grid, dim3(256), 0, a.st, a.ws, a.n, a.E, a.h_count,
+                               a.thr, a.a_scale, a.cnt);
         const dim3 per_hyp(grid_for(a.h_count, 256), (unsigned)a.batch);
         hipLaunchKernelGGL(score_class_count_kernel, per_hyp, dim3(256), 0, a.st, a.cnt, a.h_count, a.buckets);
         hipLaunchKernelGGL(score_class_scan_kernel, dim3(grid_for(a.batch, 64)), dim3(64), 0, a.st, a.buckets, a.batch);
@@ -661,14 +685,12 @@ int launch_filtered(const FilteredLaunch& a) {
         if (rc != SFM_OK) return rc;
         order_arg = a.order;
     }
-    // SFM_SCORE_ONE_SIDED=0 switches tier 1 back to the two-sided test (ablation: 3.33 vs 3.17 ms on 50k x 100k)
-    static const bool one_sided = getenv("SFM_SCORE_ONE_SIDED") ? atoi(getenv("SFM_SCORE_ONE_SIDED")) != 0 : true;
-    if (one_sided)
+    if (a.one_sided)
         hipLaunchKernelGGL((score_sed_filtered_kernel<HPW, true>), grid, dim3(256), 0, a.st, a.corr, a.ws, a.n, a.E, a.S,
-                           a.h_count, a.thr, order_arg, a.cnt, a.s1, a.s2);
+                           a.h_count, a.thr, a.a_scale, order_arg, a.cnt, a.s1, a.s2);
     else
         hipLaunchKernelGGL((score_sed_filtered_kernel<HPW, false>), grid, dim3(256), 0, a.st, a.corr, a.ws, a.n, a.E, a.S,
-                           a.h_count, a.thr, order_arg, a.cnt, a.s1, a.s2);
+                           a.h_count, a.thr, a.a_scale, order_arg, a.cnt, a.s1, a.s2);
     return check_launch("score_sed_filtered_kernel");
 }
 
@@ -705,8 +727,11 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
     int32_t* buckets = reinterpret_cast<int32_t*>(ws + ws_buckets_offset(n, batch));
     int32_t* order = reinterpret_cast<int32_t*>(ws + ws_order_offset(n, batch));
     hipLaunchKernelGGL(score_reset_kernel, dim3((unsigned)batch), dim3(256), 0, st, ws, buckets);
+    // SFM_SCORE_ONE_SIDED=0 switches tier 1 back to the two-sided test (ablation)
+    static const bool one_sided = getenv("SFM_SCORE_ONE_SIDED") ? atoi(getenv("SFM_SCORE_ONE_SIDED")) != 0 : true;
+    const double a_scale = one_sided ? one_sided_scale(thr) : 1.0;
     hipLaunchKernelGGL(score_prepare_kernel, dim3(grid_for(n, 256, 64), (unsigned)batch), dim3(256), 0, st,
-                       (const Corr*)corr, n, ws);
+                       (const Corr*)corr, n, a_scale, ws);
     int rc = check_launch("score_prepare_kernel");
     if (rc != SFM_OK) return rc;
     // longest-first processing order (cost pre-pass + counting sort); SFM_SCORE_ORDER=0 keeps index order
@@ -726,7 +751,7 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
         while (hpw > 1 && (h_count + hpw - 1) / hpw * batch < 5120) hpw /= 2;
     }
     const FilteredLaunch args{(const Corr*)corr, ws, (int)n, E, S, (int)h_count, thr, use_order, cnt, s1, s2,
-                              buckets, order, batch, st};
+                              buckets, order, batch, st, one_sided, a_scale};
     switch (hpw) {
         case 1: return launch_filtered<1>(args);
         case 2: return launch_filtered<2>(args);

@@ -502,7 +502,9 @@ def _assert_same_scores(exact, filt):
 
 
 @pytest.mark.parametrize("n,h", [(300, 64), (4099, 130), (20000, 515)])
-@pytest.mark.parametrize("thr", [1.5e-6, 1e-3, 0.0, 1e-12, 1e30, -1.0, float("nan"), float("inf")])
+@pytest.mark.parametrize("thr", [1.5e-6, 1e-3, 0.0, 1e-12, 1e30, -1.0, float("nan"), float("inf"),
+                                 # around the range in which the threshold is folded into the prepared coordinates
+                                 1e-31, 9e-31, 1.1e-30, 1e-20, 9e29, 1.1e30, 1e38, 1e300, 5e-324])
 def test_filtered_score_equals_exact(dev, n, h, thr):
     _, _, _, corr = scene(n)
     S = orc.philox_sample_table(13, 0, h, n)
