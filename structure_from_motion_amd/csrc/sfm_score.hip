@@ -277,38 +277,45 @@ SFM_DEVICE bool filter_rejects(const FilterConsts& f, float T, float xa, float y
 // Choosing per hypothesis between the db and the da form (sed is symmetric under E -> E^T, a <-> b) would guard
 // against lopsided matrices, but the second code path costs a wave of occupancy (109 VGPRs, SGPR spills) — more than
 // the filter saves; a lopsided E only makes tier 1 weaker, never wrong.
-// The loop's form of the one-sided test, as a wave mask (bit = lane rejects).
+// The loop's form of the one-sided test, as a wave mask (bit = lane rejects): 12 VALU instructions per evaluation —
+// 8 FMA for r', 2 FMA for dB, one square, one compare.
 //  * No threshold multiply: the prepared a-side coordinates (and E_j2, the entries that meet a's third coordinate)
-//    carry the factor c = (1 - 1e-6) / sqrt(T), so the bilinear form evaluates to r' = c r with the same rounding
-//    budget (every input still rounded once), delta is computed from the scaled data-set maxima, and
-//    s'^2 > dB  with  s' = |r'| - delta' <= c |r_fl|  implies  r_fl^2 > dB / c^2 >= T dB  (c^2 T < 1).  c = 0 switches
-//    the test off (thr negative, NaN, or T outside [1e-30, 1e30]): r' = 0, s' <= 0.
-//  * One compare: dB >= 0 whenever it is not NaN, and s |s| > dB >= 0 forces s > 0 (|s| is an operand modifier).
-//  * No underflow guard in the loop: dB >= cb (rounding is monotone), and arm_one_sided has checked cb > 1e-36 for
-//    this hypothesis or switched its filter off (delta = +inf: s = -inf, never rejects).
-//  * Each compare writes its lane mask straight to a scalar register pair; going through a per-lane bool and a
+//    carry a factor c, so the bilinear form evaluates to r' = c r with the same rounding budget (every input still
+//    rounded once) and delta' is computed from the scaled data-set maxima: |c r_fl| >= |r'| - delta'.
+//  * No subtraction of delta' and no sign test: with k = 2^-10 and 2 x d <= k' x^2 + d^2 / k' (k' = k / (1 + k)),
+//        (x - d)^2 >= x^2 / (1 + k) - d^2 / k,
+//    so  r'^2 > dB + delta'^2 (1 + k) / k  implies  (|r'| - delta')^2 >= dB / (1 + k)  (and |r'| > delta'), hence
+//    r_fl^2 >= dB / (c^2 (1 + k)) >= T dB  when  c^2 (1 + k) T <= 1:  c = (1 - 1e-6) / sqrt(T (1 + k)).  The delta term is
+//    folded into cb once per hypothesis (arm_one_sided); it is ~1e-9 of a typical dB.
+//    c = 0 switches the test off (thr negative, NaN, or T outside [1e-30, 1e30]): r' = 0 never exceeds dB >= 0.
+//  * No underflow guard in the loop: dB >= cb (rounding is monotone), and arm_one_sided makes cb +inf where it
+//    would be too small to trust (or NaN).
+//  * The compare writes its lane mask straight to a scalar register pair; going through a per-lane bool and a
 //    ballot makes the compiler materialise 0/1 in a VGPR and compare it again.
-// 14 VALU instructions per evaluation: 8 FMA for r', 2 FMA for dB, subtract, signed square, compare.
 SFM_DEVICE unsigned long long reject_mask_one_sided(const FilterConsts& f, float xa_scaled, float ya_scaled, float xb,
                                                     float yb) {
     const float lb0 = fmaf(xb, f.e[0], fmaf(yb, f.e[3], f.e[6]));
     const float lb1 = fmaf(xb, f.e[1], fmaf(yb, f.e[4], f.e[7]));
     const float lb2 = fmaf(xb, f.e[2], fmaf(yb, f.e[5], f.e[8]));
     const float r = fmaf(lb0, xa_scaled, fmaf(lb1, ya_scaled, lb2));
-    const float s = fabsf(r) - f.delta;
     const float dB = fmaf(lb0, lb0, fmaf(lb1, lb1, f.cb));
-    return __builtin_amdgcn_ballot_w64(s * fabsf(s) > dB);
+    return __builtin_amdgcn_ballot_w64(r * r > dB);
 }
 
-// Per-hypothesis precondition of reject_mask_one_sided (see there).  NaN fails the comparison and disarms too.
+// Turn the constants of the two-sided test into those of reject_mask_one_sided: fold delta into cb (see there), and
+// switch the filter off for this hypothesis (cb = +inf: nothing exceeds dB) when cb is too small to keep dB out of
+// the denormal range, or NaN.
 SFM_DEVICE void arm_one_sided(FilterConsts& f) {
-    if (!(f.cb > 1e-36f)) f.delta = INFINITY;
+    constexpr float kappa = 1.0f / 1024.0f;
+    const float folded = f.cb + (f.delta * f.delta) * ((1.0f + kappa) / kappa * (1.0f + 1e-5f));
+    f.cb = (f.cb > 1e-36f) ? folded : INFINITY;  // NaN cb, or NaN / inf delta -> NaN or inf: never rejects
+    if (!(f.cb == f.cb)) f.cb = INFINITY;
 }
 
 // Factor carried by the prepared a-side coordinates (host side).
 inline double one_sided_scale(double thr) {
     const double T = thr * (1.0 + 1.0 / 1024.0) * (1.0 + 1e-5);
-    return (T > 1e-30 && T < 1e30) ? (1.0 - 1e-6) / sqrt(T) : 0.0;  // NaN compares false
+    return (T > 1e-30 && T < 1e30) ? (1.0 - 1e-6) / sqrt(T * (1.0 + 1.0 / 1024.0)) : 0.0;  // NaN compares false
 }
 
 // ------------------------------------------------------------------------------------------------
