@@ -303,6 +303,49 @@ def pyshuffle_table(n: int, iterations: int, rng=_pyrandom, snapshot_iteration: 
     return S, snap
 
 
+class PyShuffleTable:
+    """The sample table of ``iterations`` cumulative ``random.shuffle`` calls (``pyshuffle_table``) that also keeps
+    up to ``checkpoints`` snapshots of (generator state, permutation) on the way, so that the full permutation after
+    any iteration — the order in which the reference returns the winner's inliers — is re-derived by replaying at
+    most ``iterations / checkpoints`` shuffles instead of all of them up to the winner."""
+
+    def __init__(self, n: int, iterations: int, rng=_pyrandom, advance: bool = True, checkpoints: int = 32):
+        lib = _native.load()
+        self.n, self.iterations = n, iterations
+        self.stride = max(1, -(-iterations // max(1, checkpoints)))
+        version, internal, gauss = rng.getstate()
+        state = (C.c_uint32 * 624)(*internal[:624])
+        index = C.c_int32(internal[624])
+        perm = np.arange(n, dtype=np.int32)
+        self.S = np.empty((iterations, 8), dtype=np.int32)
+        self._saved = []  # (state bytes, index, permutation) before each segment
+        for start in range(0, iterations, self.stride):
+            count = min(self.stride, iterations - start)
+            self._saved.append((bytes(state), index.value, perm.copy()))
+            check(lib.sfm_pyshuffle_table(
+                C.cast(state, C.c_void_p), C.cast(C.byref(index), C.c_void_p), n, count,
+                self.S[start:].ctypes.data_as(C.c_void_p), perm.ctypes.data_as(C.c_void_p), -1, None),
+                "sfm_pyshuffle_table")
+        if advance:
+            rng.setstate((version, tuple(state) + (index.value,), gauss))
+
+    def permutation_after(self, iteration: int) -> np.ndarray:
+        """The shuffled index list as it stood after ``iteration`` (0-based) — ``data`` of ransac.py:62-64."""
+        if not 0 <= iteration < self.iterations:
+            raise IndexError(iteration)
+        lib = _native.load()
+        state_bytes, index_value, perm = self._saved[iteration // self.stride]
+        state = (C.c_uint32 * 624).from_buffer_copy(state_bytes)
+        index = C.c_int32(index_value)
+        perm = perm.copy()
+        count = iteration % self.stride + 1
+        scratch = np.empty((count, 8), dtype=np.int32)
+        check(lib.sfm_pyshuffle_table(
+            C.cast(state, C.c_void_p), C.cast(C.byref(index), C.c_void_p), self.n, count,
+            scratch.ctypes.data_as(C.c_void_p), perm.ctypes.data_as(C.c_void_p), -1, None), "sfm_pyshuffle_table")
+        return perm
+
+
 # ------------------------------------------------------------------------------------------------------
 # the RANSAC engine: sample table -> fit -> score -> select -> mask, all enqueued on one stream
 # ------------------------------------------------------------------------------------------------------

@@ -67,11 +67,10 @@ def ransac_feature_pairs(data, camera_matrix, threshold, min_extra, aggregation,
     corr = device.normalize_correspondences(device.to_device(pix_a), device.to_device(pix_b), camera_matrix)
     ws = device.RansacWorkspace(1, n, iterations, dev)
     sampler = sampler_name()
-    state_before = None
+    table = None
     if sampler == "pyshuffle":
-        state_before = random.getstate()
-        table, _ = device.pyshuffle_table(n, iterations, random, advance=True)
-        ws.S.copy_(device.to_device(table, dtype=ws.S.dtype).reshape(1, iterations, 8))
+        table = device.PyShuffleTable(n, iterations, random, advance=True)
+        ws.S.copy_(device.to_device(table.S, dtype=ws.S.dtype).reshape(1, iterations, 8))
     else:
         seed = int(os.environ["SFM_SEED"]) if "SFM_SEED" in os.environ else random.getrandbits(64)
         device.sample_philox(seed, 0, iterations, n, out=ws.S)
@@ -96,10 +95,7 @@ def ransac_feature_pairs(data, camera_matrix, threshold, min_extra, aggregation,
             return E_ref.cpu().numpy().reshape(3, 3), [copy.deepcopy(data[int(i)]) for i in keep]
     survivors = outcome.mask == 1
     if sampler == "pyshuffle":
-        replay = random.Random()
-        replay.setstate(state_before)
-        _, perm = device.pyshuffle_table(n, outcome.best_h + 1, replay,
-                                         snapshot_iteration=outcome.best_h, advance=False)
+        perm = table.permutation_after(outcome.best_h)
         order = [int(i) for i in perm[:8]] + [int(i) for i in perm[8:] if survivors[i]]
     else:
         order = [int(i) for i in outcome.sample] + [int(i) for i in np.nonzero(survivors)[0]]

@@ -84,6 +84,29 @@ def test_pyshuffle_replay_uses_global_random(native_lib):
     np.testing.assert_array_equal(S2[0], p[:8])  # state was not advanced
 
 
+@pytest.mark.parametrize("n,iters,checkpoints", [(10, 100, 32), (341, 257, 7), (9, 5, 32), (50, 64, 1), (12, 1, 4)])
+def test_checkpointed_shuffle_table(native_lib, n, iters, checkpoints):
+    """PyShuffleTable == literal CPython shuffles: the table, the generator state afterwards, and the full
+    permutation after any iteration, re-derived from the nearest checkpoint."""
+    from structure_from_motion_amd import device
+
+    rng, twin = random.Random(11), random.Random(11)
+    table = device.PyShuffleTable(n, iters, rng, checkpoints=checkpoints)
+    perm, history = list(range(n)), []
+    for _ in range(iters):
+        twin.shuffle(perm)
+        history.append(list(perm))
+    np.testing.assert_array_equal(table.S, np.array([h[:8] for h in history]))
+    assert rng.getstate() == twin.getstate()
+    for it in sorted({0, iters - 1, iters // 2, iters // 3, max(0, iters - 2)}):
+        np.testing.assert_array_equal(table.permutation_after(it), history[it])
+    with pytest.raises(IndexError):
+        table.permutation_after(iters)
+    untouched = random.Random(11)
+    device.PyShuffleTable(n, iters, untouched, advance=False)
+    assert untouched.getstate() == random.Random(11).getstate()
+
+
 # ------------------------------------------------------------------------------------------------------
 # generic driver (reference lib/ransac/tests/test_ransac.py)
 # ------------------------------------------------------------------------------------------------------
