@@ -258,6 +258,46 @@ __global__ __launch_bounds__(256) void row_summary_kernel(const double* __restri
 // max(v_i, p_i), B = min over left-subtree columns of v_i.  All of it is selection (min / max / compare), no
 // arithmetic: the result is bit-identical to row_summary_kernel on the full matrix.  32 B per 128 scores leave
 // the kernel instead of 1 KiB, and the matrix is never re-read.
+// 16-lane row rotations by DPP (a VALU move modifier: no LDS crossbar, unlike __shfl): lane l of a row reads lane
+// (l + N) mod 16 of the same row.
+template <int N>
+SFM_DEVICE int row_ror(int x) {
+    return __builtin_amdgcn_update_dpp(0, x, 0x120 | N, 0xf, 0xf, false);
+}
+template <int N>
+SFM_DEVICE double row_ror(double x) {
+    return __hiloint2double(row_ror<N>(__double2hiint(x)), row_ror<N>(__double2loint(x)));
+}
+
+// Smallest value with its first column, and the second smallest (counting duplicates) of a set of scores.
+struct TopTwo {
+    double m1;
+    int32_t at;  // column of m1 (first occurrence), INT32_MAX if the set has no comparable element
+    double m2;
+};
+SFM_DEVICE void top_two_add(TopTwo& t, double v, int32_t column) {  // columns arrive in increasing order; NaN is ignored
+    const bool first = v < t.m1;
+    t.m2 = first ? t.m1 : ((v < t.m2) ? v : t.m2);
+    t.at = first ? column : t.at;
+    t.m1 = first ? v : t.m1;
+}
+SFM_DEVICE TopTwo top_two_merge(const TopTwo& a, const TopTwo& b) {
+    const bool take_b = (b.m1 < a.m1) || (b.m1 == a.m1 && b.at < a.at);
+    TopTwo r;
+    r.m1 = take_b ? b.m1 : a.m1;
+    r.at = take_b ? b.at : a.at;
+    r.m2 = fmin(fmin(a.m2, b.m2), take_b ? a.m1 : b.m1);
+    return r;
+}
+template <int N>
+SFM_DEVICE TopTwo top_two_ror(const TopTwo& t) {
+    TopTwo r;
+    r.m1 = row_ror<N>(t.m1);
+    r.at = row_ror<N>(t.at);
+    r.m2 = row_ror<N>(t.m2);
+    return r;
+}
+
 struct TileSummary {
     double tile_min, left_prefixed, left_min;
     int64_t tile_arg;
@@ -275,23 +315,83 @@ __global__ __launch_bounds__(256, 2) void pair_summary_kernel(
     const int64_t a0 = (int64_t)blockIdx.y * kTileA, b0 = (int64_t)blockIdx.x * kTileB;
     double acc[kRowsPerLane][kColsPerLane];
     tile_accumulate<MODE, DIRECT>(Pa, stride_a, Pb, stride_b, nA, nB, K, a0, b0, sA, sB, acc);
-    // per-column operands of this lane's 8 columns
-    double qbj[kColsPerLane];
+    // Per-column and per-row operands of this lane's 8 x 8 block, fetched in one batch: unconditional loads at
+    // clamped indices (a predicated load per element compiles to load -> wait -> next load, 32 memory latencies in a
+    // row at two waves per SIMD — it was most of the kernel's fixed 1.5 ms).
+    double qbj[kColsPerLane], qai_all[kRowsPerLane];
+    uint8_t okb_raw[kColsPerLane], oka_raw[kRowsPerLane];
+#pragma unroll
+    for (int j = 0; j < kColsPerLane; ++j) {
+        const int64_t ib = min(b0 + (j / 2) * 32 + tx * 2 + (j % 2), nB - 1);
+        qbj[j] = qb[ib];
+        okb_raw[j] = okb[ib];
+    }
+#pragma unroll
+    for (int i = 0; i < kRowsPerLane; ++i) {
+        const int64_t ia = min(a0 + ty * kRowsPerLane + i, nA - 1);
+        qai_all[i] = qa[ia];
+        oka_raw[i] = oka[ia];
+    }
     bool okj[kColsPerLane], validj[kColsPerLane], leftj[kColsPerLane];
 #pragma unroll
     for (int j = 0; j < kColsPerLane; ++j) {
         const int64_t ib = b0 + (j / 2) * 32 + tx * 2 + (j % 2);
         validj[j] = ib < nB;
-        qbj[j] = validj[j] ? qb[ib] : 0.0;
-        okj[j] = validj[j] && okb[ib] != 0;
+        okj[j] = validj[j] && okb_raw[j] != 0;
         leftj[j] = validj[j] && ib >= 1 && in_left_subtree(ib + 1);
     }
+    const bool uniform_tile = b0 >= 256;                      // see the fast path below
+    const bool first_left = in_left_subtree(b0 + 1);          // heap position of the tile's first column (and 126 more)
+    const bool last_left = in_left_subtree(b0 + kTileB);      // ... of its last column
+    const bool last_valid = b0 + kTileB - 1 < nB;
 #pragma unroll
     for (int i = 0; i < kRowsPerLane; ++i) {
         const int64_t ia = a0 + ty * kRowsPerLane + i;
         const bool row_valid = ia < nA;  // uniform over the 16 lanes of the row
-        const double qai = row_valid ? qa[ia] : 0.0;
-        const bool oki = row_valid && oka[ia] != 0;
+        const double qai = qai_all[i];
+        const bool oki = row_valid && oka_raw[i] != 0;
+        if (uniform_tile) {  // block-uniform
+            // From column 256 on, a 128-column tile lies inside one run of the heap's left/right pattern except,
+            // possibly, for its LAST column (runs end at positions that are multiples of 128).  With F = the first
+            // 127 columns and p_i the minimum of the tile's columns before i:
+            //   min over i in F of max(v_i, p_i) = second smallest element of F (duplicates counted) — before the
+            //   first minimum every term is >= the prefix minimum in front of it, at it the term IS that prefix
+            //   minimum, after it the term is v_i itself —
+            // so no scan is needed, only a top-two reduction (selection only: bit-identical to the general path).
+            TopTwo t = {INFINITY, INT32_MAX, INFINITY};
+            double v_last = INFINITY;  // the tile's last column, meaningful in lane tx == 15 only
+#pragma unroll
+            for (int j = 0; j < kColsPerLane; ++j) {
+                const double v = finish_score<MODE>(acc[i][j], oki && okj[j], qai, qbj[j], K);
+                const int32_t column = (int32_t)(b0 + (j / 2) * 32 + tx * 2 + (j % 2));
+                const bool is_last = (j == kColsPerLane - 1) && (tx == 15);
+                if (is_last) v_last = validj[j] ? v : INFINITY;
+                if (validj[j] && !is_last) top_two_add(t, v, column);
+            }
+            t = top_two_merge(t, top_two_ror<8>(t));
+            t = top_two_merge(t, top_two_ror<4>(t));
+            t = top_two_merge(t, top_two_ror<2>(t));
+            t = top_two_merge(t, top_two_ror<1>(t));
+            if (tx == 15 && row_valid) {
+                TileSummary r;
+                const bool last_wins = v_last < t.m1;  // strict: an equal earlier column keeps the minimum
+                r.tile_min = last_wins ? v_last : t.m1;
+                r.tile_arg = last_wins ? (b0 + kTileB - 1) : (t.at == INT32_MAX ? INT64_MAX : (int64_t)t.at);
+                double left_prefixed = INFINITY, left_min = INFINITY;
+                if (first_left) {
+                    left_prefixed = t.m2;
+                    left_min = t.m1;
+                }
+                if (last_left && last_valid) {
+                    left_prefixed = fmin(left_prefixed, (v_last < t.m1) ? t.m1 : v_last);  // p_last = min of F
+                    left_min = fmin(left_min, v_last);
+                }
+                r.left_prefixed = left_prefixed;
+                r.left_min = left_min;
+                tiles[(int64_t)blockIdx.x * nA + ia] = r;
+            }
+            continue;
+        }
         double carry = INFINITY;  // minimum of the tile's columns before the current group
         double left_prefixed = INFINITY, left_min = INFINITY;
         MinAt top = {INFINITY, INT64_MAX};

@@ -154,7 +154,8 @@ def test_fused_summary_equals_matrix_path_with_ties_and_nonfinite(metric):
     bad[30:33, 50:52] = np.inf
     images.append((bad, np.roll(bad, (2, 1), axis=(0, 1))))
     for ia, ib in images:
-        for nA, nB in [(3, 1), (5, 2), (70, 129), (40, 1000)]:
+        # 5000 columns: tiles on both sides of every left/right run boundary up to 4096, last columns included
+        for nA, nB in [(3, 1), (5, 2), (70, 129), (40, 1000), (9, 5000), (3, 384), (3, 385), (3, 512), (3, 513)]:
             fa = np.column_stack([rng.integers(-1, W + 1, nA), rng.integers(-1, H + 1, nA)]).astype(np.float64)
             fb = np.column_stack([rng.integers(-1, W + 1, nB), rng.integers(-1, H + 1, nB)]).astype(np.float64)
             sc = _device_match.score_matrix(metric, ia, ib, feats(fa), feats(fb), 5)
