@@ -31,9 +31,9 @@
 //   NaN / inf / overflow / underflow anywhere make a comparison false (or the guard fail) and the
 //   pair goes to tier 2.  thr < 0 or NaN switches the filter off.
 //   The steady-state loop uses the ONE-SIDED form of this test (drop the 1/da term: s^2 > T dB), which needs
-//   neither la nor dA — reject_mask_one_sided below, which also folds T into the prepared coordinates and hoists the
-//   underflow guard out of the loop (14 VALU per evaluation); SFM_SCORE_ONE_SIDED=0 restores the two-sided test
-//   everywhere (ablation).
+//   neither la nor dA — reject_mask_one_sided below, which also folds T into the prepared coordinates, delta into
+//   the dB slack and the underflow guard into a per-hypothesis check (12 VALU per evaluation);
+//   SFM_SCORE_ONE_SIDED=0 restores the two-sided test everywhere (ablation).
 //
 // Compiled with -ffp-contract=off; the fp32 tier spells its FMAs explicitly.
 #include <hip/hip_runtime.h>
