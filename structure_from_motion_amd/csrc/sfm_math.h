@@ -468,16 +468,36 @@ SFM_DEVICE void philox_sample8(uint64_t seed, uint64_t h, uint32_t n, int32_t ou
     }
 }
 
-// 64-lane butterfly reductions with a fixed combination order (deterministic, no atomics).
+// 64-lane sums with a fixed combination order (deterministic, no atomics): four DPP row rotations give every lane
+// the sum of its 16-lane row, the four row sums are then read out (v_readlane) and added in row order.  All VALU — a
+// __shfl_xor butterfly goes through the LDS crossbar (ds_bpermute) six times in a dependent chain, which is what a
+// short kernel epilogue waits on.
+template <int N>
+SFM_DEVICE int dpp_row_ror(int x) {
+    return __builtin_amdgcn_update_dpp(0, x, 0x120 | N, 0xf, 0xf, false);
+}
+template <int N>
+SFM_DEVICE double dpp_row_ror(double x) {
+    return __hiloint2double(dpp_row_ror<N>(__double2hiint(x)), dpp_row_ror<N>(__double2loint(x)));
+}
+SFM_DEVICE double read_lane(double x, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), lane),
+                            __builtin_amdgcn_readlane(__double2loint(x), lane));
+}
 SFM_DEVICE double wave_sum(double x) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
-    return x;
+    x += dpp_row_ror<8>(x);
+    x += dpp_row_ror<4>(x);
+    x += dpp_row_ror<2>(x);
+    x += dpp_row_ror<1>(x);
+    return ((read_lane(x, 0) + read_lane(x, 16)) + read_lane(x, 32)) + read_lane(x, 48);
 }
 SFM_DEVICE int wave_sum(int x) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
-    return x;
+    x += dpp_row_ror<8>(x);
+    x += dpp_row_ror<4>(x);
+    x += dpp_row_ror<2>(x);
+    x += dpp_row_ror<1>(x);
+    return ((__builtin_amdgcn_readlane(x, 0) + __builtin_amdgcn_readlane(x, 16)) + __builtin_amdgcn_readlane(x, 32)) +
+           __builtin_amdgcn_readlane(x, 48);
 }
 
 }  // namespace sfm

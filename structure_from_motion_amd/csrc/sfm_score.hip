@@ -61,22 +61,18 @@ constexpr int kRing = 256;  // entries per (wave, hypothesis) ring; <= 63 left +
 SFM_DEVICE void finish_hypothesis(const Corr* __restrict__ pts, const int32_t* __restrict__ sample,
                                   const double (&e)[9], double thr, int lane, int c, double a1, double a2,
                                   int32_t* cnt_out, double* s1_out, double* s2_out) {
-    int ck = sfm::wave_sum(c);
-    double s1k = sfm::wave_sum(a1);
-    double s2k = sfm::wave_sum(a2);
-    int dc = 0;
-    double d1 = 0.0, d2 = 0.0;
+    // the sample fix-up goes into the per-lane partials of lanes 0..7 first: one set of reductions, not two
     if (lane < 8) {
         const Corr p = pts[sample[lane]];
         const double sed = sfm::sed_value(e, p.xa, p.ya, p.xb, p.yb);
-        const bool counted = sed <= thr;  // already in (ck, s1k, s2k)
-        dc = counted ? -1 : 0;
-        d1 = counted ? 0.0 : sed;  // NaN / inf propagate: such a model never wins
-        d2 = counted ? 0.0 : sed * sed;
+        const bool counted = sed <= thr;  // already in (c, a1, a2)
+        c += counted ? -1 : 0;
+        a1 += counted ? 0.0 : sed;  // NaN / inf propagate: such a model never wins
+        a2 += counted ? 0.0 : sed * sed;
     }
-    ck += sfm::wave_sum(dc);
-    s1k += sfm::wave_sum(d1);
-    s2k += sfm::wave_sum(d2);
+    const int ck = sfm::wave_sum(c);
+    const double s1k = sfm::wave_sum(a1);
+    const double s2k = sfm::wave_sum(a2);
     if (lane == 0) {
         *cnt_out = ck;
         *s1_out = s1k;
