@@ -143,6 +143,96 @@ SFM_DEVICE int null_vector_of_design(const double (&xa)[8], const double (&ya)[8
     return flag;
 }
 
+// ---- N-point variant (refit on many inliers): Y^T Y is symmetric positive semi-definite and, after Hartley
+// normalisation of many points, has one small eigenvalue well separated from the rest.  Its eigenvector is found
+// by inverse iteration on a Cholesky factor (a few hundred flops) instead of a full Jacobi eigen-decomposition with
+// eigenvectors (tens of thousands), and the reference's degeneracy predicate "second-smallest eigenvalue <= 1e-10"
+// (eight_point.py:415-421) by Sylvester's law of inertia: the number of negative pivots of the LDL^T factorisation of
+// A - 1e-10 I is the number of eigenvalues below 1e-10.
+SFM_DEVICE constexpr int tri9(int p, int q) { return p * 9 - p * (p - 1) / 2 + (q - p); }  // p <= q, packed upper triangle
+
+SFM_DEVICE int eigenvalues_below9(const double (&a)[45], double tau) {
+    double l[45], d[9];  // unit lower factor stored at tri9(j, i) for j < i
+    int negative = 0;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        double dj = a[tri9(j, j)] - tau;
+#pragma unroll
+        for (int k = 0; k < j; ++k) dj -= l[tri9(k, j)] * l[tri9(k, j)] * d[k];
+        if (dj == 0.0) dj = -1e-300;  // a zero pivot: an eigenvalue AT tau counts as below (the predicate is <=)
+        d[j] = dj;
+        negative += (dj < 0.0) ? 1 : 0;
+#pragma unroll
+        for (int i = j + 1; i < 9; ++i) {
+            double v = a[tri9(j, i)];
+#pragma unroll
+            for (int k = 0; k < j; ++k) v -= l[tri9(k, i)] * l[tri9(k, j)] * d[k];
+            l[tri9(j, i)] = v / dj;
+        }
+    }
+    return negative;  // NaN pivots compare false: a NaN matrix counts nothing here and is caught by the caller
+}
+
+// Unit eigenvector of the smallest eigenvalue of the PSD matrix `a` (packed upper triangle).  Wave-uniform loop.
+SFM_DEVICE void smallest_eigenvector_psd9(const double (&a)[45], double (&x)[9]) {
+    double trace = 0.0;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) trace += a[tri9(j, j)];
+    const double sigma = fmax(trace * 1e-15, 1e-300);  // keeps the factorisation positive when an eigenvalue is ~0
+    double l[45], inv[9];                               // Cholesky factor of a + sigma I at tri9(j, i), j <= i
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        double dj = a[tri9(j, j)] + sigma;
+#pragma unroll
+        for (int k = 0; k < j; ++k) dj -= l[tri9(k, j)] * l[tri9(k, j)];
+        dj = fmax(dj, sigma);
+        const double ljj = sqrt(dj);
+        l[tri9(j, j)] = ljj;
+        inv[j] = 1.0 / ljj;
+#pragma unroll
+        for (int i = j + 1; i < 9; ++i) {
+            double v = a[tri9(j, i)];
+#pragma unroll
+            for (int k = 0; k < j; ++k) v -= l[tri9(k, i)] * l[tri9(k, j)];
+            l[tri9(j, i)] = v * inv[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) x[j] = 1.0 / 3.0;
+    for (int iteration = 0; iteration < 200; ++iteration) {
+        double y[9], z[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {  // L y = x
+            double v = x[i];
+#pragma unroll
+            for (int k = 0; k < i; ++k) v -= l[tri9(k, i)] * y[k];
+            y[i] = v * inv[i];
+        }
+#pragma unroll
+        for (int i = 8; i >= 0; --i) {  // L^T z = y
+            double v = y[i];
+#pragma unroll
+            for (int k = i + 1; k < 9; ++k) v -= l[tri9(i, k)] * z[k];
+            z[i] = v * inv[i];
+        }
+        double norm2 = 0.0, dot = 0.0;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            norm2 += z[j] * z[j];
+            dot += z[j] * x[j];
+        }
+        const double scale = ((dot < 0.0) ? -1.0 : 1.0) / sqrt(norm2);
+        double change = 0.0;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const double next = z[j] * scale;
+            change = fmax(change, fabs(next - x[j]));
+            x[j] = next;
+        }
+        if (!(change > 1e-16)) break;  // converged (or NaN: nothing more to do)
+    }
+}
+
 // rank-2 enforcement (eight_point.py:430-446): drop the smallest singular direction of f (row-major 3x3)
 SFM_DEVICE void enforce_rank2(const double (&f)[9], double (&fr)[3][3]) {
     double g[3][3], vv[3][3];

@@ -6,7 +6,8 @@
 // _enforce_fundamental_mat_constraints (:430-446), T2^T F T1 and the division by [2,2] (:163-166).
 //
 // One 512-thread block per image pair does the whole loop: three strided reduction passes over the inliers
-// (centroids; mean distances; the 45 distinct entries of Y^T Y), the 9x9 eigen-solve + rank-2 projection on wave 0,
+// (centroids; mean distances; the 45 distinct entries of Y^T Y), the smallest eigenvector of Y^T Y by inverse iteration
+// on a Cholesky factor + rank-2 projection on wave 0,
 // one scoring pass over all N points, and — if accepted — one pass rewriting the mask.  N <= 50k points x 32 B is
 // L2-resident; the kernel is latency-bound and runs once per RANSAC call, off the headline path.
 #include <hip/hip_runtime.h>
@@ -131,10 +132,11 @@ __global__ __launch_bounds__(kThreads) void refine_kernel(
         // eigen-solve + rank 2 + un-normalise: every lane of wave 0 runs the same problem (the Jacobi sweeps are
         // wave-uniform loops); lane 0 publishes
         if (tid < kWave) {
-            double yty[45], f[9], w[9], second;
+            double yty[45], f[9];
 #pragma unroll
             for (int k = 0; k < 45; ++k) yty[k] = total[k];
-            const int flag = sfmfit::null_vector_of_yty(yty, f, w, second);
+            const int flag = sfmfit::eigenvalues_below9(yty, 1e-10) >= 2 ? SFM_FIT_DEGENERATE : 0;
+            sfmfit::smallest_eigenvector_psd9(yty, f);
             double fr[3][3], e[9];
             sfmfit::enforce_rank2(f, fr);
             sfmfit::unnormalise(fr, t1, t2, e);
