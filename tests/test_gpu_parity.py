@@ -415,6 +415,31 @@ def test_triangulate_large_vs_oracle(dev):
     assert np.max(np.abs(got - want) / np.linalg.norm(want, axis=1, keepdims=True)) <= 1e-9
 
 
+def test_triangulate_mixed_waves_with_outliers(dev):
+    """30 % gross outliers: waves mix lanes whose inverse iteration converges in three steps with lanes that never
+    converge, so the QR route and the per-wave Jacobi fallback both run and their results are merged per lane.
+    Inliers must match the oracle's SVD point for point; for the outliers (sigma_3 ~ sigma_4: the point itself is
+    ill-determined) the returned vector must still be a minimiser: |A x| / |x| == sigma_4."""
+    n = 20000
+    pa, pb, K, R, t, is_out = orc.synthetic_two_view(n, seed=31, outlier_fraction=0.3)
+    T = np.eye(4)
+    T[:3, :3], T[:3, 3] = R, t
+    K_ext = np.hstack((K, np.zeros((3, 1))))
+    P1, P2 = K_ext @ np.eye(4), K_ext @ T
+    corr = orc.pack_correspondences(pa, pb)
+    got = dev.triangulate(dev.to_device(corr), dev.to_device(P1.reshape(12)), dev.to_device(P2.reshape(12))).cpu().numpy()
+    want = orc.triangulate_points(pa, pb, K, T)
+    inl = ~is_out
+    assert np.max(np.abs(got[inl] - want[inl]) / np.linalg.norm(want[inl], axis=1, keepdims=True)) <= 1e-9
+    A = orc.dlt_matrix(corr, P1[:3], P2[:3])                       # (n, 4, 4)
+    x = np.concatenate([got, np.ones((n, 1))], axis=1)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    residual = np.linalg.norm(np.einsum("nij,nj->ni", A, x), axis=1)
+    sv = np.linalg.svd(A, compute_uv=False)
+    assert np.all(np.isfinite(got))
+    assert np.max(np.abs(residual - sv[:, 3]) / sv[:, 0]) <= 1e-9
+
+
 # ------------------------------------------------------------------------------------------------------
 # sharding: G virtual shards on one GPU through the sharded engine == one run over all hypotheses
 # ------------------------------------------------------------------------------------------------------
