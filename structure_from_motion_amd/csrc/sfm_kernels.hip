@@ -107,7 +107,7 @@ __global__ void sample_philox_at_kernel(uint64_t seed, uint64_t seed_stride,
 constexpr int kTraceDoubles = 16 + 16 + 3 + 3 + 81 + 9 + 9 + 9;
 
 template <bool TRACE>
-__global__ __launch_bounds__(kWave) void fit_eight_point_kernel(
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) void fit_eight_point_kernel(
     const Corr* __restrict__ corr, int64_t n, const int32_t* __restrict__ S, int64_t h_count,
     double* __restrict__ E, int32_t* __restrict__ flags, double* __restrict__ lambda2,
     double* __restrict__ trace) {
