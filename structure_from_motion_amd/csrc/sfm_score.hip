@@ -450,14 +450,28 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
     const Corr* __restrict__ corr, const unsigned char* __restrict__ ws, int n,
     const double* __restrict__ E, const int32_t* __restrict__ S, int h_count, double thr, double a_scale,
     const int32_t* __restrict__ order, int32_t* __restrict__ cnt, double* __restrict__ s1,
-    double* __restrict__ s2) {
+    double* __restrict__ s2, int batch, int blocks_per_pair) {
     __shared__ __attribute__((aligned(1024))) int32_t ring[256 / kWave][HPW][kRing];  // each ring = one aligned KiB
     const int lane = threadIdx.x & (kWave - 1);
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
-    const int wave = blockIdx.x * (256 / kWave) + wave_in_block;
+    // XCD-aware block -> (pair, block of the pair) map.  Workgroups are dealt round-robin over the 8 XCDs by linear
+    // id, each XCD with its own 4 MiB L2.  Every block of a pair re-reads that pair's points (fp32 copy for tier 1,
+    // fp64 records gathered by tier 2: ~0.5 MB at N = 10k), so all blocks of a pair get ids of ONE residue class
+    // mod 8: eight pairs are in flight at a time, one per L2, instead of every L2 holding a slice of every pair.
+    int block_of_pair, pair;
+    if (batch > 1 && blocks_per_pair > 0) {
+        const int label = blockIdx.x & 7, j = blockIdx.x >> 3;
+        pair = (j / blocks_per_pair) * 8 + label;
+        block_of_pair = j % blocks_per_pair;
+        if (pair >= batch) return;  // padding of the last group of eight
+    } else {  // one pair, or a grid too large to flatten: plain (block, pair) grid
+        pair = blockIdx.y;
+        block_of_pair = blockIdx.x;
+    }
+    const int wave = block_of_pair * (256 / kWave) + wave_in_block;
     const int h0 = wave * HPW;  // first of this wave's HPW slots in the processing order
     if (h0 >= h_count) return;
-    const int64_t b = blockIdx.y;
+    const int64_t b = pair;
     // slot -> hypothesis index (longest-first order from the pre-pass, or the identity)
     // With an order, the list (heaviest first) is dealt column-major over the waves: wave w takes entries
     // w, W + w, 2W + w, 3W + w (W = number of waves), i.e. one heavy and progressively lighter hypotheses, so
@@ -477,7 +491,7 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
     const int32_t* __restrict__ Sb = S + b * (int64_t)h_count * 8;
     const uint32_t* maxima = reinterpret_cast<const uint32_t*>(ws + 16 * b);
     const float4* __restrict__ pts32 =
-        reinterpret_cast<const float4*>(ws + ws_points_offset(gridDim.y)) + b * (int64_t)n;
+        reinterpret_cast<const float4*>(ws + ws_points_offset(batch)) + b * (int64_t)n;
 
     // data-set coordinate maxima, inflated so they also bound the unrounded fp64 coordinates
     const float Xa = __uint_as_float(maxima[0]) * (1.0f + 1e-6f);
@@ -688,12 +702,17 @@ int launch_filtered(const FilteredLaunch& a) {
         if (rc != SFM_OK) return rc;
         order_arg = a.order;
     }
+    const int64_t flat_blocks = (int64_t)grid.x * ((a.batch + 7) / 8 * 8);
+    static const bool xcd_env = getenv("SFM_SCORE_XCD") ? atoi(getenv("SFM_SCORE_XCD")) != 0 : true;
+    const bool remap = xcd_env && a.batch > 1 && flat_blocks <= 0x7FFFFFFF;  // see the kernel's block -> (pair, block) map
+    const int blocks_per_pair = remap ? (int)grid.x : 0;
+    const dim3 flat = remap ? dim3((unsigned)flat_blocks) : grid;
     if (a.one_sided)
-        hipLaunchKernelGGL((score_sed_filtered_kernel<HPW, true>), grid, dim3(256), 0, a.st, a.corr, a.ws, a.n, a.E, a.S,
-                           a.h_count, a.thr, a.a_scale, order_arg, a.cnt, a.s1, a.s2);
+        hipLaunchKernelGGL((score_sed_filtered_kernel<HPW, true>), flat, dim3(256), 0, a.st, a.corr, a.ws, a.n, a.E, a.S,
+                           a.h_count, a.thr, a.a_scale, order_arg, a.cnt, a.s1, a.s2, (int)a.batch, blocks_per_pair);
     else
-        hipLaunchKernelGGL((score_sed_filtered_kernel<HPW, false>), grid, dim3(256), 0, a.st, a.corr, a.ws, a.n, a.E, a.S,
-                           a.h_count, a.thr, a.a_scale, order_arg, a.cnt, a.s1, a.s2);
+        hipLaunchKernelGGL((score_sed_filtered_kernel<HPW, false>), flat, dim3(256), 0, a.st, a.corr, a.ws, a.n, a.E, a.S,
+                           a.h_count, a.thr, a.a_scale, order_arg, a.cnt, a.s1, a.s2, (int)a.batch, blocks_per_pair);
     return check_launch("score_sed_filtered_kernel");
 }
 
