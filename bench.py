@@ -92,6 +92,19 @@ def cpu_baseline(corr: np.ndarray, seed: int, target_seconds: float):
     }
 
 
+def measured_valu(n, h):
+    """VALU-issue evidence for the dominant kernel from the committed PMC summary (the bound that actually holds:
+    the data set is cache-resident) — None for other workload sizes."""
+    path = os.path.join(REPO, "profiles", "score_traffic.json")
+    try:
+        rec = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    if rec.get("matches") != n or rec.get("hypotheses") != h:
+        return None
+    return rec.get("valu")
+
+
 def measured_traffic(n, h):
     """HBM bytes per score-kernel launch from the committed rocprofv3 PMC passes (profiles/), if they were
     taken on this workload: 2 x FETCH_SIZE (gfx950 counts 128-B requests as 64 B) + WRITE_SIZE."""
@@ -218,6 +231,7 @@ def main():
                 "traffic": measured_traffic(n, h),
                 "traffic_unit": "bytes per launch (rocprofv3 PMC: 2 x FETCH_SIZE + WRITE_SIZE, profiles/)",
                 "algorithmic_bytes": evals_per_gpu * BYTES_PER_EVAL,
+                "valu_issue": measured_valu(n, h),
                 "kernel_variant": os.environ.get("SFM_SCORE_KERNEL", "filtered"),
                 "kernel_ms": score_ms,
                 "note": "achieved = 32 B/eval x matches x hypotheses / avg score-kernel time (HIP events); "
