@@ -80,6 +80,12 @@ int sfm_sample_philox_at(uint64_t seed, uint64_t seed_stride, const int64_t* h_i
 int sfm_fit_eight_point(const double* corr, int64_t n, const int32_t* S, int64_t h_count, int64_t batch,
                         double* E, int32_t* flags, double* lambda2, void* stream);
 
+/* sfm_sample_philox (or, with seed_dev != NULL, sfm_sample_philox_dev) and sfm_fit_eight_point in ONE launch: the fit
+ * kernel draws each hypothesis' sample itself and also stores it in S.  Same S, E, flags as the two calls. */
+int sfm_sample_fit_philox(uint64_t seed, const uint64_t* seed_dev, uint64_t seed_stride, int64_t h_begin,
+                          const double* corr, int64_t n, int64_t h_count, int64_t batch, int32_t* S, double* E,
+                          int32_t* flags, void* stream);
+
 /* The same fit with its intermediates written out, for parity checks of the fused stages against the
  * reference's private helpers (_normalize_coords :308-338, _get_yT_y :363-375, _compute_f_est :396-427,
  * _enforce_fundamental_mat_constraints :430-446).  trace: dev [batch,h_count,sfm_fit_trace_doubles()] doubles:

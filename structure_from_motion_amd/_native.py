@@ -41,6 +41,7 @@ SIGNATURES = {
     "sfm_normalize_correspondences": [_P, _P, _I64, _D, _D, _D, _D, _P, _P],
     "sfm_sample_philox": [_U64, _U64, _I64, _I64, _I64, _I64, _P, _P],
     "sfm_refine_inliers": [_P, _I64, _I64, _P, _P, _P, _D, C.c_int, C.c_int, _P, _P, _P, _P],
+    "sfm_sample_fit_philox": [_U64, _P, _U64, _I64, _P, _I64, _I64, _I64, _P, _P, _P, _P],
     "sfm_sample_philox_dev": [_P, _U64, _I64, _I64, _I64, _I64, _P, _P],
     "sfm_sample_philox_at": [_U64, _U64, _P, _I64, _I64, _P, _P],
     "sfm_fit_eight_point": [_P, _I64, _P, _I64, _I64, _P, _P, _P, _P],

@@ -73,8 +73,7 @@ class TwoViewBatch:
         ws = self.ws
         self._pix, self._K = (pix_a, pix_b), np.ascontiguousarray(K, dtype=np.float64)
         device.normalize_correspondences(pix_a, pix_b, K, out=self.corr)
-        device.sample_philox(seed, 0, self.h, N, batch=B, seed_stride=seed_stride, out=ws.S)
-        ws.run(self.corr, thr, min_extra, aggregation)
+        ws.run(self.corr, thr, min_extra, aggregation, philox=(seed, 0, seed_stride))
         # winner's E and first sample index per pair (torch indexing = device memory plumbing only)
         best = ws.result[:, 1].clamp(min=0)
         rows = torch.arange(B, device=best.device)

@@ -106,18 +106,42 @@ __global__ void sample_philox_at_kernel(uint64_t seed, uint64_t seed_stride,
 // T2 {scale,cx,cy} | Y^T Y full [9][9] | eigenvalues [9] | f_est [9] | rank-2 F [9]
 constexpr int kTraceDoubles = 16 + 16 + 3 + 3 + 81 + 9 + 9 + 9;
 
+// Where the eight sample indices of a hypothesis come from: the table S (enabled == 0), or the Philox sampler run
+// inside the fit kernel, which then also fills S (one launch instead of two; a small RANSAC pass is a chain of
+// ~4 us kernels).  `seed_dev`, if not NULL, supplies the seed from device memory (graph replay).
+struct PhiloxSource {
+    const uint64_t* seed_dev;
+    uint64_t seed, seed_stride;
+    int64_t h_begin;
+    int enabled;
+};
+
 template <bool TRACE>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) void fit_eight_point_kernel(
-    const Corr* __restrict__ corr, int64_t n, const int32_t* __restrict__ S, int64_t h_count,
+    const Corr* __restrict__ corr, int64_t n, int32_t* __restrict__ S, int64_t h_count,
     double* __restrict__ E, int32_t* __restrict__ flags, double* __restrict__ lambda2,
-    double* __restrict__ trace) {
+    double* __restrict__ trace, PhiloxSource philox) {
     const int64_t b = blockIdx.y;
     const int64_t h_raw = (int64_t)blockIdx.x * kWave + threadIdx.x;
     const bool active = h_raw < h_count;
     // inactive tail lanes redo the last hypothesis so the wave-uniform Jacobi loops stay convergent
     const int64_t h = active ? h_raw : h_count - 1;
     const Corr* pts = corr + b * n;
-    const int32_t* sample = S + (b * h_count + h) * 8;
+    int32_t sample[8];
+    if (philox.enabled) {  // wave-uniform
+        const uint64_t seed = (philox.seed_dev != nullptr ? philox.seed_dev[0] : philox.seed) + (uint64_t)b * philox.seed_stride;
+        sfm::philox_sample8(seed, (uint64_t)(philox.h_begin + h), (uint32_t)n, sample);
+        if (active) {
+            int4* dst = reinterpret_cast<int4*>(S + (b * h_count + h) * 8);
+            dst[0] = make_int4(sample[0], sample[1], sample[2], sample[3]);
+            dst[1] = make_int4(sample[4], sample[5], sample[6], sample[7]);
+        }
+    } else {
+        const int4* src = reinterpret_cast<const int4*>(S + (b * h_count + h) * 8);
+        const int4 lo = src[0], hi = src[1];
+        sample[0] = lo.x; sample[1] = lo.y; sample[2] = lo.z; sample[3] = lo.w;
+        sample[4] = hi.x; sample[5] = hi.y; sample[6] = hi.z; sample[7] = hi.w;
+    }
 
     double xa[8], ya[8], xb[8], yb[8];
 #pragma unroll
@@ -710,9 +734,22 @@ int sfm_fit_eight_point(const double* corr, int64_t n, const int32_t* S, int64_t
     if (h_count == 0 || batch == 0) return SFM_OK;
     if (!corr || !S || !E || !flags) return fail(SFM_EINVAL, "sfm_fit_eight_point: null pointer");
     hipLaunchKernelGGL(fit_eight_point_kernel<false>, dim3(grid_for(h_count, kWave), (unsigned)batch),
-                       dim3(kWave), 0, (hipStream_t)stream, (const Corr*)corr, n, S, h_count, E, flags,
-                       lambda2, (double*)nullptr);
+                       dim3(kWave), 0, (hipStream_t)stream, (const Corr*)corr, n, const_cast<int32_t*>(S), h_count, E,
+                       flags, lambda2, (double*)nullptr, PhiloxSource{nullptr, 0, 0, 0, 0});
     return check_launch("fit_eight_point_kernel");
+}
+
+int sfm_sample_fit_philox(uint64_t seed, const uint64_t* seed_dev, uint64_t seed_stride, int64_t h_begin,
+                          const double* corr, int64_t n, int64_t h_count, int64_t batch, int32_t* S, double* E,
+                          int32_t* flags, void* stream) {
+    if (h_count < 0 || batch < 0 || h_begin < 0) return fail(SFM_EINVAL, "sfm_sample_fit_philox: negative size");
+    if (n < 8 || n > 0x7FFFFFFF) return fail(SFM_EINVAL, "sfm_sample_fit_philox: need 8 <= n < 2^31");
+    if (h_count == 0 || batch == 0) return SFM_OK;
+    if (!corr || !S || !E || !flags) return fail(SFM_EINVAL, "sfm_sample_fit_philox: null pointer");
+    hipLaunchKernelGGL(fit_eight_point_kernel<false>, dim3(grid_for(h_count, kWave), (unsigned)batch),
+                       dim3(kWave), 0, (hipStream_t)stream, (const Corr*)corr, n, S, h_count, E, flags,
+                       (double*)nullptr, (double*)nullptr, PhiloxSource{seed_dev, seed, seed_stride, h_begin, 1});
+    return check_launch("fit_eight_point_kernel (philox)");
 }
 
 int sfm_fit_trace_doubles(void) { return kTraceDoubles; }
@@ -724,8 +761,8 @@ int sfm_fit_eight_point_traced(const double* corr, int64_t n, const int32_t* S, 
     if (h_count == 0 || batch == 0) return SFM_OK;
     if (!corr || !S || !E || !flags || !trace) return fail(SFM_EINVAL, "sfm_fit_eight_point_traced: null pointer");
     hipLaunchKernelGGL(fit_eight_point_kernel<true>, dim3(grid_for(h_count, kWave), (unsigned)batch),
-                       dim3(kWave), 0, (hipStream_t)stream, (const Corr*)corr, n, S, h_count, E, flags,
-                       (double*)nullptr, trace);
+                       dim3(kWave), 0, (hipStream_t)stream, (const Corr*)corr, n, const_cast<int32_t*>(S), h_count, E,
+                       flags, (double*)nullptr, trace, PhiloxSource{nullptr, 0, 0, 0, 0});
     return check_launch("fit_eight_point_kernel<trace>");
 }
 

@@ -204,7 +204,9 @@ __global__ void score_prepare_kernel(const Corr* __restrict__ corr, int64_t n, d
     if (threadIdx.x < 4) {
         const float m = fmaxf(fmaxf(part[0][threadIdx.x], part[1][threadIdx.x]),
                               fmaxf(part[2][threadIdx.x], part[3][threadIdx.x]));
-        atomicMax(maxima + threadIdx.x, __float_as_uint(m));
+        // a single block per pair owns the result: plain store, and the launcher skips the zeroing kernel
+        if (gridDim.x == 1) maxima[threadIdx.x] = __float_as_uint(m);
+        else atomicMax(maxima + threadIdx.x, __float_as_uint(m));
     }
 }
 
@@ -748,14 +750,6 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
     unsigned char* ws = static_cast<unsigned char*>(workspace);
     int32_t* buckets = reinterpret_cast<int32_t*>(ws + ws_buckets_offset(n, batch));
     int32_t* order = reinterpret_cast<int32_t*>(ws + ws_order_offset(n, batch));
-    hipLaunchKernelGGL(score_reset_kernel, dim3((unsigned)batch), dim3(256), 0, st, ws, buckets);
-    // SFM_SCORE_ONE_SIDED=0 switches tier 1 back to the two-sided test (ablation)
-    static const bool one_sided = getenv("SFM_SCORE_ONE_SIDED") ? atoi(getenv("SFM_SCORE_ONE_SIDED")) != 0 : true;
-    const double a_scale = one_sided ? one_sided_scale(thr) : 1.0;
-    hipLaunchKernelGGL(score_prepare_kernel, dim3(grid_for(n, 256, 64), (unsigned)batch), dim3(256), 0, st,
-                       (const Corr*)corr, n, a_scale, ws);
-    int rc = check_launch("score_prepare_kernel");
-    if (rc != SFM_OK) return rc;
     // longest-first processing order (cost pre-pass + counting sort); SFM_SCORE_ORDER=0 keeps index order
     // It pays only when the launch has few generations of waves (a long wave starting late then idles the chip at
     // the end): 256 CUs x 20 resident waves = 5120 per generation; beyond ~12 generations the tail is negligible
@@ -763,6 +757,18 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
     const int order_env = getenv("SFM_SCORE_ORDER") ? atoi(getenv("SFM_SCORE_ORDER")) : -1;
     // ... and its fixed cost (~25 us) needs enough points per hypothesis to be won back (measured break-even ~8k).
     const bool use_order = order_env >= 0 ? order_env != 0 : (waves * batch <= 12 * 5120 && n >= 8192);
+    // Small point sets are prepared by one block per pair, which stores the maxima itself; the zeroing kernel is then
+    // only needed for the class counters of the ordering pre-pass (a small pass is a chain of ~4 us launches).
+    const unsigned prepare_blocks = n <= 8192 ? 1u : grid_for(n, 256, 64);
+    if (use_order || prepare_blocks > 1)
+        hipLaunchKernelGGL(score_reset_kernel, dim3((unsigned)batch), dim3(256), 0, st, ws, buckets);
+    // SFM_SCORE_ONE_SIDED=0 switches tier 1 back to the two-sided test (ablation)
+    static const bool one_sided = getenv("SFM_SCORE_ONE_SIDED") ? atoi(getenv("SFM_SCORE_ONE_SIDED")) != 0 : true;
+    const double a_scale = one_sided ? one_sided_scale(thr) : 1.0;
+    hipLaunchKernelGGL(score_prepare_kernel, dim3(prepare_blocks, (unsigned)batch), dim3(256), 0, st,
+                       (const Corr*)corr, n, a_scale, ws);
+    int rc = check_launch("score_prepare_kernel");
+    if (rc != SFM_OK) return rc;
     // hypotheses per wave: 4 amortises the point loads best, but a launch with fewer waves than the chip holds
     // (5120) leaves SIMDs idle — then fewer hypotheses per wave = more waves wins (SFM_SCORE_HPW overrides)
     const int hpw_env = getenv("SFM_SCORE_HPW") ? atoi(getenv("SFM_SCORE_HPW")) : 0;

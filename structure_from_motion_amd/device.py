@@ -118,6 +118,19 @@ TRACE_FIELDS = {  # name -> (offset, shape) inside one trace record of sfm_fit_e
 }
 
 
+def sample_fit_philox(corr: torch.Tensor, seed, h_begin: int, S: torch.Tensor, E: torch.Tensor, flags: torch.Tensor,
+                      seed_stride: int = 1) -> None:
+    """Philox sampling and the eight-point fit in one launch (fills S, E, flags).  ``seed``: an int, or an int64
+    device tensor whose first word is read at kernel run time (graph replay)."""
+    lib = _native.load()
+    B, N, _ = corr.shape
+    H = S.shape[1]
+    on_device = isinstance(seed, torch.Tensor)
+    check(lib.sfm_sample_fit_philox(0 if on_device else seed & (2**64 - 1), _ptr(seed) if on_device else None,
+                                    seed_stride, h_begin, _ptr(corr), N, H, B, _ptr(S), _ptr(E), _ptr(flags),
+                                    _stream()), "sfm_sample_fit_philox")
+
+
 def fit_eight_point_traced(corr: torch.Tensor, S: torch.Tensor):
     """corr [B,N,4], S [B,H,8] -> E [B,H,9], flags [B,H], dict of intermediate arrays (numpy, [B,H,...])."""
     lib = _native.load()
@@ -378,9 +391,15 @@ class RansacWorkspace:
         self.score_ws = score_workspace(n, h, batch, dev)
 
     def run(self, corr: torch.Tensor, thr: float, min_extra: float, aggregation: int,
-            h_offset: int = 0, with_mask: bool = True) -> None:
-        """fit + score + select (+ mask) for the sample table currently in ``self.S``."""
-        fit_eight_point(corr, self.S, self.E, self.flags)
+            h_offset: int = 0, with_mask: bool = True, philox=None) -> None:
+        """fit + score + select (+ mask) for the sample table currently in ``self.S`` — or, with
+        ``philox=(seed, h_begin, seed_stride)``, for Philox samples drawn inside the fit kernel (which also fills
+        ``self.S``); ``seed`` may be an int64 device tensor (read at kernel run time)."""
+        if philox is None:
+            fit_eight_point(corr, self.S, self.E, self.flags)
+        else:
+            seed, h_begin, seed_stride = philox
+            sample_fit_philox(corr, seed, h_begin, self.S, self.E, self.flags, seed_stride)
         score_sed(corr, self.E, self.S, thr, self.cnt, self.s1, self.s2, workspace=self.score_ws)
         select_best(self.cnt, self.s1, self.s2, self.flags, min_extra, aggregation, h_offset,
                     self.result)

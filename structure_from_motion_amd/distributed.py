@@ -108,17 +108,14 @@ class ShardedRansac:
     def _local_pass(self, seed) -> None:
         """sample -> fit -> score -> select on this rank's shard (+ mask when the winner is local).
         ``seed=None`` reads the seed from ``self.seed_dev`` (the form a HIP graph can replay)."""
-        d = self.device_api
         begin = self.rank * self.h
-        if seed is None:
-            d.sample_philox_dev(self.seed_dev, begin, self.h, self.n, out=self.ws.S)
-        else:
-            d.sample_philox(seed, begin, self.h, self.n, out=self.ws.S)
+        source = (self.seed_dev if seed is None else seed, begin, 1)  # sampled inside the fit kernel
         if self.world == 1:
             # single GPU: the winner is local — mask straight from the shard's own E / S
-            self.ws.run(self.corr, self.thr, self.min_extra, self.aggregation, h_offset=0, with_mask=True)
+            self.ws.run(self.corr, self.thr, self.min_extra, self.aggregation, h_offset=0, with_mask=True, philox=source)
         else:
-            self.ws.run(self.corr, self.thr, self.min_extra, self.aggregation, h_offset=begin, with_mask=False)
+            self.ws.run(self.corr, self.thr, self.min_extra, self.aggregation, h_offset=begin, with_mask=False,
+                        philox=source)
 
     def capture(self) -> None:
         """Record the local pass once into a HIP graph; later ``step`` calls rewrite one seed word in device

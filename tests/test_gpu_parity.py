@@ -54,6 +54,23 @@ def test_philox_batch_seeds(dev):
         np.testing.assert_array_equal(got[b], orc.philox_sample_table(6 + b, 0, 64, 500))
 
 
+def test_fused_sample_and_fit_equals_separate_calls(dev):
+    """sfm_sample_fit_philox == sfm_sample_philox (or _dev) followed by sfm_fit_eight_point: same S, E bit for bit."""
+    B, n, h = 3, 700, 333
+    corr = torch.stack([dev.to_device(scene(n, seed=20 + b)[3]) for b in range(B)])
+    for seed_arg, seed, h_begin, stride in ((41, 41, 0, 1), (2**63 + 5, 2**63 + 5, 1000, 7), ("dev", 9, 12, 2)):
+        S_ref = dev.sample_philox(seed, h_begin, h, n, batch=B, seed_stride=stride)
+        E_ref, f_ref = dev.fit_eight_point(corr, S_ref)
+        S = torch.zeros_like(S_ref)
+        E = torch.zeros_like(E_ref)
+        flags = torch.full_like(f_ref, -1)
+        arg = torch.tensor([seed], dtype=torch.int64, device=corr.device) if seed_arg == "dev" else seed_arg
+        dev.sample_fit_philox(corr, arg, h_begin, S, E, flags, seed_stride=stride)
+        np.testing.assert_array_equal(S.cpu().numpy(), S_ref.cpu().numpy())
+        np.testing.assert_array_equal(E.cpu().numpy(), E_ref.cpu().numpy())
+        np.testing.assert_array_equal(flags.cpu().numpy(), f_ref.cpu().numpy())
+
+
 def test_sed_values_bit_exact(dev, golden):
     rng = np.random.default_rng(0)
     _, _, _, corr = scene(3000)
