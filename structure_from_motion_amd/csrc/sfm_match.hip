@@ -76,6 +76,26 @@ __global__ void patch_extract_kernel(const double* __restrict__ image, int64_t h
     ok[i] = 1;
 }
 
+// XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (each with its own 4 MiB L2) by linear id.
+// With a plain (B tile, A tile) grid every XCD touches every B tile for every A row: 2.1 GB of fetches at
+// 20k x 20k for 26 MB of patches.  Here the 1-D block id is decoded so that each residue class mod 8 — one XCD —
+// owns a contiguous band of A tiles and walks the B tiles with its band as the inner loop: a B tile (83 KB) serves
+// the whole band while it is L2-resident, and the band's A tiles (~1.7 MB) stay resident throughout.
+struct TileCoord {
+    int64_t a_tile, b_tile;
+    bool valid;
+};
+SFM_DEVICE TileCoord decode_tile(int64_t tiles_a, int64_t tiles_b) {
+    const int64_t band = (tiles_a + 7) / 8;  // A tiles per XCD
+    const int64_t label = blockIdx.x & 7, j = blockIdx.x >> 3;
+    TileCoord t;
+    t.a_tile = label * band + j % band;
+    t.b_tile = j / band;
+    t.valid = t.a_tile < tiles_a && t.b_tile < tiles_b;
+    return t;
+}
+inline unsigned tile_grid(int64_t tiles_a, int64_t tiles_b) { return (unsigned)(8 * ((tiles_a + 7) / 8) * tiles_b); }
+
 // Tile core shared by the score-matrix kernel and the fused summary kernel.  A 256-thread block owns a
 // kTileA x kTileB tile; lane (ty, tx) accumulates rows a0 + ty*8 + i (i < 8) against columns
 // b0 + g*32 + tx*2 + j (g < 4, j < 2): its B operands are four 16-byte LDS reads at consecutive-lane addresses
@@ -170,7 +190,9 @@ __global__ __launch_bounds__(256, 2) void pair_scores_kernel(
     __shared__ double sA[kChunk][kTileA];
     __shared__ double sB[kChunk][kTileB];
     const int ty = threadIdx.x / 16, tx = threadIdx.x % 16;
-    const int64_t a0 = (int64_t)blockIdx.y * kTileA, b0 = (int64_t)blockIdx.x * kTileB;
+    const TileCoord tile = decode_tile((nA + kTileA - 1) / kTileA, (nB + kTileB - 1) / kTileB);
+    if (!tile.valid) return;  // whole block
+    const int64_t a0 = tile.a_tile * kTileA, b0 = tile.b_tile * kTileB;
     double acc[kRowsPerLane][kColsPerLane];
     tile_accumulate<MODE, DIRECT>(Pa, stride_a, Pb, stride_b, nA, nB, K, a0, b0, sA, sB, acc);
 #pragma unroll
@@ -312,7 +334,9 @@ __global__ __launch_bounds__(256, 2) void pair_summary_kernel(
     __shared__ double sA[kChunk][kTileA];
     __shared__ double sB[kChunk][kTileB];
     const int ty = threadIdx.x / 16, tx = threadIdx.x % 16;
-    const int64_t a0 = (int64_t)blockIdx.y * kTileA, b0 = (int64_t)blockIdx.x * kTileB;
+    const TileCoord tile = decode_tile((nA + kTileA - 1) / kTileA, (nB + kTileB - 1) / kTileB);
+    if (!tile.valid) return;  // whole block
+    const int64_t a0 = tile.a_tile * kTileA, b0 = tile.b_tile * kTileB;
     double acc[kRowsPerLane][kColsPerLane];
     tile_accumulate<MODE, DIRECT>(Pa, stride_a, Pb, stride_b, nA, nB, K, a0, b0, sA, sB, acc);
     // Per-column and per-row operands of this lane's 8 x 8 block, fetched in one batch: unconditional loads at
@@ -388,7 +412,7 @@ __global__ __launch_bounds__(256, 2) void pair_summary_kernel(
                 }
                 r.left_prefixed = left_prefixed;
                 r.left_min = left_min;
-                tiles[(int64_t)blockIdx.x * nA + ia] = r;
+                tiles[tile.b_tile * nA + ia] = r;
             }
             continue;
         }
@@ -439,7 +463,7 @@ __global__ __launch_bounds__(256, 2) void pair_summary_kernel(
             r.left_prefixed = left_prefixed;
             r.left_min = left_min;
             r.tile_arg = top.i;
-            tiles[(int64_t)blockIdx.x * nA + ia] = r;
+            tiles[tile.b_tile * nA + ia] = r;
         }
     }
 }
@@ -497,7 +521,9 @@ int sfm_pair_scores(int metric, const double* patches_a, int64_t stride_a, const
     if (n_a == 0 || n_b == 0) return SFM_OK;
     if (!patches_a || !patches_b || !ssq_a || !ssq_b || !ok_a || !ok_b || !scores)
         return fail(SFM_EINVAL, "sfm_pair_scores: null pointer");
-    const dim3 grid(grid_for(n_b, kTileB), grid_for(n_a, kTileA));
+    const int64_t tiles_a = (n_a + kTileA - 1) / kTileA, tiles_b = (n_b + kTileB - 1) / kTileB;
+    if (8 * ((tiles_a + 7) / 8) * tiles_b > 0x7FFFFFFF) return fail(SFM_EINVAL, "sfm_pair_scores: too many tiles");
+    const dim3 grid(tile_grid(tiles_a, tiles_b));
     const bool direct = direct_staging_ok(patches_a, stride_a, n_a) && direct_staging_ok(patches_b, stride_b, n_b);
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, grid, dim3(256), 0, (hipStream_t)stream, patches_a, stride_a, patches_b, stride_b,
@@ -532,8 +558,9 @@ int sfm_match_summary(int metric, const double* patches_a, int64_t stride_a, con
     if ((reinterpret_cast<uintptr_t>(workspace) & 15u) != 0)
         return fail(SFM_EINVAL, "sfm_match_summary: workspace must be 16-byte aligned");
     const int64_t n_tiles = (n_b + kTileB - 1) / kTileB;
-    if (grid_for(n_a, kTileA) > 65535u) return fail(SFM_EINVAL, "sfm_match_summary: too many A features");
-    const dim3 grid((unsigned)n_tiles, grid_for(n_a, kTileA));
+    const int64_t tiles_a = (n_a + kTileA - 1) / kTileA;
+    if (8 * ((tiles_a + 7) / 8) * n_tiles > 0x7FFFFFFF) return fail(SFM_EINVAL, "sfm_match_summary: too many tiles");
+    const dim3 grid(tile_grid(tiles_a, n_tiles));
     TileSummary* tiles = static_cast<TileSummary*>(workspace);
     hipStream_t st = (hipStream_t)stream;
     const bool direct = direct_staging_ok(patches_a, stride_a, n_a) && direct_staging_ok(patches_b, stride_b, n_b);
