@@ -1,6 +1,6 @@
 """Diagnostic: dump device fit results for offline accuracy analysis (vs mpmath)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import sfm_oracle as orc
 from structure_from_motion_amd import device as dev

@@ -1,7 +1,7 @@
 """Brute-force NCC matcher timing (reference apps/sfm.py:73-87 shape: 600 x 600 corners, window 9) and a
 large case; the numpy oracle is timed beside it on a bounded sample."""
 import os, sys, time, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from structure_from_motion_amd import device as dev
 from structure_from_motion_amd.feature_matching import _device_match
