@@ -457,6 +457,51 @@ def test_triangulate_mixed_waves_with_outliers(dev):
     assert np.max(np.abs(residual - sv[:, 3]) / sv[:, 0]) <= 1e-9
 
 
+def test_triangulate_random_geometries(dev):
+    """40 random camera pairs (baselines from 1 % to 200 % of the scene depth, rotations up to 60 degrees, focal
+    lengths 300..3000 px, noise 0..2 px): every returned point is a minimiser of |A x| (== sigma_4 of the DLT matrix,
+    LAPACK) and well-conditioned points agree with the SVD solution to 1e-9."""
+    rng = np.random.default_rng(12)
+    n = 1500
+    for trial in range(40):
+        f = rng.uniform(300, 3000)
+        K = np.array([[f, 0, 320.0], [0, f * rng.uniform(0.9, 1.1), 240.0], [0, 0, 1.0]])
+        axis = rng.normal(size=3)
+        axis /= np.linalg.norm(axis)
+        ang = rng.uniform(0, np.pi / 3)
+        Kx = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+        R = np.eye(3) + np.sin(ang) * Kx + (1 - np.cos(ang)) * Kx @ Kx
+        depth = rng.uniform(2, 20)
+        t = rng.normal(size=3)
+        t *= depth * 10.0 ** rng.uniform(-2, 0.3) / np.linalg.norm(t)
+        X = np.column_stack([rng.uniform(-1, 1, n) * depth / 3, rng.uniform(-1, 1, n) * depth / 3,
+                             rng.uniform(0.7, 1.3, n) * depth])
+        T = np.eye(4)
+        T[:3, :3], T[:3, 3] = R, t
+        K_ext = np.hstack((K, np.zeros((3, 1))))
+        P1, P2 = K_ext @ np.eye(4), K_ext @ T
+        Xh = np.column_stack([X, np.ones(n)])
+        pa = (P1 @ Xh.T).T
+        pb = (P2 @ Xh.T).T
+        noise = rng.uniform(0, 2)
+        pa = pa[:, :2] / pa[:, 2:3] + rng.normal(scale=noise + 1e-12, size=(n, 2))
+        pb = pb[:, :2] / pb[:, 2:3] + rng.normal(scale=noise + 1e-12, size=(n, 2))
+        corr = orc.pack_correspondences(pa, pb)
+        got = dev.triangulate(dev.to_device(corr), dev.to_device(P1.reshape(12)), dev.to_device(P2.reshape(12))).cpu().numpy()
+        A = orc.dlt_matrix(corr, P1[:3], P2[:3])
+        u, sv, vt = np.linalg.svd(A)
+        x = np.column_stack([got, np.ones(n)])
+        finite = np.all(np.isfinite(x), axis=1)
+        assert finite.mean() > 0.999
+        xn = x[finite] / np.linalg.norm(x[finite], axis=1, keepdims=True)
+        residual = np.linalg.norm(np.einsum("nij,nj->ni", A[finite], xn), axis=1)
+        assert np.max(np.abs(residual - sv[finite, 3]) / sv[finite, 0]) <= 1e-9, trial
+        want = vt[:, 3, :3] / vt[:, 3, 3:4]
+        well = finite & (sv[:, 3] < 1e-3 * sv[:, 2]) & (np.abs(vt[:, 3, 3]) > 1e-6)
+        if well.any():
+            assert np.max(np.abs(got[well] - want[well]) / np.linalg.norm(want[well], axis=1, keepdims=True)) <= 1e-9, trial
+
+
 # ------------------------------------------------------------------------------------------------------
 # sharding: G virtual shards on one GPU through the sharded engine == one run over all hypotheses
 # ------------------------------------------------------------------------------------------------------
