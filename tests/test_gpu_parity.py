@@ -802,6 +802,34 @@ def test_filtered_score_randomized_sweep(dev):
     assert total_checked > 5e6
 
 
+def test_two_sided_filter_variant_in_a_fresh_process():
+    """SFM_SCORE_ONE_SIDED=0 (read once per process) selects the two-sided tier-1 test everywhere: same counts as the
+    all-fp64 kernel, checked in a child process so that the switch is actually taken."""
+    import os
+    import subprocess
+    import sys
+
+    code = (
+        "import numpy as np, torch, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from structure_from_motion_amd import device as dev, synthetic\n"
+        "n, h = 9000, 700\n"
+        "pa, pb, K, *_ = synthetic.two_view_scene(n, seed=6)\n"
+        "corr = dev.normalize_correspondences(dev.to_device(pa), dev.to_device(pb), K).reshape(1, n, 4)\n"
+        "S = dev.sample_philox(5, 0, h, n)\n"
+        "E, _ = dev.fit_eight_point(corr, S)\n"
+        "for thr in (1.5e-6, 1e-9, 0.0, 3e-4):\n"
+        "    a = dev.score_sed(corr, E, S, thr, exact_only=True)\n"
+        "    b = dev.score_sed(corr, E, S, thr)\n"
+        "    assert torch.equal(a[0], b[0]), thr\n"
+        "    assert torch.allclose(a[1], b[1], rtol=1e-12, atol=0, equal_nan=True)\n"
+        "print('two-sided ok')\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SFM_SCORE_ONE_SIDED="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "two-sided ok" in out.stdout, out.stderr[-2000:]
+
+
 @pytest.mark.parametrize("order", ["1", "0"])
 def test_score_hypothesis_ordering_does_not_change_results(dev, monkeypatch, order):
     """The longest-first processing order (forced on / off) only affects speed: identical outputs on odd sizes,
