@@ -12,6 +12,13 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls only enqueue work;
  *     nothing synchronises with the host.
  *   - a leading `batch` dimension runs independent image pairs (blockIdx.y); batch == 1 for one pair.
+ *   - size limits of ONE call: a kernel that gives every work item a thread or wave of its own is launched
+ *     with at most 2^31-1 blocks and 2^32-1 threads along x, and `batch` (grid y) at most 65535; a call
+ *     beyond that returns SFM_EINVAL before anything is launched (never a silently partial result).  In
+ *     hypothesis counts per call: sfm_sample_philox* 2^32-256, sfm_fit_eight_point* / sfm_sample_fit_philox
+ *     2^32-64, sfm_score_sed 2^28 (16 hypotheses per 256-thread block), sfm_cheirality / sfm_triangulate
+ *     2^32-64 points.  Element-wise kernels (normalise, mask, SED values, select) walk their items with
+ *     grid-stride loops and have no such limit.
  *   - return value: 0 on success, a negative SFM_E* code otherwise; sfm_last_error() returns a
  *     thread-local message for the last failure.
  */

@@ -7,7 +7,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libsfm_hip.so")
 SOURCES = ["sfm_kernels.hip", "sfm_score.hip", "sfm_refine.hip", "sfm_pose.hip", "sfm_match.hip", "sfm_harris.hip", "pyshuffle.cpp"]
-HEADERS = ["sfm_math.h", "sfm_common.h", os.path.join("..", "..", "include", "sfm_hip.h")]
+# every header a translation unit can include: all of csrc/*.h plus the public C ABI header
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "sfm_hip.h")]
 # -ffp-contract=off: multiply/add round separately (parity with the NumPy elementwise semantics of the
 # reference); fused ops appear only where the source spells fma().
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",

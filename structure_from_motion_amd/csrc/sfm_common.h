@@ -26,7 +26,25 @@ inline int check_launch(const char* what) {
     return SFM_OK;
 }
 
-inline unsigned grid_for(int64_t work, int block, int64_t cap = 1 << 20) {
+// Limits of ONE launch (HIP on gfx950): at most 2^31-1 blocks and 2^32-1 threads along x, 65535 blocks along y/z.
+// Kernels without a grid-stride loop need every work item covered by a block of their own: their entry points
+// refuse sizes beyond that with SFM_EINVAL (SFM_REQUIRE_GRID) instead of silently covering a prefix.
+// `per_block` work items per block of `threads` threads.
+inline bool grid_fits(int64_t work, int64_t per_block, int64_t threads, int64_t y = 1, int64_t z = 1) {
+    if (work < 0 || per_block <= 0 || threads <= 0) return false;
+    if (work > (int64_t)1 << 60) return false;
+    const int64_t g = (work + per_block - 1) / per_block;
+    return g <= 0x7FFFFFFFLL && g * threads <= 0xFFFFFFFFLL && y <= 65535 && z <= 65535;
+}
+
+// blocks that cover `work` items exactly once (the caller has checked grid_fits)
+inline unsigned grid_for(int64_t work, int64_t block) {
+    const int64_t g = (work + block - 1) / block;
+    return (unsigned)(g < 1 ? 1 : g);
+}
+
+// capped grid for kernels that walk their items with a grid-stride loop
+inline unsigned grid_stride(int64_t work, int64_t block, int64_t cap) {
     int64_t g = (work + block - 1) / block;
     if (g < 1) g = 1;
     if (g > cap) g = cap;
@@ -34,6 +52,13 @@ inline unsigned grid_for(int64_t work, int block, int64_t cap = 1 << 20) {
 }
 
 }  // namespace sfmhost
+
+#define SFM_REQUIRE_GRID(fn, work, per_block, ...)                                                     \
+    do {                                                                                               \
+        if (!sfmhost::grid_fits((work), (per_block), __VA_ARGS__))                                       \
+            return sfmhost::fail(SFM_EINVAL, fn ": size exceeds what one launch covers (2^31-1 blocks, " \
+                                                "2^32-1 threads in x; 65535 in y/z)");               \
+    } while (0)
 
 constexpr int kWave = 64;
 

@@ -18,6 +18,7 @@ namespace {
 using sfmhost::check_launch;
 using sfmhost::fail;
 using sfmhost::grid_for;
+using sfmhost::grid_stride;
 
 __global__ void correlate_kernel(const double* __restrict__ image, int64_t h, int64_t w,
                                  const double* __restrict__ kernel, int ks, double* __restrict__ out) {
@@ -173,6 +174,7 @@ int sfm_cross_correlate(const double* image, int64_t height, int64_t width, cons
     if (height < kernel_size || width < kernel_size || height > 65535)
         return fail(SFM_EINVAL, "sfm_cross_correlate: kernel larger than image (or more than 65535 rows)");
     if (!image || !kernel || !out) return fail(SFM_EINVAL, "sfm_cross_correlate: null pointer");
+    SFM_REQUIRE_GRID("sfm_cross_correlate", width, 256, 256, height);
     hipLaunchKernelGGL(correlate_kernel, dim3(grid_for(width, 256), (unsigned)height), dim3(256), 0,
                        (hipStream_t)stream, image, height, width, kernel, kernel_size, out);
     return check_launch("correlate_kernel");
@@ -186,6 +188,7 @@ int sfm_harris_cornerness(const double* sobel_x, const double* sobel_y, int64_t 
     if (out_height == 0 || out_width == 0) return SFM_OK;
     if (out_height > height || out_width > width) return fail(SFM_EINVAL, "sfm_harris_cornerness: output larger than input");
     if (!sobel_x || !sobel_y || !out) return fail(SFM_EINVAL, "sfm_harris_cornerness: null pointer");
+    SFM_REQUIRE_GRID("sfm_harris_cornerness", out_width, 256, 256, out_height);
     hipLaunchKernelGGL(cornerness_kernel, dim3(grid_for(out_width, 256), (unsigned)out_height), dim3(256), 0,
                        (hipStream_t)stream, sobel_x, sobel_y, height, width, block_size, k, clamp_negative,
                        out_height, out_width, out);
@@ -204,6 +207,7 @@ int sfm_nms_round(const double* image, uint8_t* state, int64_t height, int64_t w
                   void* stream) {
     if (height <= 0 || width <= 0 || height > 65535) return fail(SFM_EINVAL, "sfm_nms_round: bad size");
     if (!image || !state || !unresolved) return fail(SFM_EINVAL, "sfm_nms_round: null pointer");
+    SFM_REQUIRE_GRID("sfm_nms_round", width, 256, 256, height);
     hipLaunchKernelGGL(nms_round_kernel, dim3(grid_for(width, 256), (unsigned)height), dim3(256), 0,
                        (hipStream_t)stream, image, state, height, width, unresolved);
     return check_launch("nms_round_kernel");
@@ -213,6 +217,7 @@ int sfm_nms_finalize(double* image, const uint8_t* state, int64_t height, int64_
     if (height < 0 || width < 0) return fail(SFM_EINVAL, "sfm_nms_finalize: negative size");
     if (height == 0 || width == 0) return SFM_OK;
     if (!image || !state) return fail(SFM_EINVAL, "sfm_nms_finalize: null pointer");
+    SFM_REQUIRE_GRID("sfm_nms_finalize", height * width, 256, 256);
     hipLaunchKernelGGL(nms_finalize_kernel, dim3(grid_for(height * width, 256)), dim3(256), 0, (hipStream_t)stream,
                        image, state, height * width);
     return check_launch("nms_finalize_kernel");
@@ -227,7 +232,7 @@ int sfm_compact_nonzero(const double* image, int64_t count, int32_t capacity, in
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(zero_counter_kernel, dim3(1), dim3(1), 0, st, counter);
     if (count > 0)
-        hipLaunchKernelGGL(compact_nonzero_kernel, dim3(grid_for(count, 256, 1024)), dim3(256), 0, st, image, count,
+        hipLaunchKernelGGL(compact_nonzero_kernel, dim3(grid_stride(count, 256, 1024)), dim3(256), 0, st, image, count,
                            capacity, counter, index, value);
     return check_launch("compact_nonzero_kernel");
 }

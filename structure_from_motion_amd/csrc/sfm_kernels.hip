@@ -31,6 +31,7 @@ namespace {
 using sfmhost::check_launch;
 using sfmhost::fail;
 using sfmhost::grid_for;
+using sfmhost::grid_stride;
 using namespace sfmfit;
 
 static_assert(sizeof(sfm_select_result) == 40, "sfm_select_result layout is part of the ABI");
@@ -688,7 +689,7 @@ int sfm_normalize_correspondences(const double* pix_a, const double* pix_b, int6
     if (count < 0) return fail(SFM_EINVAL, "sfm_normalize_correspondences: negative count");
     if (count == 0) return SFM_OK;
     if (!pix_a || !pix_b || !corr) return fail(SFM_EINVAL, "sfm_normalize_correspondences: null pointer");
-    hipLaunchKernelGGL(normalize_kernel, dim3(grid_for(count, 256, 2048)), dim3(256), 0,
+    hipLaunchKernelGGL(normalize_kernel, dim3(grid_stride(count, 256, 2048)), dim3(256), 0,
                        (hipStream_t)stream, (const double2*)pix_a, (const double2*)pix_b, count, fx, fy,
                        cx, cy, (Corr*)corr);
     return check_launch("normalize_kernel");
@@ -700,6 +701,7 @@ int sfm_sample_philox(uint64_t seed, uint64_t seed_stride, int64_t h_begin, int6
     if (n < 8 || n > 0x7FFFFFFF) return fail(SFM_EINVAL, "sfm_sample_philox: need 8 <= n < 2^31");
     if (h_count == 0 || batch == 0) return SFM_OK;
     if (!S) return fail(SFM_EINVAL, "sfm_sample_philox: null pointer");
+    SFM_REQUIRE_GRID("sfm_sample_philox", h_count, 256, 256, batch);
     hipLaunchKernelGGL(sample_philox_kernel, dim3(grid_for(h_count, 256), (unsigned)batch), dim3(256), 0,
                        (hipStream_t)stream, seed, seed_stride, h_begin, h_count, (uint32_t)n, S);
     return check_launch("sample_philox_kernel");
@@ -711,6 +713,7 @@ int sfm_sample_philox_dev(const uint64_t* seed_dev, uint64_t seed_stride, int64_
     if (n < 8 || n > 0x7FFFFFFF) return fail(SFM_EINVAL, "sfm_sample_philox_dev: need 8 <= n < 2^31");
     if (h_count == 0 || batch == 0) return SFM_OK;
     if (!S || !seed_dev) return fail(SFM_EINVAL, "sfm_sample_philox_dev: null pointer");
+    SFM_REQUIRE_GRID("sfm_sample_philox_dev", h_count, 256, 256, batch);
     hipLaunchKernelGGL(sample_philox_dev_kernel, dim3(grid_for(h_count, 256), (unsigned)batch), dim3(256), 0,
                        (hipStream_t)stream, seed_dev, seed_stride, h_begin, h_count, (uint32_t)n, S);
     return check_launch("sample_philox_dev_kernel");
@@ -722,6 +725,7 @@ int sfm_sample_philox_at(uint64_t seed, uint64_t seed_stride, const int64_t* h_i
     if (n < 8 || n > 0x7FFFFFFF) return fail(SFM_EINVAL, "sfm_sample_philox_at: need 8 <= n < 2^31");
     if (batch == 0) return SFM_OK;
     if (!S || !h_index) return fail(SFM_EINVAL, "sfm_sample_philox_at: null pointer");
+    SFM_REQUIRE_GRID("sfm_sample_philox_at", batch, 64, 64);
     hipLaunchKernelGGL(sample_philox_at_kernel, dim3(grid_for(batch, 64)), dim3(64), 0, (hipStream_t)stream,
                        seed, seed_stride, h_index, (uint32_t)n, batch, S);
     return check_launch("sample_philox_at_kernel");
@@ -733,6 +737,7 @@ int sfm_fit_eight_point(const double* corr, int64_t n, const int32_t* S, int64_t
     if (n < 8) return fail(SFM_EINVAL, "sfm_fit_eight_point: need at least 8 correspondences");
     if (h_count == 0 || batch == 0) return SFM_OK;
     if (!corr || !S || !E || !flags) return fail(SFM_EINVAL, "sfm_fit_eight_point: null pointer");
+    SFM_REQUIRE_GRID("sfm_fit_eight_point", h_count, kWave, kWave, batch);
     hipLaunchKernelGGL(fit_eight_point_kernel<false>, dim3(grid_for(h_count, kWave), (unsigned)batch),
                        dim3(kWave), 0, (hipStream_t)stream, (const Corr*)corr, n, const_cast<int32_t*>(S), h_count, E,
                        flags, lambda2, (double*)nullptr, PhiloxSource{nullptr, 0, 0, 0, 0});
@@ -746,6 +751,7 @@ int sfm_sample_fit_philox(uint64_t seed, const uint64_t* seed_dev, uint64_t seed
     if (n < 8 || n > 0x7FFFFFFF) return fail(SFM_EINVAL, "sfm_sample_fit_philox: need 8 <= n < 2^31");
     if (h_count == 0 || batch == 0) return SFM_OK;
     if (!corr || !S || !E || !flags) return fail(SFM_EINVAL, "sfm_sample_fit_philox: null pointer");
+    SFM_REQUIRE_GRID("sfm_fit_eight_point", h_count, kWave, kWave, batch);
     hipLaunchKernelGGL(fit_eight_point_kernel<false>, dim3(grid_for(h_count, kWave), (unsigned)batch),
                        dim3(kWave), 0, (hipStream_t)stream, (const Corr*)corr, n, S, h_count, E, flags,
                        (double*)nullptr, (double*)nullptr, PhiloxSource{seed_dev, seed, seed_stride, h_begin, 1});
@@ -760,6 +766,7 @@ int sfm_fit_eight_point_traced(const double* corr, int64_t n, const int32_t* S, 
     if (n < 8) return fail(SFM_EINVAL, "sfm_fit_eight_point_traced: need at least 8 correspondences");
     if (h_count == 0 || batch == 0) return SFM_OK;
     if (!corr || !S || !E || !flags || !trace) return fail(SFM_EINVAL, "sfm_fit_eight_point_traced: null pointer");
+    SFM_REQUIRE_GRID("sfm_fit_eight_point_traced", h_count, kWave, kWave, batch);
     hipLaunchKernelGGL(fit_eight_point_kernel<true>, dim3(grid_for(h_count, kWave), (unsigned)batch),
                        dim3(kWave), 0, (hipStream_t)stream, (const Corr*)corr, n, const_cast<int32_t*>(S), h_count, E,
                        flags, (double*)nullptr, trace, PhiloxSource{nullptr, 0, 0, 0, 0});
@@ -798,7 +805,7 @@ int sfm_select_best(const int32_t* cnt, const double* s1, const double* s2, cons
     }
     hipLaunchKernelGGL(select_init_kernel, dim3((unsigned)batch), dim3(1), 0, st, result);
     if (h_count > 0) {
-        const dim3 grid(grid_for(h_count, 256, 64), (unsigned)batch);
+        const dim3 grid(grid_stride(h_count, 256, 64), (unsigned)batch);
         hipLaunchKernelGGL(select_pass1_kernel, grid, dim3(256), 0, st, cnt, s1, s2, flags, h_count, min_extra,
                            aggregation, result);
         hipLaunchKernelGGL(select_pass2_kernel, grid, dim3(256), 0, st, cnt, s1, s2, flags, h_count, min_extra,
@@ -814,7 +821,8 @@ int sfm_inlier_mask(const double* corr, int64_t n, const double* E, const int32_
     if (h_count < 0 || batch < 0 || n < 0) return fail(SFM_EINVAL, "sfm_inlier_mask: negative size");
     if (n == 0 || batch == 0) return SFM_OK;
     if (!corr || !E || !S || !result || !mask) return fail(SFM_EINVAL, "sfm_inlier_mask: null pointer");
-    hipLaunchKernelGGL(inlier_mask_kernel, dim3(grid_for(n, 256, 1024), (unsigned)batch), dim3(256), 0,
+    SFM_REQUIRE_GRID("sfm_inlier_mask", 1, 1, 256, batch);
+    hipLaunchKernelGGL(inlier_mask_kernel, dim3(grid_stride(n, 256, 1024), (unsigned)batch), dim3(256), 0,
                        (hipStream_t)stream, (const Corr*)corr, n, E, S, h_count, result, thr, mask);
     return check_launch("inlier_mask_kernel");
 }
@@ -823,7 +831,7 @@ int sfm_sed_values(const double* corr, int64_t n, const double* E, double* out, 
     if (n < 0) return fail(SFM_EINVAL, "sfm_sed_values: negative size");
     if (n == 0) return SFM_OK;
     if (!corr || !E || !out) return fail(SFM_EINVAL, "sfm_sed_values: null pointer");
-    hipLaunchKernelGGL(sed_values_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(sed_values_kernel, dim3(grid_stride(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream,
                        (const Corr*)corr, n, E, out);
     return check_launch("sed_values_kernel");
 }
@@ -833,6 +841,7 @@ int sfm_cheirality(const double* corr, int64_t m, const double* pose_rt, int64_t
     if (m < 0 || poses < 0) return fail(SFM_EINVAL, "sfm_cheirality: negative size");
     if (m == 0 || poses == 0) return SFM_OK;
     if (!corr || !pose_rt || !pass) return fail(SFM_EINVAL, "sfm_cheirality: null pointer");
+    SFM_REQUIRE_GRID("sfm_cheirality", m, kWave, kWave, poses);
     hipLaunchKernelGGL(cheirality_kernel, dim3(grid_for(m, kWave), (unsigned)poses), dim3(kWave), 0,
                        (hipStream_t)stream, (const Corr*)corr, m, pose_rt, distance_threshold, pass);
     return check_launch("cheirality_kernel");
@@ -843,6 +852,7 @@ int sfm_triangulate(const double* corr, int64_t m, const double* P1, const doubl
     if (m < 0) return fail(SFM_EINVAL, "sfm_triangulate: negative size");
     if (m == 0) return SFM_OK;
     if (!corr || !P1 || !P2 || !X) return fail(SFM_EINVAL, "sfm_triangulate: null pointer");
+    SFM_REQUIRE_GRID("sfm_triangulate", m, kWave, kWave);
     hipLaunchKernelGGL(triangulate_kernel, dim3(grid_for(m, kWave)), dim3(kWave), 0, (hipStream_t)stream,
                        (const Corr*)corr, m, P1, P2, X);
     return check_launch("triangulate_kernel");
@@ -853,6 +863,7 @@ int sfm_decompose_essential(const double* E, int64_t batch, double* pose_rt, int
     if (batch < 0) return fail(SFM_EINVAL, "sfm_decompose_essential: negative size");
     if (batch == 0) return SFM_OK;
     if (!E || !pose_rt || !status) return fail(SFM_EINVAL, "sfm_decompose_essential: null pointer");
+    SFM_REQUIRE_GRID("sfm_decompose_essential", batch, kWave, kWave);
     hipLaunchKernelGGL(decompose_essential_kernel, dim3(grid_for(batch, kWave)), dim3(kWave), 0,
                        (hipStream_t)stream, E, batch, pose_rt, status);
     return check_launch("decompose_essential_kernel");

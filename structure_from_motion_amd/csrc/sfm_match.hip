@@ -507,6 +507,7 @@ int sfm_patch_extract(const double* image, int64_t height, int64_t width, const 
     if (n == 0) return SFM_OK;
     if (stride < n) return fail(SFM_EINVAL, "sfm_patch_extract: stride < n");
     if (!image || !feats || !patches || !ssq || !ok) return fail(SFM_EINVAL, "sfm_patch_extract: null pointer");
+    SFM_REQUIRE_GRID("sfm_patch_extract", n, 64, 64);
     hipLaunchKernelGGL(patch_extract_kernel, dim3(grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, image,
                        height, width, feats, n, stride, window_size / 2, subtract_mean, patches, ssq, ok);
     return check_launch("patch_extract_kernel");
@@ -560,6 +561,7 @@ int sfm_match_summary(int metric, const double* patches_a, int64_t stride_a, con
     const int64_t n_tiles = (n_b + kTileB - 1) / kTileB;
     const int64_t tiles_a = (n_a + kTileA - 1) / kTileA;
     if (8 * ((tiles_a + 7) / 8) * n_tiles > 0x7FFFFFFF) return fail(SFM_EINVAL, "sfm_match_summary: too many tiles");
+    SFM_REQUIRE_GRID("sfm_match_summary", n_a, 256, 256);
     const dim3 grid(tile_grid(tiles_a, n_tiles));
     TileSummary* tiles = static_cast<TileSummary*>(workspace);
     hipStream_t st = (hipStream_t)stream;
@@ -585,6 +587,7 @@ int sfm_match_row_summary(const double* scores, int64_t n_a, int64_t n_b, double
     if (n_b == 0) return fail(SFM_EINVAL, "sfm_match_row_summary: empty rows");
     if (n_b > 0x7FFFFFFF) return fail(SFM_EINVAL, "sfm_match_row_summary: rows too long");
     if (!scores || !best || !arg || !second) return fail(SFM_EINVAL, "sfm_match_row_summary: null pointer");
+    SFM_REQUIRE_GRID("sfm_match_row_summary", n_a, 256 / kWave, 256);
     hipLaunchKernelGGL(row_summary_kernel, dim3(grid_for(n_a, 256 / kWave)), dim3(256), 0, (hipStream_t)stream,
                        scores, n_a, n_b, best, arg, second);
     return check_launch("row_summary_kernel");

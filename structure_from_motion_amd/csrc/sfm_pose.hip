@@ -190,6 +190,7 @@ int sfm_cheirality_batched(const double* corr, int64_t n, int64_t batch, const d
     if (batch > 65535) return fail(SFM_EINVAL, "sfm_cheirality_batched: batch > 65535");
     if (!corr || !pose_rt || !pass) return fail(SFM_EINVAL, "sfm_cheirality_batched: null pointer");
     // one pose per block in z: 5.08 ms per C5 batch vs 5.29 with all four poses in one wave (profiles/r01/README.md)
+    SFM_REQUIRE_GRID("sfm_cheirality_batched", n, kChunkPoints * (256 / kWave), 256, batch);
     hipLaunchKernelGGL(cheirality_batched_kernel, dim3(grid_for(n, kChunkPoints * (256 / kWave)), (unsigned)batch, 4),
                        dim3(256), 0, (hipStream_t)stream, (const Corr*)corr, n, pose_rt, mask, distance_threshold, pass);
     return check_launch("cheirality_batched_kernel");
@@ -215,6 +216,7 @@ int sfm_triangulate_selected(const double* pix_a, const double* pix_b, int64_t n
         return fail(SFM_EINVAL, "sfm_triangulate_selected: null pointer");
     Intrinsics intr;
     for (int j = 0; j < 9; ++j) intr.k[j] = K[j];  // host pointer, passed by value
+    SFM_REQUIRE_GRID("sfm_triangulate_selected", n, kChunkPoints * (256 / kWave), 256, batch);
     hipLaunchKernelGGL(triangulate_selected_kernel, dim3(grid_for(n, kChunkPoints * (256 / kWave)), (unsigned)batch),
                        dim3(256), 0, (hipStream_t)stream, (const double2*)pix_a, (const double2*)pix_b, n, intr, pose_rt, best,
                        pass, X, valid);

@@ -49,6 +49,7 @@ namespace {
 using sfmhost::check_launch;
 using sfmhost::fail;
 using sfmhost::grid_for;
+using sfmhost::grid_stride;
 
 constexpr int kHypPerWave = 4;
 constexpr int kRing = 256;  // entries per (wave, hypothesis) ring; <= 63 left + 128 pushed per step; drained in groups of 64
@@ -686,6 +687,7 @@ struct FilteredLaunch {
 template <int HPW>
 int launch_filtered(const FilteredLaunch& a) {
     const int64_t waves = (a.h_count + HPW - 1) / HPW;
+    SFM_REQUIRE_GRID("sfm_score_sed", waves, 256 / kWave, 256, a.batch);
     const dim3 grid(grid_for(waves, 256 / kWave), (unsigned)a.batch);
     const int32_t* order_arg = nullptr;
     if (a.use_order) {
@@ -696,6 +698,7 @@ int launch_filtered(const FilteredLaunch& a) {
         else
             hipLaunchKernelGGL((score_estimate_kernel<HPW, false>), grid, dim3(256), 0, a.st, a.ws, a.n, a.E, a.h_count,
                                a.thr, a.a_scale, a.cnt);
+        SFM_REQUIRE_GRID("sfm_score_sed (ordering pre-pass)", a.h_count, 256, 256, a.batch);
         const dim3 per_hyp(grid_for(a.h_count, 256), (unsigned)a.batch);
         hipLaunchKernelGGL(score_class_count_kernel, per_hyp, dim3(256), 0, a.st, a.cnt, a.h_count, a.buckets);
         hipLaunchKernelGGL(score_class_scan_kernel, dim3(grid_for(a.batch, 64)), dim3(64), 0, a.st, a.buckets, a.batch);
@@ -737,6 +740,7 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
     if (n < 8) return fail(SFM_EINVAL, "sfm_score_sed: need at least 8 correspondences");
     hipStream_t st = (hipStream_t)stream;
     const int64_t waves = (h_count + kHypPerWave - 1) / kHypPerWave;
+    SFM_REQUIRE_GRID("sfm_score_sed", waves, 256 / kWave, 256, batch);
     const dim3 grid(grid_for(waves, 256 / kWave), (unsigned)batch);
     if (workspace == nullptr) {
         hipLaunchKernelGGL(score_sed_exact_kernel<kHypPerWave>, grid, dim3(256), 0, st, (const Corr*)corr, (int)n,
@@ -747,6 +751,18 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
         return fail(SFM_EINVAL, "sfm_score_sed: workspace smaller than sfm_score_workspace_bytes(n, h_count, batch)");
     if ((reinterpret_cast<uintptr_t>(workspace) & 15u) != 0)
         return fail(SFM_EINVAL, "sfm_score_sed: workspace must be 16-byte aligned");
+    // hypotheses per wave: 4 amortises the point loads best, but a launch with fewer waves than the chip holds
+    // (5120) leaves SIMDs idle — then fewer hypotheses per wave = more waves wins (SFM_SCORE_HPW overrides)
+    const int hpw_env = getenv("SFM_SCORE_HPW") ? atoi(getenv("SFM_SCORE_HPW")) : 0;
+    int hpw = kHypPerWave;
+    if (hpw_env == 1 || hpw_env == 2 || hpw_env == 4) {
+        hpw = hpw_env;
+    } else {
+        while (hpw > 1 && (h_count + hpw - 1) / hpw * batch < 5120) hpw /= 2;
+    }
+    // every size check comes before the first launch: a refused call must not have touched the workspace
+    SFM_REQUIRE_GRID("sfm_score_sed", (h_count + hpw - 1) / hpw, 256 / kWave, 256, batch);
+    SFM_REQUIRE_GRID("sfm_score_sed (ordering pre-pass)", h_count, 256, 256, batch);
     unsigned char* ws = static_cast<unsigned char*>(workspace);
     int32_t* buckets = reinterpret_cast<int32_t*>(ws + ws_buckets_offset(n, batch));
     int32_t* order = reinterpret_cast<int32_t*>(ws + ws_order_offset(n, batch));
@@ -759,7 +775,7 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
     const bool use_order = order_env >= 0 ? order_env != 0 : (waves * batch <= 12 * 5120 && n >= 8192);
     // Small point sets are prepared by one block per pair, which stores the maxima itself; the zeroing kernel is then
     // only needed for the class counters of the ordering pre-pass (a small pass is a chain of ~4 us launches).
-    const unsigned prepare_blocks = n <= 8192 ? 1u : grid_for(n, 256, 64);
+    const unsigned prepare_blocks = n <= 8192 ? 1u : grid_stride(n, 256, 64);
     if (use_order || prepare_blocks > 1)
         hipLaunchKernelGGL(score_reset_kernel, dim3((unsigned)batch), dim3(256), 0, st, ws, buckets);
     // SFM_SCORE_ONE_SIDED=0 switches tier 1 back to the two-sided test (ablation)
@@ -769,15 +785,6 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
                        (const Corr*)corr, n, a_scale, ws);
     int rc = check_launch("score_prepare_kernel");
     if (rc != SFM_OK) return rc;
-    // hypotheses per wave: 4 amortises the point loads best, but a launch with fewer waves than the chip holds
-    // (5120) leaves SIMDs idle — then fewer hypotheses per wave = more waves wins (SFM_SCORE_HPW overrides)
-    const int hpw_env = getenv("SFM_SCORE_HPW") ? atoi(getenv("SFM_SCORE_HPW")) : 0;
-    int hpw = kHypPerWave;
-    if (hpw_env == 1 || hpw_env == 2 || hpw_env == 4) {
-        hpw = hpw_env;
-    } else {
-        while (hpw > 1 && (h_count + hpw - 1) / hpw * batch < 5120) hpw /= 2;
-    }
     const FilteredLaunch args{(const Corr*)corr, ws, (int)n, E, S, (int)h_count, thr, use_order, cnt, s1, s2,
                               buckets, order, batch, st, one_sided, a_scale};
     switch (hpw) {

@@ -44,6 +44,33 @@ def test_argument_validation_without_gpu(native_lib):
     assert native_lib.sfm_cheirality(None, 0, None, 4, 50.0, None, None) == 0
 
 
+def test_sizes_beyond_one_launch_are_refused(native_lib):
+    """Kernels without a grid-stride loop must cover every item with a block of its own: sizes beyond one launch's
+    limits (2^31-1 blocks / 2^32-1 threads in x, 65535 in y) return SFM_EINVAL before any HIP call instead of
+    silently scoring a prefix (include/sfm_hip.h, "size limits of ONE call").  Pointers are fake non-null values:
+    nothing may be dereferenced or launched on this path."""
+    p = C.c_void_p(0x1000)
+    big_h = 1 << 28          # 16 hypotheses per 256-thread block -> 2^32 threads: one too many
+    assert native_lib.sfm_score_sed(p, 50_000, p, p, big_h + 16, 1, 1e-6, p, p, p, None, 0, None) == -1
+    assert b"one launch" in native_lib.sfm_last_error()
+    ws_bytes = native_lib.sfm_score_workspace_bytes(50_000, big_h + 16, 1)
+    ws = C.c_void_p(0x10000)
+    assert native_lib.sfm_score_sed(p, 50_000, p, p, big_h + 16, 1, 1e-6, p, p, p, ws, ws_bytes, None) == -1
+    assert b"one launch" in native_lib.sfm_last_error()
+    assert native_lib.sfm_fit_eight_point(p, 100, p, 1 << 32, 1, p, p, None, None) == -1
+    assert b"one launch" in native_lib.sfm_last_error()
+    assert native_lib.sfm_sample_fit_philox(1, None, 1, 0, p, 100, 1 << 32, 1, p, p, p, None) == -1
+    assert native_lib.sfm_sample_philox(1, 1, 0, 1 << 32, 100, 1, p, None) == -1
+    assert native_lib.sfm_cheirality(p, 1 << 32, p, 4, 50.0, p, None) == -1
+    assert native_lib.sfm_triangulate(p, 1 << 32, p, p, p, None) == -1
+    assert native_lib.sfm_decompose_essential(p, 1 << 32, p, p, None) == -1
+    # batch is the grid's y dimension
+    assert native_lib.sfm_fit_eight_point(p, 100, p, 64, 65536, p, p, None, None) == -1
+    assert native_lib.sfm_sample_philox(1, 1, 0, 64, 100, 65536, p, None) == -1
+    assert native_lib.sfm_score_sed(p, 100, p, p, 64, 65536, 1e-6, p, p, p, None, 0, None) == -1
+    assert native_lib.sfm_cheirality_batched(p, 100, 65536, p, p, 50.0, p, None) == -1
+
+
 @pytest.mark.parametrize("n,iters,seed", [(10, 100, 5), (75, 30, 0), (2, 10, 1), (1, 3, 2), (1000, 7, 123456789)])
 def test_pyshuffle_replay_matches_cpython(native_lib, n, iters, seed):
     from structure_from_motion_amd import device
