@@ -124,11 +124,33 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
                   int64_t batch, double thr, int32_t* cnt, double* s1, double* s2, void* workspace,
                   int64_t workspace_bytes, void* stream);
 
+/* Measurement hook: the next sfm_score_sed calls of the calling thread record the hipEvent_t `before` / `after`
+ * (passed as void*, either may be NULL) on the launch stream immediately around the scoring kernel itself — not the
+ * workspace preparation or the ordering pre-pass — so that a benchmark can time exactly the kernel a profiler
+ * reports.  (NULL, NULL) switches it off. */
+int sfm_score_set_timing_events(void* before, void* after);
+
 /* Model selection (ransac.py:75-86): lowest aggregated error among hypotheses with
  * cnt >= min_extra, strict <, earliest index wins, NaN/inf never win.  result: dev [batch]. */
 int sfm_select_best(const int32_t* cnt, const double* s1, const double* s2, const int32_t* flags,
                     int64_t h_count, int64_t batch, double min_extra, int aggregation, int64_t h_offset,
                     sfm_select_result* result, void* stream);
+
+/* Cross-shard selection for hypothesis-sharded RANSAC (one rank per GPU).  Each rank runs
+ * sfm_select_best over its own block of hypotheses with h_offset = the block's first global index, the ranks
+ * all-gather their [batch] records (40 bytes each) into gathered[world][batch], and this folds them: lowest error
+ * key, then lowest global index (the sequential "strictly lower error replaces the incumbent" rule of
+ * ransac.py:83-86 for any partition); first_flagged = minimum, n_flagged = sum (saturating), so every rank takes
+ * the same decision about degenerate samples (eight_point.py:415-421 raised through ransac.py:65).
+ * Outputs (each optional, dev): global [batch] = the folded records; best_h [batch] = the winners' global indices
+ * (-1 if none; the form sfm_sample_philox_at reads); single [batch] = the folded records with best_h replaced by
+ * 0 / -1, i.e. addressed at a one-hypothesis E / S array holding the locally re-derived winner (for sfm_inlier_mask).
+ * The _host variant takes host pointers and runs on the calling thread (the fold is 40 bytes per rank: it exists so
+ * that the N > 1 selection logic is testable over a CPU process group). */
+int sfm_fold_select_records(const sfm_select_result* gathered, int64_t world, int64_t batch,
+                            sfm_select_result* global, int64_t* best_h, sfm_select_result* single, void* stream);
+int sfm_fold_select_records_host(const sfm_select_result* gathered, int64_t world, int64_t batch,
+                                 sfm_select_result* global, int64_t* best_h, sfm_select_result* single);
 
 /* Inlier mask of the selected model: mask[b,i] = 1 if point i is a non-sample survivor, 2 if it is one of
  * the 8 sample points, 0 otherwise.  `result` as written by sfm_select_best with h_offset 0 (or with

@@ -15,7 +15,7 @@ AGG_SUM, AGG_SQUARE, AGG_MEAN, AGG_RMS = 0, 1, 2, 3
 FIT_DEGENERATE = 1
 MATCH_NCC, MATCH_SSD = 0, 1
 INT64_MAX = (1 << 63) - 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class SelectResult(C.Structure):
@@ -49,7 +49,10 @@ SIGNATURES = {
     "sfm_fit_stage": [C.c_int, _P, _P, _P],
     "sfm_hartley_normalize": [_P, _I64, _P, _P],
     "sfm_score_sed": [_P, _I64, _P, _P, _I64, _I64, _D, _P, _P, _P, _P, _I64, _P],
+    "sfm_score_set_timing_events": [_P, _P],
     "sfm_select_best": [_P, _P, _P, _P, _I64, _I64, _D, C.c_int, _I64, _P, _P],
+    "sfm_fold_select_records": [_P, _I64, _I64, _P, _P, _P, _P],
+    "sfm_fold_select_records_host": [_P, _I64, _I64, _P, _P, _P],
     "sfm_inlier_mask": [_P, _I64, _P, _P, _I64, _I64, _P, _D, _P, _P],
     "sfm_sed_values": [_P, _I64, _P, _P, _P],
     "sfm_cheirality": [_P, _I64, _P, _I64, _D, _P, _P],

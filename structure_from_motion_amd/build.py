@@ -6,13 +6,27 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libsfm_hip.so")
-SOURCES = ["sfm_kernels.hip", "sfm_score.hip", "sfm_refine.hip", "sfm_pose.hip", "sfm_match.hip", "sfm_harris.hip", "pyshuffle.cpp"]
+SOURCES = ["sfm_kernels.hip", "sfm_score.hip", "sfm_refine.hip", "sfm_pose.hip", "sfm_shard.hip", "sfm_match.hip", "sfm_harris.hip", "pyshuffle.cpp"]
 # every header a translation unit can include: all of csrc/*.h plus the public C ABI header
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "sfm_hip.h")]
 # -ffp-contract=off: multiply/add round separately (parity with the NumPy elementwise semantics of the
 # reference); fused ops appear only where the source spells fma().
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
+
+
+def score_source_sha() -> str:
+    """Fingerprint of the sources the scoring kernels are compiled from; profiles/score_traffic.json is stamped
+    with it so that bench.py can tell when the committed PMC counters were taken on an older kernel."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in ("sfm_score.hip", "sfm_math.h", "sfm_common.h"):
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(f.read())
+    for flag in FLAGS:
+        h.update(flag.encode())
+    return h.hexdigest()[:16]
 
 
 def _stale() -> bool:

@@ -682,7 +682,7 @@ __global__ __launch_bounds__(kWave) void decompose_essential_kernel(const double
 extern "C" {
 
 const char* sfm_last_error(void) { return sfmhost::error_buffer(); }
-int sfm_abi_version(void) { return 6; }
+int sfm_abi_version(void) { return 7; }
 
 int sfm_normalize_correspondences(const double* pix_a, const double* pix_b, int64_t count, double fx,
                                   double fy, double cx, double cy, double* corr, void* stream) {

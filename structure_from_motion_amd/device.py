@@ -201,6 +201,16 @@ def score_sed(corr: torch.Tensor, E: torch.Tensor, S: torch.Tensor, thr: float, 
     return cnt, s1, s2
 
 
+def score_timing_events(before: Optional[torch.cuda.Event], after: Optional[torch.cuda.Event]) -> None:
+    """Have the following ``score_sed`` calls record ``before`` / ``after`` immediately around the scoring kernel
+    (``sfm_score_set_timing_events``); ``(None, None)`` switches it off.  The events must have been recorded once
+    before (torch creates the underlying hipEvent lazily)."""
+    lib = _native.load()
+    check(lib.sfm_score_set_timing_events(before.cuda_event if before is not None else None,
+                                          after.cuda_event if after is not None else None),
+          "sfm_score_set_timing_events")
+
+
 def select_best(cnt, s1, s2, flags, min_extra: float, aggregation: int, h_offset: int = 0, out=None):
     """-> int64 tensor [B,5] viewing the sfm_select_result records."""
     lib = _native.load()

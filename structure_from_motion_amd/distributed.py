@@ -1,68 +1,36 @@
-"""Multi-GPU RANSAC: hypotheses shard across ranks, one tiny exchange picks the global best model.
+"""Multi-GPU RANSAC: hypotheses shard across ranks, ONE tiny collective picks the global best model.
 
 One process per GPU (``torch.distributed``; backend "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU for
-tests).  Rank r fits and scores hypotheses ``[r*H, (r+1)*H)`` of the global counter-based sample stream
-against its own replica of the correspondences (32 B x N, at most a few MB); the only data-path
-exchange is 16 bytes per rank:
+tests).  Rank r fits and scores its contiguous block of the global counter-based sample stream
+(``shard_range``) against its own replica of the correspondences (32 B x N, at most a few MB).  The only
+data-path exchange per pass is one ``all_gather`` of each rank's 40-byte ``sfm_select_result`` — written by the
+selection kernel itself with global hypothesis indices — after which every rank folds the ``world`` records
+locally (``sfm_fold_select_records``: lowest error key, then lowest global index; flag statistics min / sum):
 
-    key  = all_reduce(MIN) of the winner's error bits   (non-negative f64 bits are monotone as int64;
-                                                         "no model" is INT64_MAX)
-    h    = all_reduce(MIN) of the winner's global index, masked to ranks whose key equals the global key
+* that reproduces the sequential rule "strictly lower error wins, earliest first" (reference
+  ``lib/ransac/ransac.py:83-86``) for any partition of the hypotheses;
+* degenerate samples (``lib/epipolar/eight_point.py:415-421``, raised through ``ransac.py:65``) are seen by all
+  ranks alike, so ``SFM_DEGENERATE=raise|skip`` acts exactly as in the single-GPU drop-in path;
+* every rank re-derives the winner locally from (seed, h*) — the sample is a pure function of them — so no
+  E / mask broadcast is needed.
 
-which reproduces the sequential rule "strictly lower error wins, earliest first" (reference
-``lib/ransac/ransac.py:83``) for any sharding.  Every rank then re-derives the winner locally
-(``finalize``): the sample is a pure function of (seed, h), so no E / mask broadcast is needed.
+Image-pair batches (BASELINE config 5) shard over pairs with no collective at all.
 """
 from __future__ import annotations
 
-from typing import Tuple
+import ctypes as C
+import os
+from typing import NamedTuple, Optional, Tuple
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
-from ._native import INT64_MAX
+from . import _native
+from ._native import INT64_MAX, SelectResult, check
 
 NO_MODEL_KEY = INT64_MAX
-
-
-def reduce_best(key: torch.Tensor, best_h: torch.Tensor, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """key, best_h: int64 tensors of equal shape (one entry per image pair) holding this rank's winner
-    (``sfm_select_result.key`` / ``.best_h`` with global indices; best_h = -1 and key = INT64_MAX if the
-    rank found no model).  Returns the global (key, best_h), identical on every rank."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return key.clone(), best_h.clone()
-    gkey = _all_reduce_min(key, group)
-    sentinel = torch.full_like(best_h, INT64_MAX)
-    cand = torch.where((key == gkey) & (best_h >= 0), best_h, sentinel)
-    cand = _all_reduce_min(cand, group)
-    gbest = torch.where(cand == sentinel, torch.full_like(cand, -1), cand)
-    return gkey, gbest
-
-
-def _all_reduce_min(t: torch.Tensor, group=None) -> torch.Tensor:
-    """MIN all-reduce of a small int64 tensor.  With the "nccl" backend (RCCL) the device tensor is reduced in
-    place over xGMI; with "gloo" (CPU tests, or a rehearsal with several ranks sharing one GPU) device tensors
-    are staged through the host."""
-    out = t.clone()
-    if out.is_cuda and dist.get_backend(group) == "gloo":
-        host = out.cpu()
-        dist.all_reduce(host, op=dist.ReduceOp.MIN, group=group)
-        out.copy_(host)
-    else:
-        dist.all_reduce(out, op=dist.ReduceOp.MIN, group=group)
-    return out
-
-
-def reduce_flagged(first_flagged: torch.Tensor, n_flagged: torch.Tensor, group=None):
-    """Global (lowest flagged hypothesis index, number of flagged hypotheses) so that every rank raises
-    the same EightPointCalculationError."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return first_flagged.clone(), n_flagged.clone()
-    first = first_flagged.clone()
-    dist.all_reduce(first, op=dist.ReduceOp.MIN, group=group)
-    total = n_flagged.clone()
-    dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
-    return first, total
+RECORD_WORDS = C.sizeof(SelectResult) // 8   # the record viewed as int64 words
 
 
 def shard_range(total_hypotheses: int, rank: int, world: int) -> Tuple[int, int]:
@@ -72,61 +40,145 @@ def shard_range(total_hypotheses: int, rank: int, world: int) -> Tuple[int, int]
     return begin, max(0, min(total_hypotheses, begin + per) - begin)
 
 
-class ShardedRansac:
-    """RANSAC-E over ``world`` GPUs: rank r owns hypotheses [r*H, (r+1)*H) of the Philox stream.
+def _distributed(group) -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
 
-    ``step`` enqueues sample -> fit -> score -> select on the local shard, the 16-byte exchange, and the
-    local re-derivation of the global winner (sample, E, inlier mask) — no host synchronisation.
+
+def gather_records(record: torch.Tensor, out: Optional[torch.Tensor] = None, group=None) -> torch.Tensor:
+    """The ONE collective of a sharded pass.  record: int64 [batch, 5] view of this rank's sfm_select_result
+    records -> int64 [world, batch, 5], identical on every rank.  With the "nccl" backend (RCCL) the device tensor
+    is gathered in place over xGMI; with "gloo" (CPU tests, or a rehearsal with several ranks sharing one GPU)
+    device tensors are staged through the host."""
+    world = dist.get_world_size(group) if _distributed(group) else 1
+    if out is None:
+        out = torch.empty((world,) + tuple(record.shape), dtype=record.dtype, device=record.device)
+    if world == 1:
+        out[0].copy_(record)
+        return out
+    if record.is_cuda and dist.get_backend(group) == "gloo":
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host.view(-1), record.cpu().reshape(-1), group=group)
+        out.copy_(host)
+    else:
+        dist.all_gather_into_tensor(out.view(-1), record.reshape(-1), group=group)
+    return out
+
+
+def fold_records(gathered: torch.Tensor, global_record: Optional[torch.Tensor] = None,
+                 best_h: Optional[torch.Tensor] = None, single: Optional[torch.Tensor] = None):
+    """gathered int64 [world, batch, 5] -> (global_record [batch,5], best_h [batch], single [batch,5]) by
+    ``sfm_fold_select_records`` — a kernel on the current stream for device tensors, the same routine on the
+    calling thread for host tensors (CPU process-group tests)."""
+    lib = _native.load()
+    world, batch, words = gathered.shape
+    assert words == RECORD_WORDS and gathered.dtype == torch.int64 and gathered.is_contiguous()
+    dev = gathered.device
+    if global_record is None:
+        global_record = torch.empty((batch, words), dtype=torch.int64, device=dev)
+    if best_h is None:
+        best_h = torch.empty((batch,), dtype=torch.int64, device=dev)
+    if single is None:
+        single = torch.empty((batch, words), dtype=torch.int64, device=dev)
+    if gathered.is_cuda:
+        check(lib.sfm_fold_select_records(gathered.data_ptr(), world, batch, global_record.data_ptr(),
+                                          best_h.data_ptr(), single.data_ptr(),
+                                          torch.cuda.current_stream().cuda_stream), "sfm_fold_select_records")
+    else:
+        check(lib.sfm_fold_select_records_host(gathered.data_ptr(), world, batch, global_record.data_ptr(),
+                                               best_h.data_ptr(), single.data_ptr()),
+              "sfm_fold_select_records_host")
+    return global_record, best_h, single
+
+
+def read_records(record: torch.Tensor):
+    """Host copies of int64 [batch, 5] records as ``SelectResult`` structures (synchronises)."""
+    raw = record.cpu().numpy().tobytes()
+    size = C.sizeof(SelectResult)
+    return [SelectResult.from_buffer_copy(raw[i * size:(i + 1) * size]) for i in range(record.shape[0])]
+
+
+def degenerate_policy(policy: Optional[str] = None) -> str:
+    policy = (policy or os.environ.get("SFM_DEGENERATE", "raise")).lower()
+    if policy not in ("raise", "skip"):
+        raise ValueError(f"SFM_DEGENERATE must be 'raise' or 'skip', got {policy!r}")
+    return policy
+
+
+class ShardedOutcome(NamedTuple):
+    best_h: int                    # global index of the winning hypothesis, -1 if none
+    error: float                   # its aggregated inlier error (+inf if none)
+    E: Optional[np.ndarray]        # (3,3)
+    sample: Optional[np.ndarray]   # (8,) indices of its sample
+    mask: Optional[np.ndarray]     # (N,) uint8: 1 survivor, 2 sample point
+    n_flagged: int                 # degenerate samples among ALL ranks' hypotheses
+    first_flagged: int             # lowest global index of one, -1 if none
+
+
+class ShardedRansac:
+    """RANSAC-E over ``world`` GPUs.  Either ``hypotheses_per_rank`` (rank r owns [r*H, (r+1)*H) of the Philox
+    stream: weak scaling) or ``total_hypotheses`` (the global count is split by ``shard_range``: BASELINE
+    config 4, 1 M hypotheses over 8 GPUs).
+
+    ``step`` enqueues sample -> fit -> score -> select on the local shard, the 40-byte all-gather, the fold and
+    the local re-derivation of the global winner (sample, E, inlier mask) — no host synchronisation.
     """
 
-    def __init__(self, corr: torch.Tensor, hypotheses_per_rank: int, thr: float, min_extra: float,
-                 aggregation: int, rank: int = 0, world: int = 1, group=None):
+    def __init__(self, corr: torch.Tensor, hypotheses_per_rank: Optional[int], thr: float, min_extra: float,
+                 aggregation: int, rank: int = 0, world: int = 1, group=None,
+                 total_hypotheses: Optional[int] = None):
         from . import device
 
         self.device_api = device
         self.corr = corr.reshape(1, -1, 4)
         self.n = self.corr.shape[1]
-        self.h = hypotheses_per_rank
+        if total_hypotheses is not None:
+            self.h_begin, self.h = shard_range(total_hypotheses, rank, world)
+            self.total = total_hypotheses
+        else:
+            self.h_begin, self.h = rank * hypotheses_per_rank, hypotheses_per_rank
+            self.total = hypotheses_per_rank * world
         self.thr, self.min_extra, self.aggregation = thr, min_extra, aggregation
         self.rank, self.world, self.group = rank, world, group
         dev = corr.device
-        self.ws = device.RansacWorkspace(1, self.n, self.h, dev)
-        # winner re-derivation buffers (one hypothesis)
-        self.win_S = torch.empty((1, 1, 8), dtype=torch.int32, device=dev)
-        self.win_E = torch.empty((1, 1, 9), dtype=torch.float64, device=dev)
-        self.win_flags = torch.empty((1, 1), dtype=torch.int32, device=dev)
-        self.win_record = torch.zeros((1, 5), dtype=torch.int64, device=dev)
-        if world == 1:  # the local record is the global one: views, no copies
-            self.global_key, self.global_best = self.ws.result[:, 0], self.ws.result[:, 1]
+        self.ws = device.RansacWorkspace(1, self.n, self.h, dev)  # h == 0 (more ranks than hypotheses) is a valid empty shard
+        if world == 1:  # the local record is the global one: views, no copies, no exchange
+            self.global_record = self.ws.result
+            self.global_best = self.ws.result[:, 1]
         else:
-            self.global_key = torch.empty((1,), dtype=torch.int64, device=dev)
+            words = RECORD_WORDS
+            self.gathered = torch.empty((world, 1, words), dtype=torch.int64, device=dev)
+            self.global_record = torch.empty((1, words), dtype=torch.int64, device=dev)
             self.global_best = torch.empty((1,), dtype=torch.int64, device=dev)
-
+            self.win_record = torch.empty((1, words), dtype=torch.int64, device=dev)
+            # winner re-derivation buffers (one hypothesis)
+            self.win_S = torch.empty((1, 1, 8), dtype=torch.int32, device=dev)
+            self.win_E = torch.empty((1, 1, 9), dtype=torch.float64, device=dev)
+            self.win_flags = torch.empty((1, 1), dtype=torch.int32, device=dev)
         self.graph = None
         self.seed_dev = None
 
     def _local_pass(self, seed) -> None:
         """sample -> fit -> score -> select on this rank's shard (+ mask when the winner is local).
         ``seed=None`` reads the seed from ``self.seed_dev`` (the form a HIP graph can replay)."""
-        begin = self.rank * self.h
-        source = (self.seed_dev if seed is None else seed, begin, 1)  # sampled inside the fit kernel
+        source = (self.seed_dev if seed is None else seed, self.h_begin, 1)  # sampled inside the fit kernel
         if self.world == 1:
             # single GPU: the winner is local — mask straight from the shard's own E / S
-            self.ws.run(self.corr, self.thr, self.min_extra, self.aggregation, h_offset=0, with_mask=True, philox=source)
-        else:
-            self.ws.run(self.corr, self.thr, self.min_extra, self.aggregation, h_offset=begin, with_mask=False,
+            self.ws.run(self.corr, self.thr, self.min_extra, self.aggregation, h_offset=0, with_mask=True,
                         philox=source)
+        else:
+            self.ws.run(self.corr, self.thr, self.min_extra, self.aggregation, h_offset=self.h_begin,
+                        with_mask=False, philox=source)
 
     def capture(self) -> None:
         """Record the local pass once into a HIP graph; later ``step`` calls rewrite one seed word in device
-        memory and replay it (one graph launch instead of ~a dozen kernel launches — what bounds small
-        problems such as the demo's N~300 x H=2000).  Only single-GPU passes are captured whole; with
-        world > 1 the graph covers the local pass and the exchange stays eager."""
+        memory and replay it.  With world > 1 the graph covers the local pass and the exchange stays eager.
+        Every buffer the captured kernels touch is allocated before capture begins (``RansacWorkspace`` and
+        ``seed_dev``): nothing is allocated from the graph's private pool."""
         self.seed_dev = torch.zeros(1, dtype=torch.int64, device=self.corr.device)
         side = torch.cuda.Stream(device=self.corr.device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            self._local_pass(None)  # warm-up outside capture (lazy module loads, workspace sizing)
+            self._local_pass(None)  # warm-up outside capture (lazy module loads)
         torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
@@ -134,38 +186,55 @@ class ShardedRansac:
         self.graph = graph
 
     def step(self, seed: int) -> None:
-        d = self.device_api
+        self.step_local(seed)
+        if self.world > 1:
+            gather_records(self.ws.result, self.gathered, self.group)   # the one collective: 40 B per rank
+            self.finish(seed)
+
+    def step_local(self, seed: int) -> None:
+        """This rank's share of a pass: sample -> fit -> score -> select over its own hypotheses; leaves the
+        rank's select record (global indices) in ``self.ws.result``."""
         if self.graph is not None:
             s = seed & (2**64 - 1)
             self.seed_dev.fill_(s - 2**64 if s >= 2**63 else s)
             self.graph.replay()
         else:
             self._local_pass(seed)
-        if self.world == 1:
-            return
-        key, best = self.ws.result[:, 0].contiguous(), self.ws.result[:, 1].contiguous()
-        gkey, gbest = reduce_best(key, best, self.group)
-        self.global_key.copy_(gkey)
-        self.global_best.copy_(gbest)
+
+    def finish(self, seed: int, gathered: Optional[torch.Tensor] = None) -> None:
+        """Fold the gathered records and re-derive the global winner locally.  ``gathered`` ([world, 1, 5] int64)
+        defaults to what ``step`` all-gathered; tests that run several virtual ranks on one GPU pass the stacked
+        records of those ranks instead."""
+        d = self.device_api
+        if gathered is not None:
+            self.gathered.copy_(gathered)
+        fold_records(self.gathered, self.global_record, self.global_best, self.win_record)
         # every rank re-derives the winner from (seed, h*): same code path -> bit-identical E
         d.sample_philox_at(seed, self.global_best, self.n, out=self.win_S)
         d.fit_eight_point(self.corr, self.win_S, self.win_E, self.win_flags)
-        self.win_record[:, 0] = gkey
-        self.win_record[:, 1] = torch.where(gbest >= 0, torch.zeros_like(gbest), gbest)
         d.inlier_mask(self.corr, self.win_E, self.win_S, self.win_record, self.thr, self.ws.mask)
 
-    def outcome(self):
-        """Host copy of the global winner (synchronises): (best_h, error, E (3,3), sample, mask)."""
-        import numpy as np
+    def outcome(self, policy: Optional[str] = None) -> ShardedOutcome:
+        """Host copy of the global winner (synchronises).  A degenerate sample anywhere in the global hypothesis
+        range raises ``EightPointCalculationError`` on every rank alike unless the policy (argument, else
+        ``SFM_DEGENERATE``) is "skip" — the reference aborts the whole call (eight_point.py:415-421 through
+        ransac.py:65), exactly as the single-GPU drop-in path does."""
+        rec = read_records(self.global_record)[0]
+        first = -1 if rec.first_flagged == INT64_MAX else int(rec.first_flagged)
+        n_flagged = int(rec.n_flagged)
+        if n_flagged and degenerate_policy(policy) == "raise":
+            from .epipolar.eight_point import EightPointCalculationError
 
-        best = int(self.global_best.cpu()[0])
+            raise EightPointCalculationError(
+                "More than one eigenvalue of Y.T @ Y is small. Cannot confidently estimate"
+                f" fundamental matrix. (hypothesis {first}, {n_flagged} in total)")
+        best = int(rec.best_h)
         if best < 0:
-            return -1, float("inf"), None, None, None
-        err = float(self.global_key.view(torch.float64).cpu()[0])
+            return ShardedOutcome(-1, float("inf"), None, None, None, n_flagged, first)
         if self.world == 1:
             E = self.ws.E[0, best].cpu().numpy().reshape(3, 3)
             sample = self.ws.S[0, best].cpu().numpy().astype(np.int64)
         else:
             E = self.win_E.cpu().numpy().reshape(3, 3)
             sample = self.win_S.cpu().numpy().reshape(8).astype(np.int64)
-        return best, err, E, sample, self.ws.mask.cpu().numpy()[0]
+        return ShardedOutcome(best, float(rec.best_err), E, sample, self.ws.mask.cpu().numpy()[0], n_flagged, first)

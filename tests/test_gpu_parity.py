@@ -505,40 +505,153 @@ def test_triangulate_random_geometries(dev):
 # ------------------------------------------------------------------------------------------------------
 # sharding: G virtual shards on one GPU through the sharded engine == one run over all hypotheses
 # ------------------------------------------------------------------------------------------------------
+def run_virtual_shards(dev, corr_d, total, world, seed, thr=1.5e-6, min_extra=10, spoil=None):
+    """``world`` virtual ranks on one GPU: each runs ShardedRansac.step_local over its shard_range of ``total``
+    hypotheses; their records are stacked exactly as the all-gather would deliver them and every rank finishes
+    from that.  ``spoil(rank, engine)`` may tamper with a rank's buffers between the fit and the selection.
+    Returns the engines."""
+    from structure_from_motion_amd import distributed
+    from structure_from_motion_amd._native import AGG_RMS
+
+    engines = [distributed.ShardedRansac(corr_d, None, thr, min_extra, AGG_RMS, rank=r, world=world,
+                                         total_hypotheses=total) for r in range(world)]
+    for r, eng in enumerate(engines):
+        eng.step_local(seed)
+        if spoil is not None and spoil(r, eng):
+            # redo the selection over the tampered buffers (same call the local pass makes)
+            dev.select_best(eng.ws.cnt, eng.ws.s1, eng.ws.s2, eng.ws.flags, min_extra, AGG_RMS, eng.h_begin,
+                            eng.ws.result)
+    gathered = torch.stack([eng.ws.result for eng in engines])   # [world, 1, 5], rank-major
+    for eng in engines:
+        eng.finish(seed, gathered)
+    return engines
+
+
 def test_virtual_shards_equal_single_run(dev):
+    from structure_from_motion_amd import distributed
+    from structure_from_motion_amd._native import AGG_RMS
+
+    n, total, G, seed = 1500, 1601, 4, 21   # 1601: the last shard is shorter than the others
+    _, _, _, corr = scene(n)
+    corr_d = dev.to_device(corr)
+    whole = distributed.ShardedRansac(corr_d, total, 1.5e-6, 10, AGG_RMS, rank=0, world=1)
+    whole.step(seed)
+    want = whole.outcome()
+    engines = run_virtual_shards(dev, corr_d, total, G, seed)
+    assert [e.h for e in engines] == [401, 401, 401, 398]
+    for eng in engines:   # every rank arrives at the same winner, E, sample and mask — those of the single run
+        got = eng.outcome()
+        assert got.best_h == want.best_h and got.error == want.error and got.n_flagged == 0
+        np.testing.assert_array_equal(got.E, want.E)
+        np.testing.assert_array_equal(got.sample, want.sample)
+        np.testing.assert_array_equal(got.mask, want.mask)
+    ref = orc.ransac_essential(corr, orc.philox_sample_table(seed, 0, total, n), 1.5e-6, 10, orc.RMS)
+    assert ref["best"] == want.best_h
+    np.testing.assert_array_equal(np.nonzero(want.mask)[0], np.sort(ref["inliers"]))
+    # more ranks than hypotheses: empty shards publish "no model" records and the fold ignores them
+    tiny = run_virtual_shards(dev, corr_d, 5, 8, seed, min_extra=0)
+    assert [e.h for e in tiny] == [1, 1, 1, 1, 1, 0, 0, 0]
+    ref = orc.ransac_essential(corr, orc.philox_sample_table(seed, 0, 5, n), 1.5e-6, 0, orc.RMS)
+    assert all(e.outcome().best_h == ref["best"] for e in tiny)
+
+
+def test_virtual_shards_degenerate_sample_reaches_every_rank(dev):
+    """A degenerate sample on ONE rank (eight_point.py:415-421) must abort the call on EVERY rank, as it does
+    in the reference (ransac.py:65) and in the single-GPU drop-in path; SFM_DEGENERATE=skip drops the hypothesis
+    everywhere instead — also when it would have been the winner."""
+    from structure_from_motion_amd.epipolar.eight_point import EightPointCalculationError
+
+    n, total, G, seed = 1200, 800, 4, 33
+    _, _, _, corr = scene(n)
+    corr_d = dev.to_device(corr)
+    clean = run_virtual_shards(dev, corr_d, total, G, seed)
+    winner = clean[0].outcome()
+    owner = winner.best_h // 200
+    victim = winner.best_h - owner * 200
+
+    def spoil(rank, eng):   # flag the would-be winner as degenerate on its own rank
+        if rank != owner:
+            return False
+        eng.ws.flags[0, victim] = 1
+        return True
+
+    spoiled = run_virtual_shards(dev, corr_d, total, G, seed, spoil=spoil)
+    for eng in spoiled:
+        with pytest.raises(EightPointCalculationError, match=f"hypothesis {winner.best_h}, 1 in total"):
+            eng.outcome()
+        with pytest.raises(EightPointCalculationError):
+            eng.outcome(policy="raise")
+    # skip: the flagged hypothesis does not compete; the runner-up of the sequential rule wins on every rank
+    S = orc.philox_sample_table(seed, 0, total, n)
+    E, _, _ = orc.fit_hypotheses(corr, S)
+    cnt, s1, s2 = orc.score_hypotheses(corr, E, S, 1.5e-6)
+    err = orc.aggregate(cnt, s1, s2, orc.RMS)
+    err[winner.best_h] = np.inf
+    runner_up, _ = orc.select_best(err, cnt, 10)
+    outs = [eng.outcome(policy="skip") for eng in spoiled]
+    assert all(o.best_h == runner_up and o.n_flagged == 1 and o.first_flagged == winner.best_h for o in outs)
+    for o in outs[1:]:
+        np.testing.assert_array_equal(o.E, outs[0].E)
+        np.testing.assert_array_equal(o.mask, outs[0].mask)
+
+
+def test_c4_virtual_shards_full_size(dev):
+    """BASELINE config 4 at its real shape — 1 000 000 hypotheses over 8 ranks (125 000 each) x 50 000
+    correspondences — as 8 virtual ranks on one GPU.  Beyond the oracle's reach in seconds, so size-independent
+    properties per shard (count = population of the hypothesis' own mask for the shard winner, shard winner = host
+    argmin of the device errors, a strided sub-sample equals the oracle) plus: the fold equals the host reduction of
+    the eight records, and the winner re-derived from (seed, h*) on every rank equals the owning shard's own E / S,
+    with global indices beyond 2^19 in play."""
     from structure_from_motion_amd import distributed
     from structure_from_motion_amd._native import AGG_RMS, INT64_MAX
 
-    n, h, G, seed = 1500, 400, 4, 21
+    n, total, G, seed = 50_000, 1_000_000, 8, 5
+    thr, min_extra = 1.5e-6, 10
     _, _, _, corr = scene(n)
     corr_d = dev.to_device(corr)
-    whole = distributed.ShardedRansac(corr_d, h * G, 1.5e-6, 10, AGG_RMS, rank=0, world=1)
-    whole.step(seed)
-    want = whole.outcome()
-    keys, bests = [], []
-    for r in range(G):
-        shard = distributed.ShardedRansac(corr_d, h, 1.5e-6, 10, AGG_RMS, rank=r, world=1)
-        shard.rank = r  # hypotheses [r*h, (r+1)*h) of the same Philox stream
-        shard.step(seed)
-        keys.append(int(shard.ws.result[0, 0].cpu()))
-        local = int(shard.ws.result[0, 1].cpu())  # world == 1 reports shard-local indices
-        bests.append(local + r * h if local >= 0 else -1)
-    # the two MIN reductions of distributed.reduce_best, done by hand over the virtual ranks
-    gkey = min(keys)
-    gbest = min([b for k, b in zip(keys, bests) if k == gkey and b >= 0] or [-1])
-    assert gbest == want[0]
-    assert np.int64(gkey).view(np.float64) == want[1]
-    # re-derivation of the winner from (seed, h*) gives the same E / sample / mask on any rank
-    any_rank = distributed.ShardedRansac(corr_d, h, 1.5e-6, 10, AGG_RMS, rank=3, world=1)
-    any_rank.global_best.fill_(gbest)
-    d = dev
-    d.sample_philox_at(seed, any_rank.global_best, n, out=any_rank.win_S)
-    d.fit_eight_point(any_rank.corr, any_rank.win_S, any_rank.win_E, any_rank.win_flags)
-    np.testing.assert_array_equal(any_rank.win_E.cpu().numpy().reshape(3, 3), want[2])
-    np.testing.assert_array_equal(any_rank.win_S.cpu().numpy().reshape(8), want[3])
-    ref = orc.ransac_essential(corr, orc.philox_sample_table(seed, 0, h * G, n), 1.5e-6, 10, orc.RMS)
-    assert ref["best"] == want[0]
-    np.testing.assert_array_equal(np.nonzero(want[4])[0], np.sort(ref["inliers"]))
+    engines = run_virtual_shards(dev, corr_d, total, G, seed)
+    assert [(e.h_begin, e.h) for e in engines] == [(r * 125_000, 125_000) for r in range(G)]
+    records, shard_err = [], []
+    for r, eng in enumerate(engines):
+        rec = distributed.read_records(eng.ws.result)[0]
+        records.append(rec)
+        cnt = eng.ws.cnt.cpu().numpy()[0]
+        s2 = eng.ws.s2.cpu().numpy()[0]
+        err = orc.aggregate(cnt, s2, s2, orc.RMS)
+        best, best_err = orc.select_best(err, cnt, min_extra)
+        assert rec.best_h == best + eng.h_begin and rec.best_err == best_err and rec.best_cnt == cnt[best]
+        assert rec.n_flagged == 0 and rec.first_flagged == INT64_MAX
+        shard_err.append(best_err)
+        # the shard's samples are the global Philox stream at its offset, its fits and counts the oracle's
+        pick = np.arange(r, eng.h, 24989)
+        S = eng.ws.S.cpu().numpy()[0]
+        np.testing.assert_array_equal(S[pick], orc.philox_sample_table(seed, eng.h_begin, eng.h, n)[pick])
+        E_pick = eng.ws.E.cpu().numpy()[0][pick].reshape(-1, 3, 3)
+        cnt_o, _, s2_o = orc.score_hypotheses(corr, E_pick, S[pick], thr)
+        np.testing.assert_array_equal(cnt[pick], cnt_o)
+        np.testing.assert_allclose(s2[pick], s2_o, rtol=1e-12)
+    # fold == host reduction: lowest error, then lowest global index
+    gmin = min(shard_err)
+    want_h = min(rec.best_h for rec, e in zip(records, shard_err) if e == gmin)
+    assert max(rec.best_h for rec in records) >= 2**19   # global indices beyond 2^19 went through the reducer
+    owner = engines[want_h // 125_000]
+    local = want_h - owner.h_begin
+    E_own = owner.ws.E[0, local].cpu().numpy().reshape(3, 3)
+    S_own = owner.ws.S[0, local].cpu().numpy().astype(np.int64)
+    outs = [eng.outcome() for eng in engines]
+    for o in outs:
+        assert o.best_h == want_h and o.error == gmin
+        np.testing.assert_array_equal(o.E, E_own)        # re-derived winner == the owning shard's own fit, bit for bit
+        np.testing.assert_array_equal(o.sample, S_own)
+        np.testing.assert_array_equal(o.mask, outs[0].mask)
+    assert int((outs[0].mask == 2).sum()) == 8
+    assert int((outs[0].mask == 1).sum()) == int(owner.ws.cnt[0, local].cpu())
+    np.testing.assert_array_equal(np.nonzero(outs[0].mask == 2)[0], np.sort(S_own))
+    # a re-derivation far beyond 2^19 (the last hypothesis of the stream) equals the oracle's sample
+    last = torch.tensor([total - 1], dtype=torch.int64, device=corr_d.device)
+    np.testing.assert_array_equal(dev.sample_philox_at(seed, last, n).cpu().numpy().reshape(8),
+                                  orc.philox_sample_table(seed, total - 1, 1, n)[0])
+    assert rel(outs[0].E, orc.fit_hypotheses(corr, S_own[None, :])[0][0]) <= 1e-6
 
 
 @pytest.mark.parametrize("n,h", [(300, 2000), (9000, 12000)])
@@ -710,6 +823,88 @@ def test_batched_two_view_pipeline(dev):
         np.testing.assert_allclose(res.t, t, atol=1e-6)
         np.testing.assert_array_equal(res.pose_mask, mask)
         assert np.max(np.abs(res.points - pts) / np.linalg.norm(pts, axis=1, keepdims=True)) <= 1e-6
+
+
+def _c5_scenes(B, n):
+    scenes = [orc.synthetic_two_view(n, seed=300 + b, outlier_fraction=0.25) for b in range(B)]
+    return scenes, scenes[0][2]
+
+
+def test_c5_batched_pipeline_full_size(dev, tmp_path):
+    """BASELINE config 5 at its real shape: 256 pairs x 10 000 correspondences x 2 000 hypotheses, E-estimation +
+    cheirality + triangulation on the device in one enqueue.  Exercises the batch-flattened grids and the XCD-aware
+    block -> (pair, block) map of the scoring kernel with all 32 groups of eight pairs.
+      * every pair: count of the winner == population of its mask, winner == host argmin of the device errors;
+      * one pair out of every group of eight, cycling through the residues mod 8, and pair 255: the full oracle comparison of
+        test_batched_two_view_pipeline — winner, ordered inlier list, votes, pose mask bit-exact; E, R, t, points
+        <= 1e-6;
+      * the same batch scored in a child process with SFM_SCORE_XCD=0 (plain (block, pair) grid): byte-identical
+        cnt / s1 / s2."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+
+    from structure_from_motion_amd import batched
+    from structure_from_motion_amd._native import AGG_RMS
+
+    B, n, h, thr, min_extra, seed = 256, 10_000, 2_000, 1.5e-6, 10, 70
+    scenes, K = _c5_scenes(B, n)
+    pix_a = dev.to_device(np.stack([s[0] for s in scenes]))
+    pix_b = dev.to_device(np.stack([s[1] for s in scenes]))
+    pipe = batched.TwoViewBatch(B, n, h)
+    pipe.run(pix_a, pix_b, K, seed=seed, thr=thr, min_extra=min_extra, aggregation=AGG_RMS)
+    results = pipe.results()
+    cnt = pipe.ws.cnt.cpu().numpy()
+    s1 = pipe.ws.s1.cpu().numpy()
+    s2 = pipe.ws.s2.cpu().numpy()
+    mask = pipe.ws.mask.cpu().numpy()
+    assert all(r.status == batched.OK for r in results)
+    for b, res in enumerate(results):
+        err = orc.aggregate(cnt[b], s2[b], s2[b], orc.RMS)
+        best, _ = orc.select_best(err, cnt[b], min_extra)
+        assert res.best_h == best, b
+        assert int((mask[b] == 1).sum()) == cnt[b, best] and int((mask[b] == 2).sum()) == 8, b
+        assert len(res.inlier_order) == cnt[b, best] + 8
+        assert len(res.points) == len(res.pose_mask) and np.all(np.isfinite(res.points))
+    checked = sorted({8 * g + (3 * g) % 8 for g in range(32)} | {B - 1})   # one pair of every group of eight
+    assert {b % 8 for b in checked} == set(range(8)) and {b // 8 for b in checked} == set(range(32))
+    for b in checked:
+        ref, order, R, t, pmask, votes, pts = _oracle_pair(scenes[b][0], scenes[b][1], K, seed + b, h, thr, min_extra)
+        res = results[b]
+        assert res.best_h == ref["best"], b
+        assert rel(res.E, ref["E"]) <= 1e-6
+        np.testing.assert_array_equal(res.inlier_order, order)
+        assert sorted(res.votes.tolist()) == sorted(votes)
+        np.testing.assert_allclose(res.R, R, atol=1e-6)
+        np.testing.assert_allclose(res.t, t, atol=1e-6)
+        np.testing.assert_array_equal(res.pose_mask, pmask)
+        assert np.max(np.abs(res.points - pts) / np.linalg.norm(pts, axis=1, keepdims=True)) <= 1e-6
+        np.testing.assert_array_equal(cnt[b], ref["cnt"])      # every hypothesis of the pair, not only the winner
+        np.testing.assert_allclose(s2[b], ref["s2"], rtol=1e-12)
+    digest = hashlib.sha256(cnt.tobytes() + s1.tobytes() + s2.tobytes()).hexdigest()
+    del pipe
+    torch.cuda.empty_cache()
+    out_file = tmp_path / "digest.txt"
+    code = (
+        "import hashlib, sys\n"
+        "import numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from oracle import sfm_oracle as orc\n"
+        "from structure_from_motion_amd import batched, device as dev\n"
+        "from structure_from_motion_amd._native import AGG_RMS\n"
+        "B, n, h = 256, 10000, 2000\n"
+        "scenes = [orc.synthetic_two_view(n, seed=300 + b, outlier_fraction=0.25) for b in range(B)]\n"
+        "pipe = batched.TwoViewBatch(B, n, h)\n"
+        "pipe.run(dev.to_device(np.stack([s[0] for s in scenes])), dev.to_device(np.stack([s[1] for s in scenes])),\n"
+        "         scenes[0][2], seed=70, thr=1.5e-6, min_extra=10, aggregation=AGG_RMS)\n"
+        "cnt, s1, s2 = (t.cpu().numpy() for t in (pipe.ws.cnt, pipe.ws.s1, pipe.ws.s2))\n"
+        "open(%r, 'w').write(hashlib.sha256(cnt.tobytes() + s1.tobytes() + s2.tobytes()).hexdigest())\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(out_file))
+    env = dict(os.environ, SFM_SCORE_XCD="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out_file.read_text() == digest   # the block -> pair map only moves work between XCDs
 
 
 def test_batched_pipeline_with_local_optimisation(dev):
