@@ -7,15 +7,24 @@ pass (sample -> eight-point fit -> SED scoring -> selection -> inlier mask), inp
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Workload: the configuration the north-star target is quoted on — 50 000 correspondences x 100 000
-hypotheses per GPU (BASELINE.json configs[2]); with N GPUs every rank processes its own 100 000
-hypotheses of one global Philox stream (weak scaling) and one 16-byte RCCL exchange per step picks the
-global best model.  One JSON line on stdout (rank 0).
+Workload.  N = 1: the configuration the north-star target is quoted on — 50 000 correspondences x 100 000
+hypotheses (BASELINE.json configs[2]).  N > 1: BASELINE.json configs[3] — 1 000 000 hypotheses of ONE global
+Philox stream split over the N ranks (1 000 000 // N each, 125 000 at N = 8), one 40-byte all-gather per step to
+pick the global best model; `--hypotheses H` overrides with H per rank (weak scaling).  One JSON line on stdout
+(rank 0).
+
+Roofline.  The correspondence set (1.6 MB) is L2-resident, so HBM bytes do not bound the scoring kernel; VALU issue
+does.  `roofline.frac` = (VALU wave-instructions of one launch, from the committed rocprofv3 PMC passes, priced at
+the spec issue rates of MI355X_MICROARCH.md: 2 cycles per wave64 instruction on the SIMD-32 pipes, 4 for fp64) /
+(1024 SIMDs x 2.4 GHz x the kernel's duration measured live with HIP events around that kernel).  The HBM views the
+contract asks for are kept beside it: `hbm_algorithmic` (32 B per evaluation / kernel time — exceeds the peak
+because the set is cache-resident) and `hbm_physical` (FETCH_SIZE x 2 + WRITE_SIZE per launch / kernel time).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import random
 import subprocess
 import sys
 import time
@@ -28,18 +37,25 @@ if REPO not in sys.path:
 
 BYTES_PER_EVAL = 32.0          # xa, ya, xb, yb as f64, read once per hypothesis
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); ~6290 measured-achievable
+SIMDS, CLOCK_GHZ = 1024, 2.4   # 256 CUs x 4 SIMD-32; max clock (MI355X_MICROARCH.md chip table)
+CYC_VALU, CYC_F64 = 2.0, 4.0   # spec issue cycles per wave64 instruction: v_fma_f32 2 (SIMD-32); fp64 at half rate
 THR, MIN_EXTRA = 1.5e-6, 10    # reference apps/config/config.yaml:6-9 (RMS aggregation)
+C4_TOTAL = 1_000_000           # BASELINE.json configs[3]
+COUNTERS = os.path.join(REPO, "profiles", "score_traffic.json")
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--matches", type=int, default=50_000)
-    ap.add_argument("--hypotheses", type=int, default=100_000, help="per GPU")
+    ap.add_argument("--hypotheses", type=int, default=None,
+                    help="per GPU (default: 100 000 at --gpus 1, 1 000 000 // N at --gpus N)")
     ap.add_argument("--seed", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the kernel variants and the through-the-API timings (profiling runs)")
     ap.add_argument("--graph", action="store_true",
                     help="replay each step as one captured HIP graph (for launch-bound small workloads)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration")
@@ -48,7 +64,9 @@ def parse():
 
 def cpu_baseline(corr: np.ndarray, seed: int, target_seconds: float):
     """Times the CPU oracle (numpy eight-point fit + plain-C/OpenMP SED scoring + numpy selection) on a
-    bounded number of hypotheses of the same workload.  The oracle is only the thing timed here."""
+    bounded number of hypotheses of the same workload.  The oracle is only the thing timed here.  The fit is a
+    single-threaded numpy restatement and the scoring leg an OpenMP C loop, so both legs are also reported on
+    their own: `value` is the whole stage the metric names, `score_leg_value` the H x N loop alone."""
     from oracle import sfm_oracle as orc
 
     # build output (if any) goes to stderr: stdout carries exactly one JSON line
@@ -60,20 +78,29 @@ def cpu_baseline(corr: np.ndarray, seed: int, target_seconds: float):
     n = corr.shape[0]
     # a 1-GPU box's CPU share is 16 cores even when the host exposes more hardware threads
     threads = int(os.environ.get("SFM_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16)))
+    legs = {"fit": 0.0, "score": 0.0, "select": 0.0}
 
-    def run(h, h_begin):
+    def run(h, h_begin, record=True):
+        t0 = time.perf_counter()
         S = orc.philox_sample_table(seed, h_begin, h, n)
         E, deg, _ = orc.fit_hypotheses(corr, S)
         E = np.ascontiguousarray(E.reshape(h, 9))
+        t1 = time.perf_counter()
         cnt = np.zeros(h, dtype=np.int32)
         s1 = np.zeros(h)
         s2 = np.zeros(h)
         used = lib.sfm_oracle_score(corr.ctypes.data, n, E.ctypes.data, S.ctypes.data, h, THR,
                                     cnt.ctypes.data, s1.ctypes.data, s2.ctypes.data, threads)
+        t2 = time.perf_counter()
         best, err = orc.select_best(orc.aggregate(cnt, s1, s2, orc.RMS), cnt, MIN_EXTRA)
+        t3 = time.perf_counter()
+        if record:
+            legs["fit"] += t1 - t0
+            legs["score"] += t2 - t1
+            legs["select"] += t3 - t2
         return used, err
 
-    run(64, 0)  # warm the caches / thread pool
+    run(64, 0, record=False)  # warm the caches / thread pool
     chunk, done, used = 10_000, 0, 1
     t0 = time.perf_counter()
     while True:
@@ -87,35 +114,120 @@ def cpu_baseline(corr: np.ndarray, seed: int, target_seconds: float):
         "unit": "correspondence-evals/s",
         "cores": used,
         "kind": "port",
+        "score_leg_value": n * done / legs["score"] if legs["score"] > 0 else None,
+        "seconds": {k: round(v, 3) for k, v in legs.items()},
         "sample": f"{done} hypotheses x {n} matches of the same workload in {elapsed:.1f} s: numpy eight-point "
-                  f"fit (1 thread) + C/OpenMP SED scoring ({used} threads) + numpy selection",
+                  f"fit (1 thread, {legs['fit']:.1f} s) + C/OpenMP SED scoring ({used} threads, "
+                  f"{legs['score']:.1f} s) + numpy selection; score_leg_value = the H x N loop alone",
     }
 
 
-def measured_valu(n, h):
-    """VALU-issue evidence for the dominant kernel from the committed PMC summary (the bound that actually holds:
-    the data set is cache-resident) — None for other workload sizes."""
-    path = os.path.join(REPO, "profiles", "score_traffic.json")
+def load_counters(n, h):
+    """The committed rocprofv3 PMC record of the scoring kernel (tools/collect_counters.sh) and whether it was taken on
+    the kernel sources this process runs: (record or None, stale flag)."""
+    from structure_from_motion_amd import build
+
     try:
-        rec = json.load(open(path))
+        rec = json.load(open(COUNTERS))
     except (OSError, ValueError):
-        return None
-    if rec.get("matches") != n or rec.get("hypotheses") != h:
-        return None
-    return rec.get("valu")
+        return None, None
+    if rec.get("matches") != n or rec.get("hypotheses") != h or "counters" not in rec:
+        return None, None
+    return rec, rec.get("source_sha") != build.score_source_sha()
 
 
-def measured_traffic(n, h):
-    """HBM bytes per score-kernel launch from the committed rocprofv3 PMC passes (profiles/), if they were
-    taken on this workload: 2 x FETCH_SIZE (gfx950 counts 128-B requests as 64 B) + WRITE_SIZE."""
-    path = os.path.join(REPO, "profiles", "score_traffic.json")
+def roofline(n, h, kernel_ms, call_ms, variant):
+    evals = float(n) * float(h)
+    seconds = kernel_ms * 1e-3
+    algorithmic = evals * BYTES_PER_EVAL
+    rec, stale = load_counters(n, h)
+    out = {
+        "bound": "valu-issue",
+        "kernel": "score_sed_filtered_kernel" if variant == "filtered" else "score_sed_exact_kernel",
+        "kernel_ms": kernel_ms,
+        "score_call_ms": call_ms,
+        "achieved": None, "peak": SIMDS * CLOCK_GHZ, "unit": "G wave-instruction issue cycles/s", "frac": None,
+        "traffic": None,
+        "hbm_algorithmic": {"bytes_per_launch": algorithmic, "achieved_GBs": algorithmic / seconds / 1e9,
+                            "peak_GBs": HBM_PEAK_GBS, "frac": algorithmic / seconds / 1e9 / HBM_PEAK_GBS,
+                            "note": "32 B/eval x matches x hypotheses / kernel time; > 1 because the 1.6 MB "
+                                    "correspondence set is L2-resident: not a bound for this kernel"},
+        "hbm_physical": None,
+        "counters_stale": stale,
+        "note": "frac = (VALU wave-instructions per launch x spec issue cycles: 2 per wave64 instruction, 4 per fp64 "
+                "one) / (1024 SIMDs x 2.4 GHz x kernel time by HIP events around the kernel); counters from "
+                "profiles/score_traffic.json (rocprofv3 --pmc, separate passes)",
+    }
+    if rec is None or variant != "filtered":
+        return out
+    c = rec["counters"]
+    f64 = sum(c.get(k, 0.0) for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64",
+                                      "SQ_INSTS_VALU_TRANS_F64"))
+    valu = c["SQ_INSTS_VALU"]
+    mfma = c.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0)
+    cycles = (valu - f64) * CYC_VALU + f64 * CYC_F64
+    out["achieved"] = cycles / seconds / 1e9
+    out["frac"] = out["achieved"] / out["peak"]
+    out["valu"] = {"insts_per_launch": valu, "fp64_insts": f64, "per_64_evals": valu / (evals / 64.0),
+                   "issue_cycles_per_simd": cycles / SIMDS, "mfma_mops_f32": mfma or None}
+    if "GRBM_GUI_ACTIVE" in c and c.get("profiled_kernel_ms"):
+        clock = c["GRBM_GUI_ACTIVE"] / 8.0 / (c["profiled_kernel_ms"] * 1e-3) / 1e9
+        out["valu"]["clock_GHz_under_profiler"] = clock
+        out["frac_at_measured_clock"] = out["frac"] * CLOCK_GHZ / clock if clock > 0 else None
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        traffic = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+        out["traffic"] = traffic
+        out["hbm_physical"] = {"bytes_per_launch": traffic, "achieved_GBs": traffic / seconds / 1e9,
+                               "frac": traffic / seconds / 1e9 / HBM_PEAK_GBS,
+                               "note": "rocprofv3 PMC: 2 x FETCH_SIZE (gfx950 counts 128-B requests as 64 B) + "
+                                       "WRITE_SIZE, KiB, per launch"}
+    out["counters_from"] = {k: rec.get(k) for k in ("git", "source_sha", "abi", "collected")}
+    return out
+
+
+def api_timings(device_mod):
+    """Wall time of the drop-in call itself — lib.epipolar.epipolar_ransac.estimate_essential_mat_with_ransac as
+    reference apps/sfm.py:110-119 calls it (Feature lists in, (E, inlier pairs) out) — at BASELINE configs[0]'s scale
+    (300 x 2000) and configs[1] (5000 x 10000), after one warm-up call each.  Not part of `value`."""
+    from lib.common.feature import Feature
+    from lib.epipolar.eight_point import create_trivial_matches
+    from lib.epipolar.epipolar_ransac import estimate_essential_mat_with_ransac
+    from lib.ransac.ransac import ErrorAggregationMethod
+    from structure_from_motion_amd import synthetic
+
+    out = {}
+    saved = {k: os.environ.get(k) for k in ("SFM_SAMPLER", "SFM_SEED")}
     try:
-        rec = json.load(open(path))
-    except OSError:
-        return None
-    if rec.get("matches") != n or rec.get("hypotheses") != h:
-        return None
-    return (2.0 * rec["fetch_size_kib"] + rec["write_size_kib"]) * 1024.0
+        for name, n, h, sampler in (("c1_300x2000_pyshuffle", 300, 2000, "pyshuffle"),
+                                    ("c2_5000x10000_pyshuffle", 5000, 10000, "pyshuffle"),
+                                    ("c2_5000x10000_philox", 5000, 10000, "philox"),
+                                    ("c2_5000x10000_auto", 5000, 10000, None)):
+            pa, pb, K, *_ = synthetic.two_view_scene(n, seed=6)
+            fa = [Feature(x=float(x), y=float(y)) for x, y in pa]
+            fb = [Feature(x=float(x), y=float(y)) for x, y in pb]
+            matches = create_trivial_matches(n)
+            if sampler is None:
+                os.environ.pop("SFM_SAMPLER", None)
+            else:
+                os.environ["SFM_SAMPLER"] = sampler
+            os.environ["SFM_SEED"] = "5"
+            times = []
+            for rep in range(4):
+                random.seed(5)
+                t0 = time.perf_counter()
+                E, pairs = estimate_essential_mat_with_ransac(
+                    K, features_a=fa, features_b=fb, matches=matches, sed_inlier_threshold=THR,
+                    error_aggregation_method=ErrorAggregationMethod.RMS, min_num_extra_inliers=MIN_EXTRA,
+                    max_iterations=h)
+                times.append((time.perf_counter() - t0) * 1e3)
+            out[name] = {"ms": min(times[1:]), "first_call_ms": times[0], "inliers": len(pairs)}
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return out
 
 
 def main():
@@ -138,27 +250,49 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from structure_from_motion_amd import device, distributed, synthetic
+    from structure_from_motion_amd import _native, build, device, distributed, synthetic
     from structure_from_motion_amd._native import AGG_RMS
 
     device.require_gpu()
-    n, h = args.matches, args.hypotheses
+    n = args.matches
     pa, pb, K, *_ = synthetic.two_view_scene(n, seed=6)
     corr = device.normalize_correspondences(device.to_device(pa), device.to_device(pb), K)
-    engine = distributed.ShardedRansac(corr, h, THR, MIN_EXTRA, AGG_RMS, rank, world)
+    if args.hypotheses is not None:      # explicit per-GPU count: weak scaling
+        engine = distributed.ShardedRansac(corr, args.hypotheses, THR, MIN_EXTRA, AGG_RMS, rank, world)
+        scaling, partition = "weak", f"{args.hypotheses} hypotheses per GPU"
+    elif world == 1:                     # BASELINE configs[2]
+        engine = distributed.ShardedRansac(corr, 100_000, THR, MIN_EXTRA, AGG_RMS, rank, world)
+        scaling, partition = "weak", "BASELINE.json configs[2]: 100000 hypotheses on one GPU"
+    else:                                # BASELINE configs[3]: one global stream of 1 M hypotheses, split
+        engine = distributed.ShardedRansac(corr, None, THR, MIN_EXTRA, AGG_RMS, rank, world,
+                                           total_hypotheses=C4_TOTAL)
+        scaling, partition = "strong", (f"BASELINE.json configs[3]: {C4_TOTAL} hypotheses split over {world} GPUs "
+                                        f"({C4_TOTAL // world} per rank)")
+    h = engine.h
+    total_h = engine.total
 
-    # the dominant kernel (SED scoring) is bracketed with events on the stream it is launched on
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # the dominant kernel is bracketed by HIP events recorded inside sfm_score_sed, immediately around that kernel on
+    # its launch stream; a second pair brackets the whole scoring call (workspace preparation + ordering pre-pass)
+    def make_events(count):
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(count)]
+        for a, b in evs:   # torch creates the hipEvent at the first record
+            a.record()
+            b.record()
+        return evs
+
+    kernel_ev, call_ev = make_events(args.steps), make_events(args.steps)
     score = device.score_sed
     state = {"i": -1}
 
     def timed_score(*a, **k):
         i = state["i"]
         if i >= 0:
-            ev[i][0].record()
+            device.score_timing_events(*kernel_ev[i])
+            call_ev[i][0].record()
         out = score(*a, **k)
         if i >= 0:
-            ev[i][1].record()
+            call_ev[i][1].record()
+            device.score_timing_events(None, None)
         return out
 
     device.score_sed = timed_score
@@ -170,14 +304,39 @@ def main():
 
     for w in range(args.warmup):
         engine.step(args.seed + w)
+
+    variants = None
+    if world == 1 and not args.no_extras and not args.graph:
+        # the same pass with each scoring kernel, 3 steps each: the all-fp64 kernel (every evaluation in fp64) and
+        # the default two-tier kernel (conservative fp32 reject filter + the same fp64 routine for the survivors)
+        variants = {}
+        for name, env in (("exact_f64", "exact"), ("filtered", "filtered")):
+            os.environ["SFM_SCORE_KERNEL"] = env
+            engine.step(args.seed + 77)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for s in range(3):
+                state["i"] = s
+                engine.step(args.seed + 80 + s)
+            torch.cuda.synchronize()
+            wall = (time.perf_counter() - t0) / 3
+            state["i"] = -1
+            variants[name] = {"ms_per_step": wall * 1e3, "value": float(n) * h / wall,
+                              "kernel_ms": float(np.mean([a.elapsed_time(b) for a, b in kernel_ev[:3]]))}
+        os.environ.pop("SFM_SCORE_KERNEL", None)
+
+    variant = os.environ.get("SFM_SCORE_KERNEL", "filtered")
     if args.graph:
         # per-kernel events cannot be recorded inside a replayed graph: time the score kernel on a few
         # eager steps first, then capture
-        for s in range(min(args.steps, 10)):
+        timed = min(args.steps, 10)
+        for s in range(timed):
             state["i"] = s
             engine.step(args.seed + 500 + s)
         state["i"] = -1
-        ev = ev[:min(args.steps, 10)]
+        torch.cuda.synchronize()
+        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in kernel_ev[:timed]]))
+        call_ms = float(np.mean([a.elapsed_time(b) for a, b in call_ev[:timed]]))
         engine.capture()
         engine.step(args.seed + 999)
     barrier()
@@ -193,11 +352,11 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.cpu()[0])
 
-    best_h, err, E, sample, mask = engine.outcome()
-    score_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
-    evals_per_gpu = float(n) * float(h)
-    value = evals_per_gpu * world * args.steps / elapsed
-    achieved = evals_per_gpu * BYTES_PER_EVAL / (score_ms * 1e-3) / 1e9 if score_ms > 0 else None
+    out = engine.outcome()
+    if not args.graph:
+        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in kernel_ev])) if args.steps else float("nan")
+        call_ms = float(np.mean([a.elapsed_time(b) for a, b in call_ev])) if args.steps else float("nan")
+    value = float(n) * float(total_h) * args.steps / elapsed
 
     if rank == 0:
         line = {
@@ -209,37 +368,30 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f64 (+ conservative f32 reject filter)" if variant == "filtered" else "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"synthetic two-view, {n} correspondences x {h} RANSAC hypotheses per GPU "
-                            "(BASELINE.json configs[2]; the configuration the north-star target is quoted on)",
-                "matches": n, "hypotheses_per_gpu": h, "global_hypotheses": h * world,
+                "workload": f"synthetic two-view, {n} correspondences x {total_h} RANSAC hypotheses "
+                            f"({partition})",
+                "matches": n, "hypotheses_per_gpu": h, "global_hypotheses": total_h,
                 "sed_inlier_threshold": THR, "min_num_extra_inliers": MIN_EXTRA, "aggregation": "rms",
                 "sampler": "philox", "parallelism": f"hypothesis-shard x{world}",
+                "exchange": "none" if world == 1 else "one all_gather of a 40-byte select record per rank per step",
                 "launch": "hip-graph" if args.graph else "eager",
+                "library": {"abi": _native.ABI_VERSION, "score_source_sha": build.score_source_sha()},
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "score_sed_filtered_kernel",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                "traffic": measured_traffic(n, h),
-                "traffic_unit": "bytes per launch (rocprofv3 PMC: 2 x FETCH_SIZE + WRITE_SIZE, profiles/)",
-                "algorithmic_bytes": evals_per_gpu * BYTES_PER_EVAL,
-                "valu_issue": measured_valu(n, h),
-                "kernel_variant": os.environ.get("SFM_SCORE_KERNEL", "filtered"),
-                "kernel_ms": score_ms,
-                "note": "achieved = 32 B/eval x matches x hypotheses / avg score-kernel time (HIP events); "
-                        "the correspondence set (1.6 MB f64 + 0.8 MB f32 copy) is L2-resident, so physical HBM "
-                        "traffic is far lower and the kernel is VALU-issue bound (DESIGN.md)",
-            },
-            "result": {"best_h": best_h, "error": err, "inliers": int((mask != 0).sum()) if mask is not None else 0},
+            "roofline": roofline(n, h, kernel_ms, call_ms, variant),
+            "result": {"best_h": out.best_h, "error": out.error,
+                       "inliers": int((out.mask != 0).sum()) if out.mask is not None else 0,
+                       "n_flagged": out.n_flagged},
         }
+        if variants is not None:
+            line["variants"] = variants
+        if world == 1 and not args.no_extras:
+            device.score_sed = score
+            line["api_ms"] = api_timings(device)
         if not args.no_cpu_baseline and world == 1:
             corr_host = corr.cpu().numpy()
             line["cpu_baseline"] = cpu_baseline(corr_host, args.seed, args.cpu_seconds)

@@ -29,6 +29,34 @@ def score_source_sha() -> str:
     return h.hexdigest()[:16]
 
 
+OPS_LIB_PATH = os.path.join(CSRC, "libsfm_torch_ops.so")
+OPS_SOURCE = os.path.join(CSRC, "sfm_torch_ops.cpp")
+
+
+def build_ops(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/sfm_torch_ops.cpp — TORCH_LIBRARY(sfm_hip): the PyTorch-ROCm custom-op registration above the
+    C ABI — into csrc/libsfm_torch_ops.so.  Host code only (g++), linked against libsfm_hip.so and torch's libraries."""
+    deps = [OPS_SOURCE, os.path.join(CSRC, "..", "..", "include", "sfm_hip.h"), os.path.abspath(__file__)]
+    if not force and os.path.exists(OPS_LIB_PATH) and all(
+            os.path.getmtime(d) <= os.path.getmtime(OPS_LIB_PATH) for d in deps):
+        return OPS_LIB_PATH
+    import torch
+
+    troot = os.path.dirname(torch.__file__)
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+           # torch's ROCm headers are the hipified ones: they expect the platform macros of a HIP build
+           "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}",
+           f"-I{troot}/include", f"-I{troot}/include/torch/csrc/api/include", f"-I{rocm}/include",
+           OPS_SOURCE, "-o", OPS_LIB_PATH, f"-L{CSRC}", "-l:libsfm_hip.so", "-Wl,-rpath,$ORIGIN",
+           f"-L{troot}/lib", "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return OPS_LIB_PATH
+
+
 def _stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
@@ -49,5 +77,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+def build_all(force: bool = False, verbose: bool = False):
+    """libsfm_hip.so (kernels + C ABI), then libsfm_torch_ops.so (torch custom ops above it)."""
+    return build(force, verbose), build_ops(force, verbose)
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build_all(force="--force" in sys.argv, verbose=True))

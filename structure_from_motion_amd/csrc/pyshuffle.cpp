@@ -22,23 +22,24 @@ struct Mt19937 {
     uint32_t* mt;
     int index;
 
-    uint32_t next() {
-        if (index >= kN) {
-            static const uint32_t mag01[2] = {0u, 0x9908b0dfu};
-            int kk = 0;
-            for (; kk < kN - kM; ++kk) {
-                const uint32_t y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu);
-                mt[kk] = mt[kk + kM] ^ (y >> 1) ^ mag01[y & 1u];
-            }
-            for (; kk < kN - 1; ++kk) {
-                const uint32_t y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu);
-                mt[kk] = mt[kk + (kM - kN)] ^ (y >> 1) ^ mag01[y & 1u];
-            }
-            const uint32_t y = (mt[kN - 1] & 0x80000000u) | (mt[0] & 0x7fffffffu);
-            mt[kN - 1] = mt[kM - 1] ^ (y >> 1) ^ mag01[y & 1u];
-            index = 0;
+    // regenerate the 624 state words (Modules/_randommodule.c genrand_uint32, the `mti >= N` branch)
+    void regenerate() {
+        static const uint32_t mag01[2] = {0u, 0x9908b0dfu};
+        int kk = 0;
+        for (; kk < kN - kM; ++kk) {
+            const uint32_t y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu);
+            mt[kk] = mt[kk + kM] ^ (y >> 1) ^ mag01[y & 1u];
         }
-        uint32_t y = mt[index++];
+        for (; kk < kN - 1; ++kk) {
+            const uint32_t y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu);
+            mt[kk] = mt[kk + (kM - kN)] ^ (y >> 1) ^ mag01[y & 1u];
+        }
+        const uint32_t y = (mt[kN - 1] & 0x80000000u) | (mt[0] & 0x7fffffffu);
+        mt[kN - 1] = mt[kM - 1] ^ (y >> 1) ^ mag01[y & 1u];
+        index = 0;
+    }
+
+    static inline uint32_t temper(uint32_t y) {
         y ^= (y >> 11);
         y ^= (y << 7) & 0x9d2c5680u;
         y ^= (y << 15) & 0xefc60000u;
@@ -46,11 +47,34 @@ struct Mt19937 {
         return y;
     }
 
-    uint32_t below(uint32_t n) {  // n >= 1, n < 2^31
-        const int k = 32 - __builtin_clz(n);
-        uint32_t r = next() >> (32 - k);
-        while (r >= n) r = next() >> (32 - k);
-        return r;
+    // One descending Fisher-Yates pass over perm[0..n) with CPython's draw sequence.  For all i whose i + 1 has the
+    // same bit length k, randbelow(i + 1) takes getrandbits(k) = word >> (32 - k) and redraws while the value is
+    // >= i + 1.  The redraw is the unpredictable branch of the literal form (taken up to half the time); here a
+    // rejected draw is a swap of perm[i] with itself and leaves i where it was, so the inner loop has no
+    // data-dependent branch: one state word, one compare, one conditional move and one (possibly idle) swap per draw.
+    void shuffle(int32_t* perm, int64_t n) {
+        int64_t i = n - 1;
+        while (i >= 1) {
+            const int k = 64 - __builtin_clzll((unsigned long long)(i + 1));
+            const int shift = 32 - k;
+            const int64_t lowest = ((int64_t)1 << (k - 1)) - 1 > 1 ? ((int64_t)1 << (k - 1)) - 1 : 1;  // same k down to here
+            while (i >= lowest) {
+                if (index >= kN) regenerate();
+                const uint32_t* word = mt + index;
+                const int available = kN - index;
+                int used = 0;
+                while (used < available && i >= lowest) {
+                    const uint32_t r = temper(word[used++]) >> shift;
+                    const bool accept = (int64_t)r <= i;          // r < i + 1
+                    const int64_t j = accept ? (int64_t)r : i;    // rejected: swap perm[i] with itself
+                    const int32_t tmp = perm[i];
+                    perm[i] = perm[j];
+                    perm[j] = tmp;
+                    i -= accept ? 1 : 0;
+                }
+                index += used;
+            }
+        }
     }
 };
 
@@ -72,12 +96,7 @@ extern "C" int sfm_pyshuffle_table(uint32_t* mt_state, int32_t* mt_index, int64_
     }
     const int64_t take = n < 8 ? n : 8;
     for (int64_t it = 0; it < iterations; ++it) {
-        for (int64_t i = n - 1; i >= 1; --i) {
-            const uint32_t j = gen.below((uint32_t)(i + 1));
-            const int32_t tmp = perm[i];
-            perm[i] = perm[j];
-            perm[j] = tmp;
-        }
+        gen.shuffle(perm, n);
         for (int64_t k = 0; k < 8; ++k) S_out[it * 8 + k] = k < take ? perm[k] : -1;
         if (it == snapshot_iteration && snapshot) {
             for (int64_t i = 0; i < n; ++i) snapshot[i] = perm[i];

@@ -1,0 +1,371 @@
+// PyTorch-ROCm custom-op registration of the hot-path kernels: TORCH_LIBRARY(sfm_hip, ...).
+//
+// This is the thin torch-facing layer ABOVE the C ABI of include/sfm_hip.h (which stays free of torch types):
+// every op checks its tensors, takes the current HIP stream from torch and calls the matching sfm_* entry point
+// of libsfm_hip.so.  Op set = SURVEY.md §8b: normalize_coords, sample_philox, fit_eight_point, score_sed,
+// select_best, inlier_mask, cheirality, triangulate — each in a functional form (allocates its outputs; has a Meta
+// kernel, so fake-tensor tracing / torch.compile / opcheck work) and, where the engine pre-allocates its buffers
+// (device.RansacWorkspace), an in-place `_`-suffixed form with mutable arguments, plus the fused
+// sample_fit_philox_.  The reference call sites these serve: apps/sfm.py:110-119 (RANSAC-E), :133-138 (pose),
+// :181-186 (triangulation).
+//
+// Built by structure_from_motion_amd/build.py into csrc/libsfm_torch_ops.so (host code only: no kernels here).
+#include <ATen/ATen.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/library.h>
+
+#include <tuple>
+
+#include "../../include/sfm_hip.h"
+
+namespace {
+
+using at::Tensor;
+
+void* current_stream() { return (void*)c10::hip::getCurrentHIPStream().stream(); }
+
+void ok(int status, const char* what) {
+    TORCH_CHECK(status == SFM_OK, what, " failed (", status, "): ", sfm_last_error());
+}
+
+void need(const Tensor& t, const char* name, at::ScalarType dtype) {
+    TORCH_CHECK(t.is_cuda(), "sfm_hip: ", name, " must be a ROCm device tensor");
+    TORCH_CHECK(t.scalar_type() == dtype, "sfm_hip: ", name, " must have dtype ", dtype, ", got ", t.scalar_type());
+    TORCH_CHECK(t.is_contiguous(), "sfm_hip: ", name, " must be contiguous");
+}
+
+template <typename T>
+T* ptr(const Tensor& t) {
+    return t.numel() ? static_cast<T*>(t.data_ptr()) : nullptr;
+}
+
+template <typename T>
+T* ptr(const std::optional<Tensor>& t) {
+    return t.has_value() && t->defined() ? ptr<T>(*t) : nullptr;
+}
+
+at::TensorOptions like(const Tensor& t, at::ScalarType dtype) { return t.options().dtype(dtype); }
+
+constexpr int64_t kRecordWords = sizeof(sfm_select_result) / 8;
+
+// ---- shape helpers shared by the device and Meta kernels -------------------------------------------------------
+struct Dims {
+    int64_t batch, n, h;
+};
+
+Dims corr_dims(const Tensor& corr) {
+    TORCH_CHECK(corr.dim() == 3 && corr.size(2) == 4, "sfm_hip: corr must be [batch, n, 4]");
+    return {corr.size(0), corr.size(1), 0};
+}
+
+Dims hypothesis_dims(const Tensor& corr, const Tensor& S) {
+    Dims d = corr_dims(corr);
+    TORCH_CHECK(S.dim() == 3 && S.size(0) == d.batch && S.size(2) == 8, "sfm_hip: S must be [batch, h, 8]");
+    d.h = S.size(1);
+    return d;
+}
+
+void check_E(const Tensor& E, const Dims& d) {
+    TORCH_CHECK(E.dim() == 3 && E.size(0) == d.batch && E.size(1) == d.h && E.size(2) == 9,
+                "sfm_hip: E must be [batch, h, 9]");
+}
+
+// ---- normalize_coords ------------------------------------------------------------------------------------------
+void normalize_coords_out(const Tensor& pix_a, const Tensor& pix_b, double fx, double fy, double cx, double cy,
+                          Tensor& out) {
+    need(pix_a, "pix_a", at::kDouble);
+    need(pix_b, "pix_b", at::kDouble);
+    need(out, "out", at::kDouble);
+    TORCH_CHECK(pix_a.sizes() == pix_b.sizes() && pix_a.dim() >= 1 && pix_a.size(-1) == 2,
+                "sfm_hip: pix_a, pix_b must be [..., 2] of equal shape");
+    const int64_t count = pix_a.numel() / 2;
+    TORCH_CHECK(out.numel() == 4 * count, "sfm_hip: out must hold 4 doubles per correspondence");
+    ok(sfm_normalize_correspondences(ptr<double>(pix_a), ptr<double>(pix_b), count, fx, fy, cx, cy, ptr<double>(out),
+                                     current_stream()),
+       "sfm_normalize_correspondences");
+}
+
+std::vector<int64_t> normalized_shape(const Tensor& pix_a) {
+    TORCH_CHECK(pix_a.dim() >= 1 && pix_a.size(-1) == 2, "sfm_hip: pix_a must be [..., 2]");
+    std::vector<int64_t> shape(pix_a.sizes().begin(), pix_a.sizes().end());
+    shape.back() = 4;
+    return shape;
+}
+
+Tensor normalize_coords(const Tensor& pix_a, const Tensor& pix_b, double fx, double fy, double cx, double cy) {
+    Tensor out = at::empty(normalized_shape(pix_a), pix_a.options());
+    normalize_coords_out(pix_a, pix_b, fx, fy, cx, cy, out);
+    return out;
+}
+
+Tensor normalize_coords_meta(const Tensor& pix_a, const Tensor& pix_b, double, double, double, double) {
+    TORCH_CHECK(pix_a.sizes() == pix_b.sizes(), "sfm_hip: pix_a, pix_b must have equal shapes");
+    return at::empty(normalized_shape(pix_a), pix_a.options());
+}
+
+// ---- sample_philox ---------------------------------------------------------------------------------------------
+// seeds travel as int64 (torch schemas have no uint64): the bit pattern is the Philox key
+Tensor sample_philox(int64_t seed, int64_t seed_stride, int64_t h_begin, int64_t h_count, int64_t n, int64_t batch,
+                     at::Device device) {
+    TORCH_CHECK(device.is_cuda(), "sfm_hip::sample_philox: device must be a ROCm device");
+    Tensor S = at::empty({batch, h_count, 8}, at::TensorOptions().dtype(at::kInt).device(device));
+    ok(sfm_sample_philox((uint64_t)seed, (uint64_t)seed_stride, h_begin, h_count, n, batch, ptr<int32_t>(S),
+                         current_stream()),
+       "sfm_sample_philox");
+    return S;
+}
+
+// ---- fit_eight_point -------------------------------------------------------------------------------------------
+void fit_eight_point_out(const Tensor& corr, const Tensor& S, Tensor& E, Tensor& flags) {
+    need(corr, "corr", at::kDouble);
+    need(S, "S", at::kInt);
+    need(E, "E", at::kDouble);
+    need(flags, "flags", at::kInt);
+    const Dims d = hypothesis_dims(corr, S);
+    check_E(E, d);
+    TORCH_CHECK(flags.numel() == d.batch * d.h, "sfm_hip: flags must be [batch, h]");
+    ok(sfm_fit_eight_point(ptr<double>(corr), d.n, ptr<int32_t>(S), d.h, d.batch, ptr<double>(E), ptr<int32_t>(flags),
+                           nullptr, current_stream()),
+       "sfm_fit_eight_point");
+}
+
+std::tuple<Tensor, Tensor> fit_eight_point(const Tensor& corr, const Tensor& S) {
+    const Dims d = hypothesis_dims(corr, S);
+    Tensor E = at::empty({d.batch, d.h, 9}, like(corr, at::kDouble));
+    Tensor flags = at::empty({d.batch, d.h}, like(corr, at::kInt));
+    fit_eight_point_out(corr, S, E, flags);
+    return {E, flags};
+}
+
+std::tuple<Tensor, Tensor> fit_eight_point_meta(const Tensor& corr, const Tensor& S) {
+    const Dims d = hypothesis_dims(corr, S);
+    return {at::empty({d.batch, d.h, 9}, like(corr, at::kDouble)), at::empty({d.batch, d.h}, like(corr, at::kInt))};
+}
+
+// Philox sampling fused into the fit launch; `seed_dev` (int64 [1] on the device) is read at kernel run time when given
+void sample_fit_philox_out(const Tensor& corr, int64_t seed, const std::optional<Tensor>& seed_dev, int64_t seed_stride,
+                           int64_t h_begin, Tensor& S, Tensor& E, Tensor& flags) {
+    need(corr, "corr", at::kDouble);
+    need(S, "S", at::kInt);
+    need(E, "E", at::kDouble);
+    need(flags, "flags", at::kInt);
+    if (seed_dev.has_value()) need(*seed_dev, "seed_dev", at::kLong);
+    const Dims d = hypothesis_dims(corr, S);
+    check_E(E, d);
+    ok(sfm_sample_fit_philox((uint64_t)seed, reinterpret_cast<const uint64_t*>(ptr<int64_t>(seed_dev)),
+                             (uint64_t)seed_stride, h_begin, ptr<double>(corr), d.n, d.h, d.batch, ptr<int32_t>(S),
+                             ptr<double>(E), ptr<int32_t>(flags), current_stream()),
+       "sfm_sample_fit_philox");
+}
+
+// ---- score_sed -------------------------------------------------------------------------------------------------
+void score_sed_out(const Tensor& corr, const Tensor& E, const Tensor& S, double thr, Tensor& cnt, Tensor& s1, Tensor& s2,
+                   const std::optional<Tensor>& workspace) {
+    need(corr, "corr", at::kDouble);
+    need(E, "E", at::kDouble);
+    need(S, "S", at::kInt);
+    need(cnt, "cnt", at::kInt);
+    need(s1, "s1", at::kDouble);
+    need(s2, "s2", at::kDouble);
+    const Dims d = hypothesis_dims(corr, S);
+    check_E(E, d);
+    TORCH_CHECK(cnt.numel() == d.batch * d.h && s1.numel() == cnt.numel() && s2.numel() == cnt.numel(),
+                "sfm_hip: cnt, s1, s2 must be [batch, h]");
+    int64_t ws_bytes = 0;
+    if (workspace.has_value() && workspace->defined()) {
+        need(*workspace, "workspace", at::kByte);
+        ws_bytes = workspace->numel();
+    }
+    ok(sfm_score_sed(ptr<double>(corr), d.n, ptr<double>(E), ptr<int32_t>(S), d.h, d.batch, thr, ptr<int32_t>(cnt),
+                     ptr<double>(s1), ptr<double>(s2), ptr<unsigned char>(workspace), ws_bytes, current_stream()),
+       "sfm_score_sed");
+}
+
+// exact = the all-fp64 kernel; otherwise the two-tier kernel (needs a scratch buffer, allocated here)
+std::tuple<Tensor, Tensor, Tensor> score_sed(const Tensor& corr, const Tensor& E, const Tensor& S, double thr,
+                                             bool exact) {
+    const Dims d = hypothesis_dims(corr, S);
+    Tensor cnt = at::empty({d.batch, d.h}, like(corr, at::kInt));
+    Tensor s1 = at::empty({d.batch, d.h}, like(corr, at::kDouble));
+    Tensor s2 = at::empty({d.batch, d.h}, like(corr, at::kDouble));
+    std::optional<Tensor> workspace;
+    if (!exact) workspace = at::empty({sfm_score_workspace_bytes(d.n, d.h, d.batch)}, like(corr, at::kByte));
+    score_sed_out(corr, E, S, thr, cnt, s1, s2, workspace);
+    return {cnt, s1, s2};
+}
+
+std::tuple<Tensor, Tensor, Tensor> score_sed_meta(const Tensor& corr, const Tensor& E, const Tensor& S, double, bool) {
+    const Dims d = hypothesis_dims(corr, S);
+    check_E(E, d);
+    return {at::empty({d.batch, d.h}, like(corr, at::kInt)), at::empty({d.batch, d.h}, like(corr, at::kDouble)),
+            at::empty({d.batch, d.h}, like(corr, at::kDouble))};
+}
+
+// ---- select_best -----------------------------------------------------------------------------------------------
+void select_best_out(const Tensor& cnt, const Tensor& s1, const Tensor& s2, const std::optional<Tensor>& flags,
+                     double min_extra, int64_t aggregation, int64_t h_offset, Tensor& result) {
+    need(cnt, "cnt", at::kInt);
+    need(s1, "s1", at::kDouble);
+    need(s2, "s2", at::kDouble);
+    need(result, "result", at::kLong);
+    if (flags.has_value()) need(*flags, "flags", at::kInt);
+    TORCH_CHECK(cnt.dim() == 2 && s1.sizes() == cnt.sizes() && s2.sizes() == cnt.sizes(),
+                "sfm_hip: cnt, s1, s2 must be [batch, h]");
+    TORCH_CHECK(result.numel() == cnt.size(0) * kRecordWords, "sfm_hip: result must be int64 [batch, 5]");
+    ok(sfm_select_best(ptr<int32_t>(cnt), ptr<double>(s1), ptr<double>(s2), ptr<int32_t>(flags), cnt.size(1),
+                       cnt.size(0), min_extra, (int)aggregation, h_offset,
+                       reinterpret_cast<sfm_select_result*>(ptr<int64_t>(result)), current_stream()),
+       "sfm_select_best");
+}
+
+Tensor select_best(const Tensor& cnt, const Tensor& s1, const Tensor& s2, const std::optional<Tensor>& flags,
+                   double min_extra, int64_t aggregation, int64_t h_offset) {
+    TORCH_CHECK(cnt.dim() == 2, "sfm_hip: cnt must be [batch, h]");
+    Tensor result = at::empty({cnt.size(0), kRecordWords}, like(cnt, at::kLong));
+    select_best_out(cnt, s1, s2, flags, min_extra, aggregation, h_offset, result);
+    return result;
+}
+
+Tensor select_best_meta(const Tensor& cnt, const Tensor&, const Tensor&, const std::optional<Tensor>&, double, int64_t,
+                        int64_t) {
+    TORCH_CHECK(cnt.dim() == 2, "sfm_hip: cnt must be [batch, h]");
+    return at::empty({cnt.size(0), kRecordWords}, like(cnt, at::kLong));
+}
+
+// ---- inlier_mask -----------------------------------------------------------------------------------------------
+void inlier_mask_out(const Tensor& corr, const Tensor& E, const Tensor& S, const Tensor& result, double thr,
+                     Tensor& mask) {
+    need(corr, "corr", at::kDouble);
+    need(E, "E", at::kDouble);
+    need(S, "S", at::kInt);
+    need(result, "result", at::kLong);
+    need(mask, "mask", at::kByte);
+    const Dims d = hypothesis_dims(corr, S);
+    check_E(E, d);
+    TORCH_CHECK(result.numel() == d.batch * kRecordWords, "sfm_hip: result must be int64 [batch, 5]");
+    TORCH_CHECK(mask.numel() == d.batch * d.n, "sfm_hip: mask must be uint8 [batch, n]");
+    ok(sfm_inlier_mask(ptr<double>(corr), d.n, ptr<double>(E), ptr<int32_t>(S), d.h, d.batch,
+                       reinterpret_cast<const sfm_select_result*>(ptr<int64_t>(result)), thr, ptr<uint8_t>(mask),
+                       current_stream()),
+       "sfm_inlier_mask");
+}
+
+Tensor inlier_mask(const Tensor& corr, const Tensor& E, const Tensor& S, const Tensor& result, double thr) {
+    const Dims d = corr_dims(corr);
+    Tensor mask = at::empty({d.batch, d.n}, like(corr, at::kByte));
+    inlier_mask_out(corr, E, S, result, thr, mask);
+    return mask;
+}
+
+Tensor inlier_mask_meta(const Tensor& corr, const Tensor&, const Tensor&, const Tensor&, double) {
+    const Dims d = corr_dims(corr);
+    return at::empty({d.batch, d.n}, like(corr, at::kByte));
+}
+
+// ---- cheirality / triangulate ------------------------------------------------------------------------------------
+Tensor cheirality(const Tensor& corr, const Tensor& pose_rt, double distance_threshold) {
+    need(corr, "corr", at::kDouble);
+    need(pose_rt, "pose_rt", at::kDouble);
+    TORCH_CHECK(corr.dim() == 2 && corr.size(1) == 4, "sfm_hip: corr must be [m, 4]");
+    TORCH_CHECK(pose_rt.dim() == 2 && pose_rt.size(1) == 12, "sfm_hip: pose_rt must be [poses, 12]");
+    Tensor pass = at::empty({pose_rt.size(0), corr.size(0)}, like(corr, at::kByte));
+    ok(sfm_cheirality(ptr<double>(corr), corr.size(0), ptr<double>(pose_rt), pose_rt.size(0), distance_threshold,
+                      ptr<uint8_t>(pass), current_stream()),
+       "sfm_cheirality");
+    return pass;
+}
+
+Tensor cheirality_meta(const Tensor& corr, const Tensor& pose_rt, double) {
+    TORCH_CHECK(corr.dim() == 2 && corr.size(1) == 4 && pose_rt.dim() == 2 && pose_rt.size(1) == 12,
+                "sfm_hip: corr [m, 4], pose_rt [poses, 12]");
+    return at::empty({pose_rt.size(0), corr.size(0)}, like(corr, at::kByte));
+}
+
+Tensor triangulate(const Tensor& corr, const Tensor& P1, const Tensor& P2) {
+    need(corr, "corr", at::kDouble);
+    need(P1, "P1", at::kDouble);
+    need(P2, "P2", at::kDouble);
+    TORCH_CHECK(corr.dim() == 2 && corr.size(1) == 4, "sfm_hip: corr must be [m, 4]");
+    TORCH_CHECK(P1.numel() == 12 && P2.numel() == 12, "sfm_hip: P1, P2 must hold 12 doubles (rows 0..2, 4 columns)");
+    Tensor X = at::empty({corr.size(0), 3}, corr.options());
+    ok(sfm_triangulate(ptr<double>(corr), corr.size(0), ptr<double>(P1), ptr<double>(P2), ptr<double>(X),
+                       current_stream()),
+       "sfm_triangulate");
+    return X;
+}
+
+Tensor triangulate_meta(const Tensor& corr, const Tensor& P1, const Tensor& P2) {
+    TORCH_CHECK(corr.dim() == 2 && corr.size(1) == 4 && P1.numel() == 12 && P2.numel() == 12,
+                "sfm_hip: corr [m, 4], P1 / P2 12 doubles");
+    return at::empty({corr.size(0), 3}, corr.options());
+}
+
+}  // namespace
+
+TORCH_LIBRARY(sfm_hip, m) {
+    m.def("normalize_coords(Tensor pix_a, Tensor pix_b, float fx, float fy, float cx, float cy) -> Tensor");
+    m.def("normalize_coords_(Tensor pix_a, Tensor pix_b, float fx, float fy, float cx, float cy, Tensor(a!) out) -> ()");
+    m.def("sample_philox(int seed, int seed_stride, int h_begin, int h_count, int n, int batch, Device device) -> Tensor");
+    m.def("fit_eight_point(Tensor corr, Tensor S) -> (Tensor, Tensor)");
+    m.def("fit_eight_point_(Tensor corr, Tensor S, Tensor(a!) E, Tensor(b!) flags) -> ()");
+    m.def("sample_fit_philox_(Tensor corr, int seed, Tensor? seed_dev, int seed_stride, int h_begin, Tensor(a!) S, "
+          "Tensor(b!) E, Tensor(c!) flags) -> ()");
+    m.def("score_sed(Tensor corr, Tensor E, Tensor S, float thr, bool exact=False) -> (Tensor, Tensor, Tensor)");
+    m.def("score_sed_(Tensor corr, Tensor E, Tensor S, float thr, Tensor(a!) cnt, Tensor(b!) s1, Tensor(c!) s2, "
+          "Tensor(d!)? workspace) -> ()");
+    m.def("select_best(Tensor cnt, Tensor s1, Tensor s2, Tensor? flags, float min_extra, int aggregation, "
+          "int h_offset=0) -> Tensor");
+    m.def("select_best_(Tensor cnt, Tensor s1, Tensor s2, Tensor? flags, float min_extra, int aggregation, "
+          "int h_offset, Tensor(a!) result) -> ()");
+    m.def("inlier_mask(Tensor corr, Tensor E, Tensor S, Tensor result, float thr) -> Tensor");
+    m.def("inlier_mask_(Tensor corr, Tensor E, Tensor S, Tensor result, float thr, Tensor(a!) mask) -> ()");
+    m.def("cheirality(Tensor corr, Tensor pose_rt, float distance_threshold) -> Tensor");
+    m.def("triangulate(Tensor corr, Tensor P1, Tensor P2) -> Tensor");
+}
+
+// ROCm devices dispatch under torch's "CUDA" key (the name of the dispatch key, not a CUDA code path)
+TORCH_LIBRARY_IMPL(sfm_hip, CUDA, m) {
+    m.impl("normalize_coords", &normalize_coords);
+    m.impl("normalize_coords_", &normalize_coords_out);
+    m.impl("fit_eight_point", &fit_eight_point);
+    m.impl("fit_eight_point_", &fit_eight_point_out);
+    m.impl("sample_fit_philox_", &sample_fit_philox_out);
+    m.impl("score_sed", &score_sed);
+    m.impl("score_sed_", &score_sed_out);
+    m.impl("select_best", &select_best);
+    m.impl("select_best_", &select_best_out);
+    m.impl("inlier_mask", &inlier_mask);
+    m.impl("inlier_mask_", &inlier_mask_out);
+    m.impl("cheirality", &cheirality);
+    m.impl("triangulate", &triangulate);
+}
+
+// sample_philox has no tensor argument to dispatch on: registered for every backend, it checks its device itself
+TORCH_LIBRARY_IMPL(sfm_hip, CompositeExplicitAutograd, m) { m.impl("sample_philox", &sample_philox); }
+
+// in-place forms under fake tensors: shapes are fixed by the caller's buffers, nothing to compute
+void normalize_coords_out_meta(const Tensor&, const Tensor&, double, double, double, double, Tensor&) {}
+void fit_eight_point_out_meta(const Tensor&, const Tensor&, Tensor&, Tensor&) {}
+void sample_fit_philox_out_meta(const Tensor&, int64_t, const std::optional<Tensor>&, int64_t, int64_t, Tensor&, Tensor&,
+                                Tensor&) {}
+void score_sed_out_meta(const Tensor&, const Tensor&, const Tensor&, double, Tensor&, Tensor&, Tensor&,
+                        const std::optional<Tensor>&) {}
+void select_best_out_meta(const Tensor&, const Tensor&, const Tensor&, const std::optional<Tensor>&, double, int64_t,
+                          int64_t, Tensor&) {}
+void inlier_mask_out_meta(const Tensor&, const Tensor&, const Tensor&, const Tensor&, double, Tensor&) {}
+
+TORCH_LIBRARY_IMPL(sfm_hip, Meta, m) {
+    m.impl("normalize_coords_", &normalize_coords_out_meta);
+    m.impl("fit_eight_point_", &fit_eight_point_out_meta);
+    m.impl("sample_fit_philox_", &sample_fit_philox_out_meta);
+    m.impl("score_sed_", &score_sed_out_meta);
+    m.impl("select_best_", &select_best_out_meta);
+    m.impl("inlier_mask_", &inlier_mask_out_meta);
+    m.impl("normalize_coords", &normalize_coords_meta);
+    m.impl("fit_eight_point", &fit_eight_point_meta);
+    m.impl("score_sed", &score_sed_meta);
+    m.impl("select_best", &select_best_meta);
+    m.impl("inlier_mask", &inlier_mask_meta);
+    m.impl("cheirality", &cheirality_meta);
+    m.impl("triangulate", &triangulate_meta);
+}

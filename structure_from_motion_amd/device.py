@@ -1,4 +1,6 @@
-"""Device plumbing: torch ROCm tensors for memory and streams, ctypes calls into libsfm_hip.so.
+"""Device plumbing: torch ROCm tensors for memory and streams; the kernels are reached as PyTorch-ROCm custom ops
+(``torch.ops.sfm_hip.*``, csrc/sfm_torch_ops.cpp — the op set of SURVEY.md §8b) and, for the entry points outside
+that set, by ctypes calls into the same C ABI (libsfm_hip.so) underneath.
 
 Nothing here computes on the CPU.  Every wrapper only enqueues work on the current torch HIP stream;
 host synchronisation happens where a caller reads a result back (``.cpu()`` / ``read_select``).
@@ -14,7 +16,7 @@ from typing import List, Optional, Tuple
 import numpy as np
 import torch
 
-from . import _native
+from . import _native, ops
 from ._native import SelectResult, check
 
 F64 = torch.float64
@@ -24,7 +26,7 @@ assert SELECT_BYTES == 40
 
 def require_gpu() -> torch.device:
     """The hot path has no CPU fallback: fail loudly without a ROCm device or the HIP library."""
-    _native.load()
+    ops.load()
     if not torch.cuda.is_available():
         raise RuntimeError(
             "structure_from_motion_amd: no ROCm GPU visible; the RANSAC / triangulation hot path "
@@ -44,6 +46,12 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return t.data_ptr()
 
 
+def _as_int64(seed: int) -> int:
+    """A 64-bit seed as the signed value torch op schemas carry (same bit pattern)."""
+    seed &= 2**64 - 1
+    return seed - 2**64 if seed >= 2**63 else seed
+
+
 def to_device(array, dtype=F64) -> torch.Tensor:
     dev = require_gpu()
     return torch.as_tensor(np.ascontiguousarray(array), dtype=dtype).to(dev)
@@ -54,22 +62,20 @@ def to_device(array, dtype=F64) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------------------
 def normalize_correspondences(pix_a: torch.Tensor, pix_b: torch.Tensor, K, out=None) -> torch.Tensor:
     """pix_a, pix_b: [..., 2] f64 on device -> corr [..., 4]."""
-    lib = _native.load()
-    count = pix_a.numel() // 2
-    assert pix_a.shape == pix_b.shape and pix_a.shape[-1] == 2
-    if out is None:
-        out = torch.empty(pix_a.shape[:-1] + (4,), dtype=F64, device=pix_a.device)
+    op = ops.load()
     fx, fy, cx, cy = float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2])
-    check(lib.sfm_normalize_correspondences(_ptr(pix_a), _ptr(pix_b), count, fx, fy, cx, cy, _ptr(out),
-                                            _stream()), "sfm_normalize_correspondences")
+    if out is None:
+        return op.normalize_coords(pix_a, pix_b, fx, fy, cx, cy)
+    op.normalize_coords_(pix_a, pix_b, fx, fy, cx, cy, out)
     return out
 
 
 def sample_philox(seed: int, h_begin: int, h_count: int, n: int, batch: int = 1, seed_stride: int = 1,
                   out=None, device=None) -> torch.Tensor:
-    lib = _native.load()
     if out is None:
-        out = torch.empty((batch, h_count, 8), dtype=torch.int32, device=device or require_gpu())
+        return ops.load().sample_philox(_as_int64(seed), seed_stride, h_begin, h_count, n, batch,
+                                        device or require_gpu())
+    lib = _native.load()  # filling a caller's buffer: straight through the C ABI
     check(lib.sfm_sample_philox(seed & (2**64 - 1), seed_stride, h_begin, h_count, n, batch, _ptr(out),
                                 _stream()), "sfm_sample_philox")
     return out
@@ -99,10 +105,20 @@ def sample_philox_at(seed: int, h_index: torch.Tensor, n: int, seed_stride: int 
 
 def fit_eight_point(corr: torch.Tensor, S: torch.Tensor, E=None, flags=None, lambda2=None):
     """corr [B,N,4], S [B,H,8] -> E [B,H,9], flags [B,H]."""
-    lib = _native.load()
     B, N, _ = corr.shape
     H = S.shape[1]
     assert S.shape == (B, H, 8) and S.dtype == torch.int32
+    if lambda2 is None:
+        op = ops.load()
+        if E is None and flags is None:
+            return op.fit_eight_point(corr, S)
+        if E is None:
+            E = torch.empty((B, H, 9), dtype=F64, device=corr.device)
+        if flags is None:
+            flags = torch.empty((B, H), dtype=torch.int32, device=corr.device)
+        op.fit_eight_point_(corr, S, E, flags)
+        return E, flags
+    lib = _native.load()  # with the second-smallest eigenvalue written out: a diagnostic outside the op set
     if E is None:
         E = torch.empty((B, H, 9), dtype=F64, device=corr.device)
     if flags is None:
@@ -122,13 +138,9 @@ def sample_fit_philox(corr: torch.Tensor, seed, h_begin: int, S: torch.Tensor, E
                       seed_stride: int = 1) -> None:
     """Philox sampling and the eight-point fit in one launch (fills S, E, flags).  ``seed``: an int, or an int64
     device tensor whose first word is read at kernel run time (graph replay)."""
-    lib = _native.load()
-    B, N, _ = corr.shape
-    H = S.shape[1]
     on_device = isinstance(seed, torch.Tensor)
-    check(lib.sfm_sample_fit_philox(0 if on_device else seed & (2**64 - 1), _ptr(seed) if on_device else None,
-                                    seed_stride, h_begin, _ptr(corr), N, H, B, _ptr(S), _ptr(E), _ptr(flags),
-                                    _stream()), "sfm_sample_fit_philox")
+    ops.load().sample_fit_philox_(corr, 0 if on_device else _as_int64(seed), seed if on_device else None,
+                                  seed_stride, h_begin, S, E, flags)
 
 
 def fit_eight_point_traced(corr: torch.Tensor, S: torch.Tensor):
@@ -182,22 +194,23 @@ def score_sed(corr: torch.Tensor, E: torch.Tensor, S: torch.Tensor, thr: float, 
               s2=None, workspace: Optional[torch.Tensor] = None, exact_only: bool = False):
     """Per-hypothesis (extra-inlier count, sum sed, sum sed^2).  Uses the two-tier kernel (fp32 pre-filter
     + exact fp64) unless ``exact_only``; both give identical counts / decisions."""
-    lib = _native.load()
+    op = ops.load()
     B, N, _ = corr.shape
     H = E.shape[1]
+    exact = exact_only or os.environ.get("SFM_SCORE_KERNEL", "filtered") == "exact"
+    if cnt is None and s1 is None and s2 is None and (exact or workspace is None):
+        return op.score_sed(corr, E, S, float(thr), exact)
     if cnt is None:
         cnt = torch.empty((B, H), dtype=torch.int32, device=corr.device)
     if s1 is None:
         s1 = torch.empty((B, H), dtype=F64, device=corr.device)
     if s2 is None:
         s2 = torch.empty((B, H), dtype=F64, device=corr.device)
-    if exact_only or os.environ.get("SFM_SCORE_KERNEL", "filtered") == "exact":
+    if exact:
         workspace = None
     elif workspace is None:
         workspace = score_workspace(N, H, B, corr.device)
-    check(lib.sfm_score_sed(_ptr(corr), N, _ptr(E), _ptr(S), H, B, float(thr), _ptr(cnt), _ptr(s1),
-                            _ptr(s2), _ptr(workspace), workspace.numel() if workspace is not None else 0,
-                            _stream()), "sfm_score_sed")
+    op.score_sed_(corr, E, S, float(thr), cnt, s1, s2, workspace)
     return cnt, s1, s2
 
 
@@ -213,23 +226,18 @@ def score_timing_events(before: Optional[torch.cuda.Event], after: Optional[torc
 
 def select_best(cnt, s1, s2, flags, min_extra: float, aggregation: int, h_offset: int = 0, out=None):
     """-> int64 tensor [B,5] viewing the sfm_select_result records."""
-    lib = _native.load()
-    B, H = cnt.shape
+    op = ops.load()
     if out is None:
-        out = torch.empty((B, SELECT_BYTES // 8), dtype=torch.int64, device=cnt.device)
-    check(lib.sfm_select_best(_ptr(cnt), _ptr(s1), _ptr(s2), _ptr(flags), H, B, float(min_extra),
-                              int(aggregation), h_offset, _ptr(out), _stream()), "sfm_select_best")
+        return op.select_best(cnt, s1, s2, flags, float(min_extra), int(aggregation), h_offset)
+    op.select_best_(cnt, s1, s2, flags, float(min_extra), int(aggregation), h_offset, out)
     return out
 
 
 def inlier_mask(corr, E, S, result, thr: float, out=None):
-    lib = _native.load()
-    B, N, _ = corr.shape
-    H = E.shape[1]
+    op = ops.load()
     if out is None:
-        out = torch.empty((B, N), dtype=torch.uint8, device=corr.device)
-    check(lib.sfm_inlier_mask(_ptr(corr), N, _ptr(E), _ptr(S), H, B, _ptr(result), float(thr), _ptr(out),
-                              _stream()), "sfm_inlier_mask")
+        return op.inlier_mask(corr, E, S, result, float(thr))
+    op.inlier_mask_(corr, E, S, result, float(thr), out)
     return out
 
 
@@ -271,21 +279,11 @@ def sed_values(corr: torch.Tensor, E: torch.Tensor) -> torch.Tensor:
 
 
 def cheirality(corr: torch.Tensor, pose_rt: torch.Tensor, distance_threshold: float) -> torch.Tensor:
-    lib = _native.load()
-    m = corr.shape[0]
-    poses = pose_rt.shape[0]
-    out = torch.empty((poses, m), dtype=torch.uint8, device=corr.device)
-    check(lib.sfm_cheirality(_ptr(corr), m, _ptr(pose_rt), poses, float(distance_threshold), _ptr(out),
-                             _stream()), "sfm_cheirality")
-    return out
+    return ops.load().cheirality(corr, pose_rt, float(distance_threshold))
 
 
 def triangulate(corr: torch.Tensor, P1: torch.Tensor, P2: torch.Tensor) -> torch.Tensor:
-    lib = _native.load()
-    m = corr.shape[0]
-    out = torch.empty((m, 3), dtype=F64, device=corr.device)
-    check(lib.sfm_triangulate(_ptr(corr), m, _ptr(P1), _ptr(P2), _ptr(out), _stream()), "sfm_triangulate")
-    return out
+    return ops.load().triangulate(corr, P1, P2)
 
 
 def decompose_essential(E: torch.Tensor, out=None):

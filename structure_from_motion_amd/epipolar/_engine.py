@@ -4,6 +4,8 @@ from __future__ import annotations
 import copy
 import os
 import random
+import warnings
+from operator import attrgetter
 from typing import Sequence
 
 import numpy as np
@@ -13,17 +15,74 @@ from .. import device
 from ..common.feature import Feature
 
 
-def feature_array(features: Sequence[Feature]) -> np.ndarray:
-    """(len, 2) float64 array of x, y; accepts lists and NumPy object arrays of Feature."""
-    out = np.empty((len(features), 2), dtype=np.float64)
-    for i, f in enumerate(features):
-        out[i, 0] = f.x
-        out[i, 1] = f.y
+_GET_X, _GET_Y = attrgetter("x"), attrgetter("y")
+
+# Above this many matches x iterations the default sampler switches from the exact random.shuffle replay to the
+# counter-based device sampler: the replay is inherently sequential (one Mersenne-Twister draw per element per
+# iteration, like the reference's own loop), ~3 ns per draw on the host against microseconds for the whole pass on
+# the GPU.  Every golden vector and the demo (600 matches x 2000 iterations = 1.2e6) stay far below it.
+AUTO_PHILOX_WORK = 10_000_000
+
+
+def feature_array(features: Sequence[Feature], out: np.ndarray | None = None) -> np.ndarray:
+    """(len, 2) float64 array of x, y; accepts lists, tuples and NumPy object arrays of Feature (or of anything
+    with ``x`` / ``y`` attributes).  One C-level pass per coordinate (``map`` + ``np.fromiter``)."""
+    n = len(features)
+    if out is None:
+        out = np.empty((n, 2), dtype=np.float64)
+    out[:, 0] = np.fromiter(map(_GET_X, features), dtype=np.float64, count=n)
+    out[:, 1] = np.fromiter(map(_GET_Y, features), dtype=np.float64, count=n)
     return out
 
 
-def sampler_name() -> str:
-    name = os.environ.get("SFM_SAMPLER", "pyshuffle").lower()
+def pair_arrays(data) -> np.ndarray:
+    """(2, len, 2) float64: [0] = pixel coordinates of the first features of the pairs, [1] = of the second."""
+    n = len(data)
+    out = np.empty((2, n, 2), dtype=np.float64)
+    if n:
+        first, second = zip(*data)
+        feature_array(first, out[0])
+        feature_array(second, out[1])
+    return out
+
+
+def copy_pairs(data, order) -> list:
+    """Fresh copies of ``data[i]`` for i in ``order`` — the reference hands back deep copies of the caller's
+    features (ransac.py:59 copies the data before shuffling).  Plain ``Feature`` pairs are rebuilt by their
+    constructor (same result as ``copy.deepcopy`` for a two-float dataclass, ~7x cheaper); anything else is
+    deep-copied."""
+    out = []
+    for i in order:
+        pair = data[i]
+        a, b = pair
+        if type(a) is Feature and type(b) is Feature and type(pair) is tuple:
+            out.append((Feature(a.x, a.y), Feature(b.x, b.y)))
+        else:
+            out.append(copy.deepcopy(pair))
+    return out
+
+
+_warned_auto_philox = False
+
+
+def sampler_name(n: int = 0, iterations: int = 0) -> str:
+    """``SFM_SAMPLER=pyshuffle|philox`` if set.  Otherwise ``pyshuffle`` — the exact replay of the reference's
+    cumulative ``random.shuffle``, so ``random.seed(k)`` reproduces the reference's samples — up to
+    ``AUTO_PHILOX_WORK`` matches x iterations, and ``philox`` (seeded from ``random.getrandbits(64)``, so the call is
+    still a deterministic function of ``random.seed``) beyond, with one warning per process."""
+    global _warned_auto_philox
+    name = os.environ.get("SFM_SAMPLER")
+    if name is None:
+        if n * iterations <= AUTO_PHILOX_WORK:
+            return "pyshuffle"
+        if not _warned_auto_philox:
+            _warned_auto_philox = True
+            warnings.warn(
+                f"structure_from_motion_amd: {n} matches x {iterations} iterations exceeds {AUTO_PHILOX_WORK}: sampling "
+                "hypotheses with the counter-based device sampler instead of replaying random.shuffle (set "
+                "SFM_SAMPLER=pyshuffle to force the exact replay, SFM_SAMPLER=philox to silence this)", stacklevel=3)
+        return "philox"
+    name = name.lower()
     if name not in ("pyshuffle", "philox"):
         raise ValueError(f"SFM_SAMPLER must be 'pyshuffle' or 'philox', got {name!r}")
     return name
@@ -62,11 +121,10 @@ def ransac_feature_pairs(data, camera_matrix, threshold, min_extra, aggregation,
         # reference: data[:8] is short, eight_point_model_fitter raises (epipolar_ransac.py:31-32)
         raise ValueError("Eight feature pairs are expected.")
     dev = device.require_gpu()
-    pix_a = feature_array([pair[0] for pair in data])
-    pix_b = feature_array([pair[1] for pair in data])
-    corr = device.normalize_correspondences(device.to_device(pix_a), device.to_device(pix_b), camera_matrix)
+    pix = device.to_device(pair_arrays(data))   # one upload: [2, n, 2]
+    corr = device.normalize_correspondences(pix[0], pix[1], camera_matrix)
     ws = device.RansacWorkspace(1, n, iterations, dev)
-    sampler = sampler_name()
+    sampler = sampler_name(n, iterations)
     table = None
     if sampler == "pyshuffle":
         table = device.PyShuffleTable(n, iterations, random, advance=True)
@@ -92,11 +150,12 @@ def ransac_feature_pairs(data, camera_matrix, threshold, min_extra, aggregation,
                                                       threshold, aggregation, rounds)
         if device.read_refine_info(info)[0][2] > 0:
             keep = np.nonzero(mask_ref.cpu().numpy()[0])[0]
-            return E_ref.cpu().numpy().reshape(3, 3), [copy.deepcopy(data[int(i)]) for i in keep]
+            return E_ref.cpu().numpy().reshape(3, 3), copy_pairs(data, keep.tolist())
     survivors = outcome.mask == 1
     if sampler == "pyshuffle":
         perm = table.permutation_after(outcome.best_h)
-        order = [int(i) for i in perm[:8]] + [int(i) for i in perm[8:] if survivors[i]]
+        rest = perm[8:]
+        order = np.concatenate([perm[:8], rest[survivors[rest]]])
     else:
-        order = [int(i) for i in outcome.sample] + [int(i) for i in np.nonzero(survivors)[0]]
-    return outcome.E, [copy.deepcopy(data[i]) for i in order]
+        order = np.concatenate([outcome.sample, np.nonzero(survivors)[0]])
+    return outcome.E, copy_pairs(data, order.tolist())

@@ -29,5 +29,5 @@ def native_lib():
     """Built C-ABI library (compiled on demand; hipcc cross-compiles without a GPU)."""
     from structure_from_motion_amd import _native, build
 
-    build.build()
+    build.build_all()
     return _native.load()

@@ -1,0 +1,195 @@
+"""The hot-path kernels as PyTorch-ROCm custom ops (``torch.ops.sfm_hip.*``, csrc/sfm_torch_ops.cpp).
+
+CPU part: the op library loads, registers exactly the op set of SURVEY.md §8b (+ the in-place forms), and its Meta
+kernels give the right shapes / dtypes (fake-tensor tracing needs nothing else).  GPU part: each op against the
+oracle on seeded inputs, and ``torch.library.opcheck`` (schema, fake tensor, dispatch registrations)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sfm_oracle as orc
+
+
+@pytest.fixture(scope="module")
+def op(native_lib):
+    from structure_from_motion_amd import ops
+
+    return ops.load()
+
+
+def test_op_set_is_registered(op):
+    from structure_from_motion_amd import ops
+
+    for name in ops.FUNCTIONAL_OPS + ops.INPLACE_OPS:
+        overload = getattr(op, name).default
+        assert overload._schema.name == f"sfm_hip::{name}"
+    # in-place forms declare what they write
+    assert "Tensor(a!) cnt" in str(op.score_sed_.default._schema)
+    assert "Tensor(a!) result" in str(op.select_best_.default._schema)
+
+
+def test_meta_kernels_shapes_and_dtypes(op):
+    B, n, h = 3, 120, 17
+    f64 = dict(dtype=torch.float64, device="meta")
+    pix = torch.empty((B, n, 2), **f64)
+    corr = op.normalize_coords(pix, pix, 1500.0, 1500.0, 300.0, 240.0)
+    assert corr.shape == (B, n, 4) and corr.dtype == torch.float64
+    S = torch.empty((B, h, 8), dtype=torch.int32, device="meta")
+    E, flags = op.fit_eight_point(corr, S)
+    assert E.shape == (B, h, 9) and flags.shape == (B, h) and flags.dtype == torch.int32
+    cnt, s1, s2 = op.score_sed(corr, E, S, 1.5e-6)
+    assert cnt.shape == (B, h) and cnt.dtype == torch.int32 and s1.dtype == s2.dtype == torch.float64
+    result = op.select_best(cnt, s1, s2, flags, 10.0, 3)
+    assert result.shape == (B, 5) and result.dtype == torch.int64
+    mask = op.inlier_mask(corr, E, S, result, 1.5e-6)
+    assert mask.shape == (B, n) and mask.dtype == torch.uint8
+    pts = torch.empty((n, 4), **f64)
+    assert op.cheirality(pts, torch.empty((4, 12), **f64), 50.0).shape == (4, n)
+    assert op.triangulate(pts, torch.empty((12,), **f64), torch.empty((3, 4), **f64)).shape == (n, 3)
+    with pytest.raises(RuntimeError, match=r"S must be \[batch, h, 8\]"):
+        op.fit_eight_point(corr, torch.empty((B, h, 7), dtype=torch.int32, device="meta"))
+
+
+def test_ops_trace_under_fake_tensor_mode(op):
+    from torch._subclasses.fake_tensor import FakeTensorMode
+
+    with FakeTensorMode():
+        corr = torch.empty((1, 64, 4), dtype=torch.float64, device="cuda")
+        S = torch.empty((1, 9, 8), dtype=torch.int32, device="cuda")
+        E, flags = op.fit_eight_point(corr, S)
+        cnt, s1, s2 = op.score_sed(corr, E, S, 1e-6)
+        result = op.select_best(cnt, s1, s2, flags, 0.0, 0)
+        assert E.device.type == "cuda" and cnt.shape == (1, 9) and result.shape == (1, 5)
+        buf = torch.empty((1, 9), dtype=torch.int32, device="cuda")
+        op.score_sed_(corr, E, S, 1e-6, buf, s1, s2, None)   # in-place form: nothing to infer, must not raise
+
+
+def test_device_tensors_are_required(op):
+    corr = torch.zeros((1, 16, 4), dtype=torch.float64)
+    S = torch.zeros((1, 2, 8), dtype=torch.int32)
+    with pytest.raises((RuntimeError, NotImplementedError)):
+        op.fit_eight_point(corr, S)   # no CPU kernel is registered: the hot path has no CPU fallback
+
+
+# ------------------------------------------------------------------------------------------------------
+# GPU: parity through the op layer
+# ------------------------------------------------------------------------------------------------------
+def _scene(n, seed=6):
+    pa, pb, K, R, t, _ = orc.synthetic_two_view(n, seed=seed, outlier_fraction=0.3)
+    corr = orc.pack_correspondences(orc.to_normalized_image_coords(pa, K), orc.to_normalized_image_coords(pb, K))
+    return pa, pb, K, corr
+
+
+@pytest.mark.gpu
+def test_ops_match_oracle(op):
+    dev = torch.device("cuda", 0)
+    n, h, thr, min_extra = 3000, 500, 1.5e-6, 10
+    pa, pb, K, corr = _scene(n)
+    to = lambda a, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).to(dev)  # noqa: E731
+    corr_d = op.normalize_coords(to(pa), to(pb), float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]))
+    np.testing.assert_array_equal(corr_d.cpu().numpy(), corr)                       # bit-exact
+    S_d = op.sample_philox(5, 1, 0, h, n, 1, dev)
+    S = orc.philox_sample_table(5, 0, h, n)
+    np.testing.assert_array_equal(S_d.cpu().numpy()[0], S)                          # bit-exact
+    corr_b = corr_d.reshape(1, n, 4)
+    E_d, flags_d = op.fit_eight_point(corr_b, S_d)
+    E_o, deg_o, _ = orc.fit_hypotheses(corr, S)
+    rel = np.max(np.abs(E_d.cpu().numpy()[0].reshape(h, 3, 3) - E_o), axis=(1, 2)) / np.max(np.abs(E_o), axis=(1, 2))
+    assert rel.max() <= 1e-6 and np.median(rel) <= 1e-11                            # tolerance of north_star: 1e-6
+    assert not flags_d.any() and not deg_o.any()
+    E_same = to(E_o.reshape(1, h, 9))   # score the oracle's own E so that counts must agree exactly
+    for exact in (False, True):
+        cnt, s1, s2 = op.score_sed(corr_b, E_same, S_d, thr, exact)
+        cnt_o, s1_o, s2_o = orc.score_hypotheses(corr, E_o, S, thr)
+        np.testing.assert_array_equal(cnt.cpu().numpy()[0], cnt_o)                  # bit-exact counts
+        np.testing.assert_allclose(s1.cpu().numpy()[0], s1_o, rtol=1e-12)           # summation order only
+        np.testing.assert_allclose(s2.cpu().numpy()[0], s2_o, rtol=1e-12)
+    for agg, method in ((0, orc.SUM), (1, orc.SQUARE), (2, orc.MEAN), (3, orc.RMS)):
+        result = op.select_best(cnt, s1, s2, flags_d, float(min_extra), agg, 0)
+        best, err = orc.select_best(orc.aggregate(cnt_o, s1.cpu().numpy()[0], s2.cpu().numpy()[0], method), cnt_o,
+                                    min_extra)
+        assert int(result[0, 1].cpu()) == best
+        assert float(result.view(torch.float64)[0, 2].cpu()) == err
+    mask = op.inlier_mask(corr_b, E_same, S_d, result, thr).cpu().numpy()[0]
+    np.testing.assert_array_equal(np.nonzero(mask)[0], np.sort(orc.inlier_indices(corr, E_o[best], S[best], thr)))
+    # pose ops on the winner's inliers
+    idx = np.sort(orc.inlier_indices(corr, E_o[best], S[best], thr))
+    R, t, pmask, votes = orc.recover_r_t(corr[idx], E_o[best])
+    pose = np.concatenate([R.reshape(9), t])[None, :]
+    passes = op.cheirality(to(corr[idx]), to(pose), 50.0).cpu().numpy()[0]
+    np.testing.assert_array_equal(np.nonzero(passes)[0], pmask)
+    T = np.eye(4)
+    T[:3, :3], T[:3, 3] = R, t
+    K34 = np.hstack([K, np.zeros((3, 1))])
+    X = op.triangulate(to(orc.pack_correspondences(pa[idx], pb[idx])), to((K34 @ np.eye(4)).reshape(12)),
+                       to((K34 @ T).reshape(12))).cpu().numpy()
+    X_o = orc.triangulate_points(pa[idx], pb[idx], K, T)
+    assert np.max(np.abs(X - X_o) / np.linalg.norm(X_o, axis=1, keepdims=True)) <= 1e-6
+
+
+@pytest.mark.gpu
+def test_inplace_ops_equal_functional_ops(op):
+    dev = torch.device("cuda", 0)
+    n, h = 2000, 300
+    _, _, _, corr = _scene(n, seed=8)
+    corr_b = torch.as_tensor(corr).to(dev).reshape(1, n, 4)
+    S = torch.empty((1, h, 8), dtype=torch.int32, device=dev)
+    E = torch.empty((1, h, 9), dtype=torch.float64, device=dev)
+    flags = torch.empty((1, h), dtype=torch.int32, device=dev)
+    op.sample_fit_philox_(corr_b, 11, None, 1, 7, S, E, flags)
+    S2 = op.sample_philox(11, 1, 7, h, n, 1, dev)
+    E2, flags2 = op.fit_eight_point(corr_b, S2)
+    assert torch.equal(S, S2) and torch.equal(E, E2) and torch.equal(flags, flags2)
+    seed_dev = torch.tensor([11], dtype=torch.int64, device=dev)
+    E3 = torch.empty_like(E)
+    op.sample_fit_philox_(corr_b, 0, seed_dev, 1, 7, S, E3, flags)
+    assert torch.equal(E3, E)
+    cnt, s1, s2 = op.score_sed(corr_b, E, S, 1.5e-6)
+    from structure_from_motion_amd import device
+
+    ws = device.score_workspace(n, h, 1, dev)
+    c2, a2, b2 = torch.empty_like(cnt), torch.empty_like(s1), torch.empty_like(s2)
+    op.score_sed_(corr_b, E, S, 1.5e-6, c2, a2, b2, ws)
+    assert torch.equal(cnt, c2) and torch.equal(s1, a2) and torch.equal(s2, b2)
+    result = op.select_best(cnt, s1, s2, flags, 10.0, 3)
+    r2 = torch.empty_like(result)
+    op.select_best_(cnt, s1, s2, flags, 10.0, 3, 0, r2)
+    assert torch.equal(result, r2)
+    mask = op.inlier_mask(corr_b, E, S, result, 1.5e-6)
+    m2 = torch.empty_like(mask)
+    op.inlier_mask_(corr_b, E, S, result, 1.5e-6, m2)
+    assert torch.equal(mask, m2)
+
+
+@pytest.mark.gpu
+def test_opcheck(op):
+    dev = torch.device("cuda", 0)
+    n, h = 600, 40
+    pa, pb, K, corr = _scene(n, seed=9)
+    pix_a, pix_b = torch.as_tensor(pa).to(dev), torch.as_tensor(pb).to(dev)
+    corr_b = torch.as_tensor(corr).to(dev).reshape(1, n, 4)
+    S = op.sample_philox(5, 1, 0, h, n, 1, dev)
+    E, flags = op.fit_eight_point(corr_b, S)
+    cnt, s1, s2 = op.score_sed(corr_b, E, S, 1.5e-6)
+    result = op.select_best(cnt, s1, s2, flags, 10.0, 3)
+    pose = torch.eye(3, 4, dtype=torch.float64, device=dev).t().contiguous().reshape(1, 12)
+    P = torch.eye(3, 4, dtype=torch.float64, device=dev).reshape(12)
+    checks = [
+        (op.normalize_coords.default, (pix_a, pix_b, 1500.0, 1510.0, 300.0, 240.0)),
+        (op.fit_eight_point.default, (corr_b, S)),
+        (op.score_sed.default, (corr_b, E, S, 1.5e-6, False)),
+        (op.score_sed.default, (corr_b, E, S, 1.5e-6, True)),
+        (op.select_best.default, (cnt, s1, s2, flags, 10.0, 3, 0)),
+        (op.select_best.default, (cnt, s1, s2, None, 10.0, 0, 5)),
+        (op.inlier_mask.default, (corr_b, E, S, result, 1.5e-6)),
+        (op.cheirality.default, (corr_b[0], pose, 50.0)),
+        (op.triangulate.default, (corr_b[0], P, P)),
+    ]
+    for overload, args in checks:
+        torch.library.opcheck(overload, args)
+    # in-place forms: schema (declared mutations are the only ones) and fake-tensor behaviour
+    c2, a2, b2 = torch.empty_like(cnt), torch.empty_like(s1), torch.empty_like(s2)
+    torch.library.opcheck(op.score_sed_.default, (corr_b, E, S, 1.5e-6, c2, a2, b2, None),
+                          test_utils=("test_schema", "test_faketensor"))
+    torch.library.opcheck(op.select_best_.default, (cnt, s1, s2, flags, 10.0, 3, 0, torch.empty_like(result)),
+                          test_utils=("test_schema", "test_faketensor"))
