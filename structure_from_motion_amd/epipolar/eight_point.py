@@ -255,13 +255,25 @@ def _cheirality_check(
     distance_threshold: float | None = None,
     z_axis_index: int = 2,
 ) -> bool:
-    """Whether the pose places the triangulated point in front of both cameras (normalised coords)."""
-    if z_axis_index != 2:
-        raise NotImplementedError("only the z axis is supported as the viewing direction")
+    """Whether the pose places the triangulated point in front of both cameras (normalised coords).
+    ``z_axis_index`` names the coordinate that points out of the cameras (reference eight_point.py:455,481)."""
+    if z_axis_index not in (0, 1, 2):
+        raise IndexError(f"index {z_axis_index} is out of bounds for axis 0 with size 3")
     if distance_threshold is None:
         distance_threshold = DEFAULT_DISTANCE_THRESHOLD
     device.require_gpu()
     corr = device.to_device(np.array([[feature_a.x, feature_a.y, feature_b.x, feature_b.y]]))
-    pose = np.concatenate([np.asarray(cam2_R_cam1, dtype=np.float64).reshape(9),
-                           np.asarray(cam2_t_cam2_cam1, dtype=np.float64).reshape(3)])
-    return bool(device.cheirality(corr, device.to_device(pose.reshape(1, 12)), distance_threshold).cpu()[0, 0])
+    R = np.asarray(cam2_R_cam1, dtype=np.float64).reshape(3, 3)
+    t = np.asarray(cam2_t_cam2_cam1, dtype=np.float64).reshape(3)
+    if z_axis_index == 2:  # the viewing direction the pose kernels are written for
+        pose = np.concatenate([R.reshape(9), t])
+        return bool(device.cheirality(corr, device.to_device(pose.reshape(1, 12)), distance_threshold).cpu()[0, 0])
+    # another outward axis (a diagnostic option of this one-pair helper; the batched pose path is z-only): the point
+    # comes from the triangulation kernel, the three comparisons of eight_point.py:478-486 are applied to it here
+    P1 = np.hstack([np.eye(3), np.zeros((3, 1))])
+    P2 = np.hstack([R, t.reshape(3, 1)])
+    in_cam1 = device.triangulate(corr, device.to_device(P1.reshape(12)), device.to_device(P2.reshape(12))).cpu().numpy()[0]
+    in_cam2 = R @ in_cam1 + t
+    tolerance = 1e-8
+    return bool(in_cam1[z_axis_index] >= -tolerance and in_cam2[z_axis_index] >= -tolerance
+                and np.linalg.norm(in_cam1) <= distance_threshold)

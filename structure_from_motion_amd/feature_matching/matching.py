@@ -145,9 +145,12 @@ def match_brute_force(
 
     rows = list(range(len(features_a)))
     if len(features_b) == 0:
-        if not strategies:
-            raise IndexError("list index out of range")  # the reference indexes an empty heap here
-        return []
+        # every heap of the reference is empty here (matching.py:55-65).  Its ratio filter drops empty heaps
+        # (:84-97) and an empty feature list has no heap to index; otherwise it indexes heap[0] of an empty heap —
+        # in the cross-check (:105) or in the final list comprehension (:79)
+        if len(features_a) == 0 or ValidationStrategy.RATIO_TEST in strategies:
+            return []
+        raise IndexError("list index out of range")
     if ValidationStrategy.RATIO_TEST in strategies and has_second:
         with np.errstate(divide="ignore", invalid="ignore"):
             passed = (np.asarray(best, dtype=np.float64) / np.asarray(second, dtype=np.float64)) <= ratio_test_threshold

@@ -63,6 +63,15 @@ def test_empty_inputs():
     assert matching.match_brute_force(fa, [], lambda a, b: 0.0,
                                       validation_strategies=matching.ValidationStrategy.RATIO_TEST) == []
     assert matching.match_brute_force([], [Feature(0, 0)], lambda a, b: 0.0) == []
+    # the reference's order of operations with every heap empty (matching.py:55-81): no features at all -> [];
+    # the ratio filter drops empty heaps before anything is indexed; the cross-check alone indexes heap[0]
+    cross = matching.ValidationStrategy.CROSSCHECK
+    ratio = matching.ValidationStrategy.RATIO_TEST
+    assert matching.match_brute_force([], [], lambda a, b: 0.0) == []
+    assert matching.match_brute_force([], [], lambda a, b: 0.0, validation_strategies=cross) == []
+    with pytest.raises(IndexError):
+        matching.match_brute_force(fa, [], lambda a, b: 0.0, validation_strategies=cross)
+    assert matching.match_brute_force(fa, [], lambda a, b: 0.0, validation_strategies={ratio, cross}) == []
 
 
 def test_score_function_recognition():
