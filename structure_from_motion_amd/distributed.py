@@ -181,8 +181,14 @@ class ShardedRansac:
             self._local_pass(None)  # warm-up outside capture (lazy module loads)
         torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
+        allocations = torch.cuda.memory_stats(self.corr.device).get("allocation.all.allocated", 0)
         with torch.cuda.graph(graph):
             self._local_pass(None)
+        grown = torch.cuda.memory_stats(self.corr.device).get("allocation.all.allocated", 0) - allocations
+        if grown:
+            # a tensor allocated during capture lives in the graph's private pool and is recycled by later
+            # replays: every buffer of the pass must exist before capture (graph replay)
+            raise RuntimeError(f"ShardedRansac.capture: {grown} device allocation(s) happened inside graph capture")
         self.graph = graph
 
     def step(self, seed: int) -> None:

