@@ -124,6 +124,24 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
                   int64_t batch, double thr, int32_t* cnt, double* s1, double* s2, void* workspace,
                   int64_t workspace_bytes, void* stream);
 
+/* One whole RANSAC pass of a SMALL problem (one image pair, 8 <= n <= 8192, h_count <= 32768) in TWO launches instead of
+ * the five of sfm_sample_fit_philox / sfm_fit_eight_point -> sfm_score_sed -> sfm_select_best -> sfm_inlier_mask, with
+ * the same outputs (S, E, flags, cnt, s1, s2, result, mask; s1 / s2 in a different, fixed summation order):
+ *   launch 1  the eight-point fits — use_philox != 0: samples drawn in the kernel from (seed or *seed_dev, h_begin + h)
+ *             and stored in S; use_philox == 0: the caller's table in S — and, in spare blocks of the same launch, the
+ *             preparation of the scoring workspace;
+ *   launch 2  SED scoring with the four waves of a block sharing the block's hypotheses and a quarter of the points
+ *             each; the block that finishes last (agent-scope arrival ticket) runs the selection of ransac.py:75-86 and
+ *             writes the winner's inlier mask (mask may be NULL).
+ * A small pass is a chain of dependent launches of a few microseconds each, so fewer launches is what shortens it.
+ * h_offset as in sfm_select_best; mask refers to local indices, i.e. needs h_offset == 0 to be meaningful.
+ * workspace: sfm_score_workspace_bytes(n, h_count, 1) bytes, 16-byte aligned. */
+int sfm_ransac_pass_small(uint64_t seed, const uint64_t* seed_dev, int use_philox, int64_t h_begin, const double* corr,
+                          int64_t n, int64_t h_count, double thr, double min_extra, int aggregation, int64_t h_offset,
+                          int32_t* S, double* E, int32_t* flags, int32_t* cnt, double* s1, double* s2,
+                          sfm_select_result* result, uint8_t* mask, void* workspace, int64_t workspace_bytes,
+                          void* stream);
+
 /* Measurement hook: the next sfm_score_sed calls of the calling thread record the hipEvent_t `before` / `after`
  * (passed as void*, either may be NULL) on the launch stream immediately around the scoring kernel itself — not the
  * workspace preparation or the ordering pre-pass — so that a benchmark can time exactly the kernel a profiler

@@ -51,6 +51,29 @@ inline unsigned grid_stride(int64_t work, int64_t block, int64_t cap) {
     return (unsigned)g;
 }
 
+// Second launch of a fused small pass (defined in sfm_score.hip, called by sfm_ransac_pass_small in sfm_kernels.hip):
+// SED scoring of all hypotheses with selection and inlier mask done by the block that finishes last.
+struct SmallPass {
+    const double* corr;
+    int64_t n;
+    const double* E;
+    const int32_t* S;
+    const int32_t* flags;
+    int64_t h_count;
+    double thr, min_extra;
+    int aggregation;
+    int64_t h_offset;
+    int32_t* cnt;
+    double* s1;
+    double* s2;
+    sfm_select_result* result;
+    uint8_t* mask;  // may be NULL
+    unsigned char* workspace;
+    hipStream_t stream;
+};
+double small_pass_a_scale(double thr);   // factor the prepared a-side coordinates carry for this threshold
+int launch_small_score(const SmallPass& pass);
+
 }  // namespace sfmhost
 
 #define SFM_REQUIRE_GRID(fn, work, per_block, ...)                                                     \

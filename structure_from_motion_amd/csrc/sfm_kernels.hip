@@ -18,6 +18,8 @@
 #include "sfm_common.h"
 #include "sfm_math.h"
 #include "sfm_fit.h"
+#include "sfm_score_ws.h"
+#include "sfm_select.h"
 
 namespace sfmhost {
 char* error_buffer() {
@@ -33,6 +35,8 @@ using sfmhost::fail;
 using sfmhost::grid_for;
 using sfmhost::grid_stride;
 using namespace sfmfit;
+using sfmsel::hypothesis_key;
+using sfmsel::kNoModelKey;
 
 static_assert(sizeof(sfm_select_result) == 40, "sfm_select_result layout is part of the ABI");
 
@@ -117,12 +121,25 @@ struct PhiloxSource {
     int enabled;
 };
 
+// Fused small pass (sfm_ransac_pass_small): `blocks` extra blocks behind the fit blocks of the launch prepare the
+// scoring workspace of the launch that follows (fp32 points, partial maxima, arrival ticket) — the preparation depends
+// on the correspondences only, so it rides along instead of costing a launch of its own.  blocks == 0: plain fit.
+struct SmallPrep {
+    unsigned char* ws;
+    double a_scale;
+    int blocks;
+};
+
 template <bool TRACE>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) void fit_eight_point_kernel(
     const Corr* __restrict__ corr, int64_t n, int32_t* __restrict__ S, int64_t h_count,
     double* __restrict__ E, int32_t* __restrict__ flags, double* __restrict__ lambda2,
-    double* __restrict__ trace, PhiloxSource philox) {
+    double* __restrict__ trace, PhiloxSource philox, SmallPrep prep) {
     const int64_t b = blockIdx.y;
+    if (prep.blocks > 0 && blockIdx.x >= gridDim.x - prep.blocks) {  // block-uniform; batch == 1 in this mode
+        sfmws::prepare_small_block(corr, (int)n, prep.a_scale, prep.ws, (int)(blockIdx.x - (gridDim.x - prep.blocks)));
+        return;
+    }
     const int64_t h_raw = (int64_t)blockIdx.x * kWave + threadIdx.x;
     const bool active = h_raw < h_count;
     // inactive tail lanes redo the last hypothesis so the wave-uniform Jacobi loops stay convergent
@@ -296,10 +313,6 @@ __global__ void hartley_normalize_kernel(const double* __restrict__ coords, int6
 // ------------------------------------------------------------------------------------------------
 // Selection: one 1024-thread block per batch entry; lexicographic min over (error bits, index).
 // ------------------------------------------------------------------------------------------------
-// "no model" key: above every finite non-negative double's bit pattern, and still positive when the
-// record is viewed as int64 (so a cross-GPU MIN all-reduce on int64 works).
-constexpr uint64_t kNoModelKey = 0x7FFFFFFFFFFFFFFFull;
-
 // Three passes over the result record with 64-bit atomics, so that many blocks can share the scan:
 //   pass 1  key = min over gated hypotheses of the error bits; flag statistics
 //   pass 2  best_h = min index among hypotheses whose key equals the minimum (earliest wins)
@@ -313,19 +326,6 @@ __global__ void select_init_kernel(sfm_select_result* __restrict__ result) {
     r.n_flagged = 0;
     r.best_cnt = 0;
     result[blockIdx.x] = r;
-}
-
-SFM_DEVICE uint64_t hypothesis_key(const int32_t* cnt, const double* s1, const double* s2, const int32_t* flags,
-                                   int64_t h, double min_extra, int aggregation, bool& flagged) {
-    const int ch = cnt[h];
-    const double err = aggregate_error(aggregation, ch, s1[h], s2[h]);
-    // Hypotheses whose sample was flagged degenerate never compete (the reference aborts on them).
-    flagged = flags != nullptr && flags[h] != 0;
-    // ransac.py:75 gate and :83 strict compare against an initial +inf: NaN and inf never win.
-    const bool ok = ((double)ch >= min_extra) && (err < INFINITY) && !flagged;
-    uint64_t bits = (uint64_t)__double_as_longlong(err);
-    if (bits == 0x8000000000000000ull) bits = 0;  // -0.0 orders as +0.0
-    return ok ? bits : kNoModelKey;
 }
 
 __global__ __launch_bounds__(256) void select_pass1_kernel(
@@ -411,67 +411,12 @@ __global__ __launch_bounds__(kSelectBlock) void select_block_kernel(
     const int32_t* __restrict__ cnt, const double* __restrict__ s1, const double* __restrict__ s2,
     const int32_t* __restrict__ flags, int64_t h_count, int64_t h_offset, double min_extra, int aggregation,
     sfm_select_result* __restrict__ result) {
-    __shared__ uint64_t sh_key[kSelectBlock / kWave];
-    __shared__ int64_t sh_best[kSelectBlock / kWave], sh_first[kSelectBlock / kWave];
-    __shared__ int sh_flags[kSelectBlock / kWave];
+    __shared__ sfmsel::SelectScratch<kSelectBlock> scratch;
+    __shared__ int64_t winner;
     const int64_t b = blockIdx.x;
-    cnt += b * h_count; s1 += b * h_count; s2 += b * h_count;
-    if (flags != nullptr) flags += b * h_count;
-    uint64_t key = kNoModelKey;
-    int64_t best = INT64_MAX, first_flag = INT64_MAX;
-    int n_flag = 0;
-    // four hypotheses per trip with their loads issued together (the loop is pure load latency otherwise)
-    for (int64_t h0 = threadIdx.x; h0 < h_count; h0 += 4 * kSelectBlock) {  // increasing h: strict < keeps the earliest
-        uint64_t k[4];
-        bool flagged[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t h = h0 + u * kSelectBlock;
-            flagged[u] = false;
-            k[u] = h < h_count ? hypothesis_key(cnt, s1, s2, flags, h, min_extra, aggregation, flagged[u]) : kNoModelKey;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t h = h0 + u * kSelectBlock;
-            if (k[u] < key) {
-                key = k[u];
-                best = h;
-            }
-            if (flagged[u]) {
-                first_flag = h < first_flag ? h : first_flag;
-                ++n_flag;
-            }
-        }
-    }
-    auto combine = [&](uint64_t ok, int64_t ob, int64_t of, int on) {
-        if (ok < key || (ok == key && ob < best)) {
-            key = ok;
-            best = ob;
-        }
-        first_flag = of < first_flag ? of : first_flag;
-        n_flag += on;
-    };
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-        combine(__shfl_xor(key, off, 64), __shfl_xor(best, off, 64), __shfl_xor(first_flag, off, 64),
-                __shfl_xor(n_flag, off, 64));
-    const int wave = threadIdx.x / kWave;
-    if ((threadIdx.x & (kWave - 1)) == 0) {
-        sh_key[wave] = key; sh_best[wave] = best; sh_first[wave] = first_flag; sh_flags[wave] = n_flag;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < kSelectBlock / kWave; ++w) combine(sh_key[w], sh_best[w], sh_first[w], sh_flags[w]);
-        const bool found = key != kNoModelKey && best != INT64_MAX;
-        sfm_select_result r;
-        r.key = found ? key : kNoModelKey;
-        r.best_h = found ? best + h_offset : -1;
-        r.best_err = found ? __longlong_as_double((long long)key) : INFINITY;
-        r.first_flagged = first_flag != INT64_MAX ? first_flag + h_offset : INT64_MAX;
-        r.n_flagged = n_flag;
-        r.best_cnt = found ? cnt[best] : 0;
-        result[b] = r;
-    }
+    sfmsel::block_select<kSelectBlock>(cnt + b * h_count, s1 + b * h_count, s2 + b * h_count,
+                                       flags != nullptr ? flags + b * h_count : nullptr, h_count, h_offset, min_extra,
+                                       aggregation, result + b, scratch, &winner);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -482,28 +427,9 @@ __global__ void inlier_mask_kernel(const Corr* __restrict__ corr, int64_t n,
                                    int64_t h_count, const sfm_select_result* __restrict__ result,
                                    double thr, uint8_t* __restrict__ mask) {
     const int64_t b = blockIdx.y;
-    const int64_t h = result[b].best_h;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    uint8_t* out = mask + b * n;
-    if (h < 0 || h >= h_count) {
-        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = 0;
-        return;
-    }
-    double e[9];
-    int32_t smp[8];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) e[k] = E[(b * h_count + h) * 9 + k];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) smp[k] = S[(b * h_count + h) * 8 + k];
-    const Corr* pts = corr + b * n;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const Corr p = pts[i];
-        const double sed = sfm::sed_value(e, p.xa, p.ya, p.xb, p.yb);
-        bool in_sample = false;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) in_sample |= (smp[k] == (int32_t)i);
-        out[i] = in_sample ? 2 : ((sed <= thr) ? 1 : 0);
-    }
+    sfmsel::write_inlier_mask(corr + b * n, n, E + b * h_count * 9, S + b * h_count * 8, h_count, result[b].best_h, thr,
+                              mask + b * n, (int64_t)blockIdx.x * blockDim.x + threadIdx.x,
+                              (int64_t)gridDim.x * blockDim.x);
 }
 
 __global__ void sed_values_kernel(const Corr* __restrict__ corr, int64_t n, const double* __restrict__ E,
@@ -740,7 +666,7 @@ int sfm_fit_eight_point(const double* corr, int64_t n, const int32_t* S, int64_t
     SFM_REQUIRE_GRID("sfm_fit_eight_point", h_count, kWave, kWave, batch);
     hipLaunchKernelGGL(fit_eight_point_kernel<false>, dim3(grid_for(h_count, kWave), (unsigned)batch),
                        dim3(kWave), 0, (hipStream_t)stream, (const Corr*)corr, n, const_cast<int32_t*>(S), h_count, E,
-                       flags, lambda2, (double*)nullptr, PhiloxSource{nullptr, 0, 0, 0, 0});
+                       flags, lambda2, (double*)nullptr, PhiloxSource{nullptr, 0, 0, 0, 0}, SmallPrep{nullptr, 0.0, 0});
     return check_launch("fit_eight_point_kernel");
 }
 
@@ -754,8 +680,43 @@ int sfm_sample_fit_philox(uint64_t seed, const uint64_t* seed_dev, uint64_t seed
     SFM_REQUIRE_GRID("sfm_fit_eight_point", h_count, kWave, kWave, batch);
     hipLaunchKernelGGL(fit_eight_point_kernel<false>, dim3(grid_for(h_count, kWave), (unsigned)batch),
                        dim3(kWave), 0, (hipStream_t)stream, (const Corr*)corr, n, S, h_count, E, flags,
-                       (double*)nullptr, (double*)nullptr, PhiloxSource{seed_dev, seed, seed_stride, h_begin, 1});
+                       (double*)nullptr, (double*)nullptr, PhiloxSource{seed_dev, seed, seed_stride, h_begin, 1},
+                       SmallPrep{nullptr, 0.0, 0});
     return check_launch("fit_eight_point_kernel (philox)");
+}
+
+int sfm_ransac_pass_small(uint64_t seed, const uint64_t* seed_dev, int use_philox, int64_t h_begin, const double* corr,
+                          int64_t n, int64_t h_count, double thr, double min_extra, int aggregation, int64_t h_offset,
+                          int32_t* S, double* E, int32_t* flags, int32_t* cnt, double* s1, double* s2,
+                          sfm_select_result* result, uint8_t* mask, void* workspace, int64_t workspace_bytes,
+                          void* stream) {
+    if (n < 8 || n > sfmws::kSmallMaxPoints)
+        return fail(SFM_EINVAL, "sfm_ransac_pass_small: need 8 <= n <= 8192 (larger point sets: the separate calls)");
+    if (h_count < 1 || h_count > 32 * 1024)
+        return fail(SFM_EINVAL, "sfm_ransac_pass_small: need 1 <= h_count <= 32768 (more hypotheses: the separate calls)");
+    if (h_begin < 0) return fail(SFM_EINVAL, "sfm_ransac_pass_small: negative h_begin");
+    if (aggregation < SFM_AGG_SUM || aggregation > SFM_AGG_RMS)
+        return fail(SFM_EINVAL, "sfm_ransac_pass_small: unknown aggregation");
+    if (!corr || !S || !E || !flags || !cnt || !s1 || !s2 || !result || !workspace)
+        return fail(SFM_EINVAL, "sfm_ransac_pass_small: null pointer");
+    if (workspace_bytes < sfm_score_workspace_bytes(n, h_count, 1))
+        return fail(SFM_EINVAL, "sfm_ransac_pass_small: workspace smaller than sfm_score_workspace_bytes(n, h_count, 1)");
+    if ((reinterpret_cast<uintptr_t>(workspace) & 15u) != 0)
+        return fail(SFM_EINVAL, "sfm_ransac_pass_small: workspace must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    // launch 1: eight-point fits (Philox samples drawn in the kernel, or the caller's table in S) + workspace preparation
+    const int prep_blocks = (int)((n + sfmws::kPrepPoints - 1) / sfmws::kPrepPoints);
+    const unsigned fit_blocks = grid_for(h_count, kWave);
+    hipLaunchKernelGGL(fit_eight_point_kernel<false>, dim3(fit_blocks + (unsigned)prep_blocks, 1u), dim3(kWave), 0, st,
+                       (const Corr*)corr, n, S, h_count, E, flags, (double*)nullptr, (double*)nullptr,
+                       PhiloxSource{seed_dev, seed, 0, h_begin, use_philox ? 1 : 0},
+                       SmallPrep{static_cast<unsigned char*>(workspace), sfmhost::small_pass_a_scale(thr), prep_blocks});
+    const int rc = check_launch("fit_eight_point_kernel (fused small pass)");
+    if (rc != SFM_OK) return rc;
+    // launch 2: scoring; its last block selects the model and writes the mask
+    return sfmhost::launch_small_score(sfmhost::SmallPass{corr, n, E, S, flags, h_count, thr, min_extra, aggregation,
+                                                          h_offset, cnt, s1, s2, result, mask,
+                                                          static_cast<unsigned char*>(workspace), st});
 }
 
 int sfm_fit_trace_doubles(void) { return kTraceDoubles; }
@@ -769,7 +730,7 @@ int sfm_fit_eight_point_traced(const double* corr, int64_t n, const int32_t* S, 
     SFM_REQUIRE_GRID("sfm_fit_eight_point_traced", h_count, kWave, kWave, batch);
     hipLaunchKernelGGL(fit_eight_point_kernel<true>, dim3(grid_for(h_count, kWave), (unsigned)batch),
                        dim3(kWave), 0, (hipStream_t)stream, (const Corr*)corr, n, const_cast<int32_t*>(S), h_count, E,
-                       flags, (double*)nullptr, trace, PhiloxSource{nullptr, 0, 0, 0, 0});
+                       flags, (double*)nullptr, trace, PhiloxSource{nullptr, 0, 0, 0, 0}, SmallPrep{nullptr, 0.0, 0});
     return check_launch("fit_eight_point_kernel<trace>");
 }
 

@@ -43,9 +43,12 @@
 
 #include "sfm_common.h"
 #include "sfm_math.h"
+#include "sfm_score_ws.h"
+#include "sfm_select.h"
 
 namespace {
 
+using namespace sfmws;  // workspace layout: kBuckets, kPointsPad, ws_*_offset, workspace_bytes_for, ...
 using sfmhost::check_launch;
 using sfmhost::fail;
 using sfmhost::grid_for;
@@ -139,24 +142,8 @@ __global__ __launch_bounds__(256) void score_sed_exact_kernel(
 // ------------------------------------------------------------------------------------------------
 // Workspace preparation for the filtered kernel: fp32 copy of the correspondences and the data-set
 // maxima of |xa|, |ya|, |xb|, |yb| (as fp32 bit patterns: non-negative floats order like unsigned ints).
-// Workspace layout: [batch x 4 uint32 maxima][batch x n float4][batch x kBuckets int32][batch x h_count int32].
+// Workspace layout: sfm_score_ws.h.
 // ------------------------------------------------------------------------------------------------
-constexpr int kEstimatePoints = 1024;             // points scanned by the cost pre-pass
-constexpr int kClasses = 12;                      // coarse cost classes: 10 - floor(log2(survivors)), 0 survivors last
-constexpr int kClassStride = 16;                  // ints between class counters: one 64-byte line each
-constexpr int kBuckets = 16 * kClassStride;       // ints reserved per batch entry
-__host__ __device__ inline int64_t ws_points_offset(int64_t batch) { return 16 * batch; }
-constexpr int64_t kPointsPad = 4096;  // bytes after the fp32 points: the scoring loop prefetches up to 3 KiB past a pair's last point
-__host__ __device__ inline int64_t ws_buckets_offset(int64_t n, int64_t batch) {
-    return 16 * batch + 16 * n * batch + kPointsPad;
-}
-__host__ __device__ inline int64_t ws_order_offset(int64_t n, int64_t batch) {
-    return ws_buckets_offset(n, batch) + ((4 * (int64_t)kBuckets * batch + 15) / 16) * 16;
-}
-__host__ __device__ inline int64_t workspace_bytes_for(int64_t n, int64_t h_count, int64_t batch) {
-    return ws_order_offset(n, batch) + 4 * h_count * batch;
-}
-
 // Zero the per-batch maxima and class counters.  A kernel rather than hipMemsetAsync: one launch instead of
 // two, and a captured hipGraph of the pass then holds kernel nodes only (with hipMemsetAsync nodes in it, replaying
 // the graph while a second captured graph was alive faulted on ROCm 7.2 — profiles/r01/README.md).
@@ -179,7 +166,7 @@ __global__ void score_prepare_kernel(const Corr* __restrict__ corr, int64_t n, d
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const Corr p = pts[i];
         // a_scale: 1 for the two-sided test; c ~ 1/sqrt(T) for the one-sided one (see reject_mask_one_sided)
-        const float4 q = make_float4((float)(p.xa * a_scale), (float)(p.ya * a_scale), (float)p.xb, (float)p.yb);
+        const float4 q = to_filter_point(p, a_scale);
         out[i] = q;
         // NaN coordinates: fmaxf ignores them; such points always fail the filter's comparisons and are
         // decided by the exact tier.
@@ -448,12 +435,28 @@ __global__ __launch_bounds__(256) void score_class_scatter_kernel(const int32_t*
 // ------------------------------------------------------------------------------------------------
 // Filtered kernel.
 // ------------------------------------------------------------------------------------------------
-template <int HPW, bool ONE_SIDED>
+// What the last block of a fused small pass needs to select the model and mark the winner's inliers.
+struct FusedTail {
+    const int32_t* flags;
+    double min_extra;
+    int aggregation;
+    int64_t h_offset;
+    sfm_select_result* result;
+    uint8_t* mask;  // may be NULL
+    int prep_blocks;
+};
+
+// FUSED (small problems, one pair): the four waves of a block share the block's HPW hypotheses and take a quarter of
+// the points each (a hypothesis that fits the scene then spreads its tier-2 work over four waves, and a launch of few
+// hypotheses still fills the chip); per-wave totals are combined through LDS in wave order.  The block that finishes
+// last — an agent-scope ticket, cdna_hip_programming.md Guideline 16 in its counter form — then runs the model
+// selection and writes the winner's inlier mask, so the pass needs no further launch.
+template <int HPW, bool ONE_SIDED, bool FUSED = false>
 __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
     const Corr* __restrict__ corr, const unsigned char* __restrict__ ws, int n,
     const double* __restrict__ E, const int32_t* __restrict__ S, int h_count, double thr, double a_scale,
     const int32_t* __restrict__ order, int32_t* __restrict__ cnt, double* __restrict__ s1,
-    double* __restrict__ s2, int batch, int blocks_per_pair) {
+    double* __restrict__ s2, int batch, int blocks_per_pair, FusedTail tail_args) {
     __shared__ __attribute__((aligned(1024))) int32_t ring[256 / kWave][HPW][kRing];  // each ring = one aligned KiB
     const int lane = threadIdx.x & (kWave - 1);
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
@@ -471,9 +474,10 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
         pair = blockIdx.y;
         block_of_pair = blockIdx.x;
     }
-    const int wave = block_of_pair * (256 / kWave) + wave_in_block;
+    // FUSED: all four waves of the block own the same hypotheses (and split the points)
+    const int wave = FUSED ? block_of_pair : block_of_pair * (256 / kWave) + wave_in_block;
     const int h0 = wave * HPW;  // first of this wave's HPW slots in the processing order
-    if (h0 >= h_count) return;
+    if (h0 >= h_count) return;  // block-uniform when FUSED
     const int64_t b = pair;
     // slot -> hypothesis index (longest-first order from the pre-pass, or the identity)
     // With an order, the list (heaviest first) is dealt column-major over the waves: wave w takes entries
@@ -497,10 +501,28 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
         reinterpret_cast<const float4*>(ws + ws_points_offset(batch)) + b * (int64_t)n;
 
     // data-set coordinate maxima, inflated so they also bound the unrounded fp64 coordinates
-    const float Xa = __uint_as_float(maxima[0]) * (1.0f + 1e-6f);
-    const float Ya = __uint_as_float(maxima[1]) * (1.0f + 1e-6f);
-    const float Xb = __uint_as_float(maxima[2]) * (1.0f + 1e-6f);
-    const float Yb = __uint_as_float(maxima[3]) * (1.0f + 1e-6f);
+    float Xa, Ya, Xb, Yb;
+    if (FUSED) {  // the fit launch left one partial maximum per prepared block of points (sfm_score_ws.h)
+        const uint32_t* partial = reinterpret_cast<const uint32_t*>(ws + ws_buckets_offset(n, 1));
+        uint4 m = make_uint4(0u, 0u, 0u, 0u);
+        if (lane < tail_args.prep_blocks) m = reinterpret_cast<const uint4*>(partial)[lane];
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {  // prep_blocks <= 16: lanes 0..15
+            m.x = max(m.x, (uint32_t)__shfl_xor((int)m.x, off, 64));
+            m.y = max(m.y, (uint32_t)__shfl_xor((int)m.y, off, 64));
+            m.z = max(m.z, (uint32_t)__shfl_xor((int)m.z, off, 64));
+            m.w = max(m.w, (uint32_t)__shfl_xor((int)m.w, off, 64));
+        }
+        Xa = __uint_as_float(__builtin_amdgcn_readfirstlane(m.x)) * (1.0f + 1e-6f);
+        Ya = __uint_as_float(__builtin_amdgcn_readfirstlane(m.y)) * (1.0f + 1e-6f);
+        Xb = __uint_as_float(__builtin_amdgcn_readfirstlane(m.z)) * (1.0f + 1e-6f);
+        Yb = __uint_as_float(__builtin_amdgcn_readfirstlane(m.w)) * (1.0f + 1e-6f);
+    } else {
+        Xa = __uint_as_float(maxima[0]) * (1.0f + 1e-6f);
+        Ya = __uint_as_float(maxima[1]) * (1.0f + 1e-6f);
+        Xb = __uint_as_float(maxima[2]) * (1.0f + 1e-6f);
+        Yb = __uint_as_float(maxima[3]) * (1.0f + 1e-6f);
+    }
     // T = thr (1+k)(1 + 1e-5), rounded up; a negative or NaN threshold switches the filter off
     const float T = (thr >= 0.0) ? (float)(thr * (1.0 + 1.0 / 1024.0) * (1.0 + 1e-5)) * (1.0f + 2e-7f) : INFINITY;
 
@@ -625,11 +647,14 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
 
     const int full_chunks = n / kWave;
     const int pairs = full_chunks / 2;
-    if (pairs > 0) {
-        const float4* __restrict__ next = pts32 + lane;  // per-lane cursor: one 64-bit add per step, no index clamping
+    // FUSED: this wave's quarter of the chunk pairs; the ragged end of the point set goes to the last wave
+    const int pr_begin = FUSED ? pairs * wave_in_block / 4 : 0;
+    const int pr_end = FUSED ? pairs * (wave_in_block + 1) / 4 : pairs;
+    if (pr_end > pr_begin) {
+        const float4* __restrict__ next = pts32 + pr_begin * 2 * kWave + lane;  // per-lane cursor: one 64-bit add per step, no index clamping
         float4 p0 = next[0], p1 = next[kWave];
-        int i0 = lane;
-        for (int pr = 0; pr < pairs; ++pr) {
+        int i0 = pr_begin * 2 * kWave + lane;
+        for (int pr = pr_begin; pr < pr_end; ++pr) {
             // prefetch the next pair; the last step reads up to 3 KiB past the pair's points, inside the workspace
             // (the next pair's points, or the kPointsPad bytes behind the last pair's) and never uses them
             next += 2 * kWave;
@@ -641,9 +666,11 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
             i0 += 2 * kWave;
         }
     }
-    for (int chunk = pairs * 2; chunk * kWave < n; ++chunk) {  // at most two iterations
-        const int i = chunk * kWave + lane;
-        process_tail(pts32[min(i, n - 1)], i, i < n);
+    if (!FUSED || wave_in_block == 3) {
+        for (int chunk = pairs * 2; chunk * kWave < n; ++chunk) {  // at most two iterations
+            const int i = chunk * kWave + lane;
+            process_tail(pts32[min(i, n - 1)], i, i < n);
+        }
     }
 #pragma unroll
     for (int k = 0; k < HPW; ++k) {
@@ -651,15 +678,75 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
         if (left > 0) drain(k, left);
     }
 
+    if constexpr (!FUSED) {
 #pragma unroll
-    for (int k = 0; k < HPW; ++k) {
-        const int h = hyp[k];
-        if (slot_valid[k]) {  // wave-uniform: this slot exists
-            double e[9];
+        for (int k = 0; k < HPW; ++k) {
+            const int h = hyp[k];
+            if (slot_valid[k]) {  // wave-uniform: this slot exists
+                double e[9];
 #pragma unroll
-            for (int j = 0; j < 9; ++j) e[j] = Eb[(int64_t)h * 9 + j];
-            const int64_t o = b * (int64_t)h_count + h;
-            finish_hypothesis(pts, Sb + (int64_t)h * 8, e, thr, lane, c[k], a1[k], a2[k], cnt + o, s1 + o, s2 + o);
+                for (int j = 0; j < 9; ++j) e[j] = Eb[(int64_t)h * 9 + j];
+                const int64_t o = b * (int64_t)h_count + h;
+                finish_hypothesis(pts, Sb + (int64_t)h * 8, e, thr, lane, c[k], a1[k], a2[k], cnt + o, s1 + o, s2 + o);
+            }
+        }
+    } else {
+        // combine the four waves' totals (fixed order: wave 0..3), then wave k finishes hypothesis k of the block
+        __shared__ int part_c[256 / kWave][HPW];
+        __shared__ double part_a1[256 / kWave][HPW], part_a2[256 / kWave][HPW];
+#pragma unroll
+        for (int k = 0; k < HPW; ++k) {
+            const int ck = sfm::wave_sum(c[k]);
+            const double a1k = sfm::wave_sum(a1[k]);
+            const double a2k = sfm::wave_sum(a2[k]);
+            if (lane == 0) {
+                part_c[wave_in_block][k] = ck;
+                part_a1[wave_in_block][k] = a1k;
+                part_a2[wave_in_block][k] = a2k;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < HPW; ++k) {
+            if (k == wave_in_block && slot_valid[k]) {  // wave-uniform
+                const int h = hyp[k];
+                double e[9];
+#pragma unroll
+                for (int j = 0; j < 9; ++j) e[j] = Eb[(int64_t)h * 9 + j];
+                const bool first = lane == 0;
+                const int ct = first ? ((part_c[0][k] + part_c[1][k]) + part_c[2][k]) + part_c[3][k] : 0;
+                const double a1t = first ? ((part_a1[0][k] + part_a1[1][k]) + part_a1[2][k]) + part_a1[3][k] : 0.0;
+                const double a2t = first ? ((part_a2[0][k] + part_a2[1][k]) + part_a2[2][k]) + part_a2[3][k] : 0.0;
+                finish_hypothesis(pts, Sb + (int64_t)h * 8, e, thr, lane, ct, a1t, a2t, cnt + h, s1 + h, s2 + h);
+            }
+        }
+        // ---- arrival ticket: the block that finishes last selects the model and marks its inliers ----
+        // Publish (Guideline 16, counter form): every storing wave drains its stores, the block meets, ONE lane
+        // releases at agent scope (L2 write-back: the reader may sit on another XCD), drains again, then counts.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        __shared__ int last_block;
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            unsigned* ticket = reinterpret_cast<unsigned*>(const_cast<unsigned char*>(ws) + ws_buckets_offset(n, 1)) + kTicketWord;
+            const unsigned arrived = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool last = arrived == gridDim.x - 1;
+            if (last) {  // acquire: drop this CU's cached copies of the other blocks' cnt / s1 / s2 lines
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            last_block = last ? 1 : 0;
+        }
+        __syncthreads();
+        if (last_block) {
+            __shared__ sfmsel::SelectScratch<256> scratch;
+            __shared__ int64_t winner;
+            const int64_t best = sfmsel::block_select<256>(cnt, s1, s2, tail_args.flags, h_count, tail_args.h_offset,
+                                                           tail_args.min_extra, tail_args.aggregation, tail_args.result,
+                                                           scratch, &winner);
+            if (tail_args.mask != nullptr)
+                sfmsel::write_inlier_mask(pts, n, E, S, h_count, best, thr, tail_args.mask, threadIdx.x, 256);
         }
     }
 }
@@ -720,15 +807,46 @@ int launch_filtered(const FilteredLaunch& a) {
     if (g_event_before) (void)hipEventRecord(g_event_before, a.st);
     if (a.one_sided)
         hipLaunchKernelGGL((score_sed_filtered_kernel<HPW, true>), flat, dim3(256), 0, a.st, a.corr, a.ws, a.n, a.E, a.S,
-                           a.h_count, a.thr, a.a_scale, order_arg, a.cnt, a.s1, a.s2, (int)a.batch, blocks_per_pair);
+                           a.h_count, a.thr, a.a_scale, order_arg, a.cnt, a.s1, a.s2, (int)a.batch, blocks_per_pair, FusedTail{});
     else
         hipLaunchKernelGGL((score_sed_filtered_kernel<HPW, false>), flat, dim3(256), 0, a.st, a.corr, a.ws, a.n, a.E, a.S,
-                           a.h_count, a.thr, a.a_scale, order_arg, a.cnt, a.s1, a.s2, (int)a.batch, blocks_per_pair);
+                           a.h_count, a.thr, a.a_scale, order_arg, a.cnt, a.s1, a.s2, (int)a.batch, blocks_per_pair, FusedTail{});
     if (g_event_after) (void)hipEventRecord(g_event_after, a.st);
     return check_launch("score_sed_filtered_kernel");
 }
 
 }  // namespace
+
+namespace sfmhost {
+
+double small_pass_a_scale(double thr) { return one_sided_scale(thr); }
+
+int launch_small_score(const SmallPass& p) {
+    // hypotheses per block: 4 amortise the point loads best; fewer when the launch would leave the chip short of waves
+    // (a block is four waves either way: they split the points)
+    int hpw = kHypPerWave;
+    while (hpw > 1 && 4 * ((p.h_count + hpw - 1) / hpw) < 5120) hpw /= 2;
+    const int64_t blocks = (p.h_count + hpw - 1) / hpw;
+    SFM_REQUIRE_GRID("sfm_ransac_pass_small", blocks, 1, 256);
+    const FusedTail tail{p.flags, p.min_extra, p.aggregation, p.h_offset, p.result, p.mask,
+                         (int)((p.n + kPrepPoints - 1) / kPrepPoints)};
+    const dim3 grid((unsigned)blocks);
+    if (g_event_before) (void)hipEventRecord(g_event_before, p.stream);
+#define SFM_LAUNCH_FUSED(H)                                                                                          \
+    hipLaunchKernelGGL((score_sed_filtered_kernel<H, true, true>), grid, dim3(256), 0, p.stream, (const Corr*)p.corr, \
+                       p.workspace, (int)p.n, p.E, p.S, (int)p.h_count, p.thr, one_sided_scale(p.thr),               \
+                       (const int32_t*)nullptr, p.cnt, p.s1, p.s2, 1, 0, tail)
+    switch (hpw) {
+        case 1: SFM_LAUNCH_FUSED(1); break;
+        case 2: SFM_LAUNCH_FUSED(2); break;
+        default: SFM_LAUNCH_FUSED(4); break;
+    }
+#undef SFM_LAUNCH_FUSED
+    if (g_event_after) (void)hipEventRecord(g_event_after, p.stream);
+    return check_launch("score_sed_filtered_kernel (fused small pass)");
+}
+
+}  // namespace sfmhost
 
 extern "C" {
 

@@ -1,0 +1,90 @@
+// Layout of the scoring workspace (sfm_score_workspace_bytes) and the device routines that fill it, shared by the
+// scoring kernels (sfm_score.hip) and by the fit kernel (sfm_kernels.hip), which prepares the workspace of a small
+// fused pass in spare blocks of its own launch.
+//
+//   [batch x 4 uint32 maxima][batch x n float4 points][kPointsPad bytes][batch x kBuckets int32][batch x h_count int32]
+//
+// maxima: data-set maxima of |xa'|, |ya'|, |xb|, |yb| of the fp32 points as bit patterns (non-negative floats order
+// like unsigned ints).  buckets: per pair 256 ints — class counters of the longest-first ordering in large launches;
+// in a fused small pass (which never orders) the same words carry the per-block partial maxima and the arrival ticket.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sfm_common.h"
+
+namespace sfmws {
+
+constexpr int kEstimatePoints = 1024;        // points scanned by the cost pre-pass
+constexpr int kClasses = 12;                 // coarse cost classes: 10 - floor(log2(survivors)), 0 survivors last
+constexpr int kClassStride = 16;             // ints between class counters: one 64-byte line each
+constexpr int kBuckets = 16 * kClassStride;  // ints reserved per batch entry
+constexpr int64_t kPointsPad = 4096;         // bytes after the fp32 points: the scoring loop prefetches up to 3 KiB past a pair's last point
+
+// fused small pass (n <= kSmallMaxPoints): the fit launch prepares the points in blocks of kPrepPoints
+constexpr int kPrepPoints = 512;             // 64 lanes x 8 points, all loads of a lane in flight together
+constexpr int kSmallMaxPoints = 8192;
+constexpr int kMaxPrepBlocks = kSmallMaxPoints / kPrepPoints;  // 16 partial maxima x 4 words = buckets[0, 64)
+constexpr int kTicketWord = 4 * kMaxPrepBlocks;                // buckets[64]: blocks that have finished scoring
+static_assert(kTicketWord < kBuckets, "partial maxima and ticket live in the class-counter words");
+
+__host__ __device__ inline int64_t ws_points_offset(int64_t batch) { return 16 * batch; }
+__host__ __device__ inline int64_t ws_buckets_offset(int64_t n, int64_t batch) {
+    return 16 * batch + 16 * n * batch + kPointsPad;
+}
+__host__ __device__ inline int64_t ws_order_offset(int64_t n, int64_t batch) {
+    return ws_buckets_offset(n, batch) + ((4 * (int64_t)kBuckets * batch + 15) / 16) * 16;
+}
+__host__ __device__ inline int64_t workspace_bytes_for(int64_t n, int64_t h_count, int64_t batch) {
+    return ws_order_offset(n, batch) + 4 * h_count * batch;
+}
+
+// fp32 record of one correspondence as tier 1 reads it; a_scale: 1 for the two-sided test, c ~ 1/sqrt(T) for the
+// one-sided one (reject_mask_one_sided in sfm_score.hip)
+__device__ __forceinline__ float4 to_filter_point(const Corr& p, double a_scale) {
+    return make_float4((float)(p.xa * a_scale), (float)(p.ya * a_scale), (float)p.xb, (float)p.yb);
+}
+
+// One 64-lane block of a fused small pass prepares points [block * 512, ...): fp32 copies and this block's partial
+// maxima; block 0 also zeroes the arrival ticket of the scoring launch that follows (a kernel boundary orders them).
+// NaN coordinates: fmaxf ignores them; such points fail every filter comparison and are decided by the exact tier.
+__device__ __forceinline__ void prepare_small_block(const Corr* __restrict__ pts, int n, double a_scale,
+                                                    unsigned char* __restrict__ ws, int block) {
+    const int lane = threadIdx.x & (kWave - 1);
+    float4* __restrict__ out = reinterpret_cast<float4*>(ws + ws_points_offset(1));
+    int32_t* buckets = reinterpret_cast<int32_t*>(ws + ws_buckets_offset(n, 1));
+    Corr p[8];
+    const int base = block * kPrepPoints + lane;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) p[j] = pts[min(base + j * kWave, n - 1)];
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = base + j * kWave;
+        if (i < n) {
+            const float4 q = to_filter_point(p[j], a_scale);
+            out[i] = q;
+            m0 = fmaxf(m0, fabsf(q.x));
+            m1 = fmaxf(m1, fabsf(q.y));
+            m2 = fmaxf(m2, fabsf(q.z));
+            m3 = fmaxf(m3, fabsf(q.w));
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        m0 = fmaxf(m0, __shfl_xor(m0, off, 64));
+        m1 = fmaxf(m1, __shfl_xor(m1, off, 64));
+        m2 = fmaxf(m2, __shfl_xor(m2, off, 64));
+        m3 = fmaxf(m3, __shfl_xor(m3, off, 64));
+    }
+    if (lane == 0) {
+        uint32_t* partial = reinterpret_cast<uint32_t*>(buckets) + 4 * block;
+        partial[0] = __float_as_uint(m0);
+        partial[1] = __float_as_uint(m1);
+        partial[2] = __float_as_uint(m2);
+        partial[3] = __float_as_uint(m3);
+        if (block == 0) buckets[kTicketWord] = 0;
+    }
+}
+
+}  // namespace sfmws

@@ -98,9 +98,13 @@ Tensor normalize_coords(const Tensor& pix_a, const Tensor& pix_b, double fx, dou
     return out;
 }
 
+// Meta kernels: shapes only, through the SymInt accessors (they also run under dynamic-shape tracing, where sizes
+// are symbolic and numel() / sizes() are not available); value checks stay with the device kernels.
 Tensor normalize_coords_meta(const Tensor& pix_a, const Tensor& pix_b, double, double, double, double) {
-    TORCH_CHECK(pix_a.sizes() == pix_b.sizes(), "sfm_hip: pix_a, pix_b must have equal shapes");
-    return at::empty(normalized_shape(pix_a), pix_a.options());
+    TORCH_CHECK(pix_a.dim() >= 1 && pix_a.dim() == pix_b.dim(), "sfm_hip: pix_a, pix_b must be [..., 2] of equal shape");
+    std::vector<c10::SymInt> shape(pix_a.sym_sizes().begin(), pix_a.sym_sizes().end());
+    shape.back() = 4;
+    return at::empty_symint(shape, pix_a.options());
 }
 
 // ---- sample_philox ---------------------------------------------------------------------------------------------
@@ -137,9 +141,15 @@ std::tuple<Tensor, Tensor> fit_eight_point(const Tensor& corr, const Tensor& S) 
     return {E, flags};
 }
 
+void meta_dims(const Tensor& corr, const Tensor& S) {
+    TORCH_CHECK(corr.dim() == 3, "sfm_hip: corr must be [batch, n, 4]");
+    TORCH_CHECK(S.dim() == 3, "sfm_hip: S must be [batch, h, 8]");
+}
+
 std::tuple<Tensor, Tensor> fit_eight_point_meta(const Tensor& corr, const Tensor& S) {
-    const Dims d = hypothesis_dims(corr, S);
-    return {at::empty({d.batch, d.h, 9}, like(corr, at::kDouble)), at::empty({d.batch, d.h}, like(corr, at::kInt))};
+    meta_dims(corr, S);
+    return {at::empty_symint({corr.sym_size(0), S.sym_size(1), 9}, like(corr, at::kDouble)),
+            at::empty_symint({corr.sym_size(0), S.sym_size(1)}, like(corr, at::kInt))};
 }
 
 // Philox sampling fused into the fit launch; `seed_dev` (int64 [1] on the device) is read at kernel run time when given
@@ -195,10 +205,42 @@ std::tuple<Tensor, Tensor, Tensor> score_sed(const Tensor& corr, const Tensor& E
 }
 
 std::tuple<Tensor, Tensor, Tensor> score_sed_meta(const Tensor& corr, const Tensor& E, const Tensor& S, double, bool) {
+    meta_dims(corr, S);
+    TORCH_CHECK(E.dim() == 3, "sfm_hip: E must be [batch, h, 9]");
+    const c10::SymInt b = corr.sym_size(0), h = S.sym_size(1);
+    return {at::empty_symint({b, h}, like(corr, at::kInt)), at::empty_symint({b, h}, like(corr, at::kDouble)),
+            at::empty_symint({b, h}, like(corr, at::kDouble))};
+}
+
+// ---- fused small pass (two launches: fit + workspace preparation, scoring + selection + mask) -------------------
+void ransac_pass_small_out(const Tensor& corr, int64_t seed, const std::optional<Tensor>& seed_dev, bool use_philox,
+                           int64_t h_begin, double thr, double min_extra, int64_t aggregation, int64_t h_offset,
+                           Tensor& S, Tensor& E, Tensor& flags, Tensor& cnt, Tensor& s1, Tensor& s2, Tensor& result,
+                           const std::optional<Tensor>& mask, Tensor& workspace) {
+    need(corr, "corr", at::kDouble);
+    need(S, "S", at::kInt);
+    need(E, "E", at::kDouble);
+    need(flags, "flags", at::kInt);
+    need(cnt, "cnt", at::kInt);
+    need(s1, "s1", at::kDouble);
+    need(s2, "s2", at::kDouble);
+    need(result, "result", at::kLong);
+    need(workspace, "workspace", at::kByte);
+    if (seed_dev.has_value()) need(*seed_dev, "seed_dev", at::kLong);
+    if (mask.has_value()) need(*mask, "mask", at::kByte);
     const Dims d = hypothesis_dims(corr, S);
+    TORCH_CHECK(d.batch == 1, "sfm_hip::ransac_pass_small_: one image pair per call");
     check_E(E, d);
-    return {at::empty({d.batch, d.h}, like(corr, at::kInt)), at::empty({d.batch, d.h}, like(corr, at::kDouble)),
-            at::empty({d.batch, d.h}, like(corr, at::kDouble))};
+    TORCH_CHECK(flags.numel() == d.h && cnt.numel() == d.h && s1.numel() == d.h && s2.numel() == d.h,
+                "sfm_hip: flags, cnt, s1, s2 must be [1, h]");
+    TORCH_CHECK(result.numel() == kRecordWords, "sfm_hip: result must be int64 [1, 5]");
+    TORCH_CHECK(!mask.has_value() || mask->numel() == d.n, "sfm_hip: mask must be uint8 [1, n]");
+    ok(sfm_ransac_pass_small((uint64_t)seed, reinterpret_cast<const uint64_t*>(ptr<int64_t>(seed_dev)), use_philox ? 1 : 0,
+                             h_begin, ptr<double>(corr), d.n, d.h, thr, min_extra, (int)aggregation, h_offset,
+                             ptr<int32_t>(S), ptr<double>(E), ptr<int32_t>(flags), ptr<int32_t>(cnt), ptr<double>(s1),
+                             ptr<double>(s2), reinterpret_cast<sfm_select_result*>(ptr<int64_t>(result)),
+                             ptr<uint8_t>(mask), ptr<unsigned char>(workspace), workspace.numel(), current_stream()),
+       "sfm_ransac_pass_small");
 }
 
 // ---- select_best -----------------------------------------------------------------------------------------------
@@ -229,7 +271,7 @@ Tensor select_best(const Tensor& cnt, const Tensor& s1, const Tensor& s2, const 
 Tensor select_best_meta(const Tensor& cnt, const Tensor&, const Tensor&, const std::optional<Tensor>&, double, int64_t,
                         int64_t) {
     TORCH_CHECK(cnt.dim() == 2, "sfm_hip: cnt must be [batch, h]");
-    return at::empty({cnt.size(0), kRecordWords}, like(cnt, at::kLong));
+    return at::empty_symint({cnt.sym_size(0), kRecordWords}, like(cnt, at::kLong));
 }
 
 // ---- inlier_mask -----------------------------------------------------------------------------------------------
@@ -258,8 +300,8 @@ Tensor inlier_mask(const Tensor& corr, const Tensor& E, const Tensor& S, const T
 }
 
 Tensor inlier_mask_meta(const Tensor& corr, const Tensor&, const Tensor&, const Tensor&, double) {
-    const Dims d = corr_dims(corr);
-    return at::empty({d.batch, d.n}, like(corr, at::kByte));
+    TORCH_CHECK(corr.dim() == 3, "sfm_hip: corr must be [batch, n, 4]");
+    return at::empty_symint({corr.sym_size(0), corr.sym_size(1)}, like(corr, at::kByte));
 }
 
 // ---- cheirality / triangulate ------------------------------------------------------------------------------------
@@ -276,9 +318,8 @@ Tensor cheirality(const Tensor& corr, const Tensor& pose_rt, double distance_thr
 }
 
 Tensor cheirality_meta(const Tensor& corr, const Tensor& pose_rt, double) {
-    TORCH_CHECK(corr.dim() == 2 && corr.size(1) == 4 && pose_rt.dim() == 2 && pose_rt.size(1) == 12,
-                "sfm_hip: corr [m, 4], pose_rt [poses, 12]");
-    return at::empty({pose_rt.size(0), corr.size(0)}, like(corr, at::kByte));
+    TORCH_CHECK(corr.dim() == 2 && pose_rt.dim() == 2, "sfm_hip: corr [m, 4], pose_rt [poses, 12]");
+    return at::empty_symint({pose_rt.sym_size(0), corr.sym_size(0)}, like(corr, at::kByte));
 }
 
 Tensor triangulate(const Tensor& corr, const Tensor& P1, const Tensor& P2) {
@@ -294,10 +335,9 @@ Tensor triangulate(const Tensor& corr, const Tensor& P1, const Tensor& P2) {
     return X;
 }
 
-Tensor triangulate_meta(const Tensor& corr, const Tensor& P1, const Tensor& P2) {
-    TORCH_CHECK(corr.dim() == 2 && corr.size(1) == 4 && P1.numel() == 12 && P2.numel() == 12,
-                "sfm_hip: corr [m, 4], P1 / P2 12 doubles");
-    return at::empty({corr.size(0), 3}, corr.options());
+Tensor triangulate_meta(const Tensor& corr, const Tensor&, const Tensor&) {
+    TORCH_CHECK(corr.dim() == 2, "sfm_hip: corr must be [m, 4]");
+    return at::empty_symint({corr.sym_size(0), 3}, corr.options());
 }
 
 }  // namespace
@@ -313,6 +353,9 @@ TORCH_LIBRARY(sfm_hip, m) {
     m.def("score_sed(Tensor corr, Tensor E, Tensor S, float thr, bool exact=False) -> (Tensor, Tensor, Tensor)");
     m.def("score_sed_(Tensor corr, Tensor E, Tensor S, float thr, Tensor(a!) cnt, Tensor(b!) s1, Tensor(c!) s2, "
           "Tensor(d!)? workspace) -> ()");
+    m.def("ransac_pass_small_(Tensor corr, int seed, Tensor? seed_dev, bool use_philox, int h_begin, float thr, "
+          "float min_extra, int aggregation, int h_offset, Tensor(a!) S, Tensor(b!) E, Tensor(c!) flags, Tensor(d!) cnt, "
+          "Tensor(e!) s1, Tensor(f!) s2, Tensor(g!) result, Tensor(h!)? mask, Tensor(i!) workspace) -> ()");
     m.def("select_best(Tensor cnt, Tensor s1, Tensor s2, Tensor? flags, float min_extra, int aggregation, "
           "int h_offset=0) -> Tensor");
     m.def("select_best_(Tensor cnt, Tensor s1, Tensor s2, Tensor? flags, float min_extra, int aggregation, "
@@ -332,6 +375,7 @@ TORCH_LIBRARY_IMPL(sfm_hip, CUDA, m) {
     m.impl("sample_fit_philox_", &sample_fit_philox_out);
     m.impl("score_sed", &score_sed);
     m.impl("score_sed_", &score_sed_out);
+    m.impl("ransac_pass_small_", &ransac_pass_small_out);
     m.impl("select_best", &select_best);
     m.impl("select_best_", &select_best_out);
     m.impl("inlier_mask", &inlier_mask);
@@ -350,6 +394,9 @@ void sample_fit_philox_out_meta(const Tensor&, int64_t, const std::optional<Tens
                                 Tensor&) {}
 void score_sed_out_meta(const Tensor&, const Tensor&, const Tensor&, double, Tensor&, Tensor&, Tensor&,
                         const std::optional<Tensor>&) {}
+void ransac_pass_small_out_meta(const Tensor&, int64_t, const std::optional<Tensor>&, bool, int64_t, double, double, int64_t,
+                                int64_t, Tensor&, Tensor&, Tensor&, Tensor&, Tensor&, Tensor&, Tensor&,
+                                const std::optional<Tensor>&, Tensor&) {}
 void select_best_out_meta(const Tensor&, const Tensor&, const Tensor&, const std::optional<Tensor>&, double, int64_t,
                           int64_t, Tensor&) {}
 void inlier_mask_out_meta(const Tensor&, const Tensor&, const Tensor&, const Tensor&, double, Tensor&) {}
@@ -359,6 +406,7 @@ TORCH_LIBRARY_IMPL(sfm_hip, Meta, m) {
     m.impl("fit_eight_point_", &fit_eight_point_out_meta);
     m.impl("sample_fit_philox_", &sample_fit_philox_out_meta);
     m.impl("score_sed_", &score_sed_out_meta);
+    m.impl("ransac_pass_small_", &ransac_pass_small_out_meta);
     m.impl("select_best_", &select_best_out_meta);
     m.impl("inlier_mask_", &inlier_mask_out_meta);
     m.impl("normalize_coords", &normalize_coords_meta);

@@ -224,6 +224,33 @@ def score_timing_events(before: Optional[torch.cuda.Event], after: Optional[torc
           "sfm_score_set_timing_events")
 
 
+SMALL_PASS_MAX_POINTS, SMALL_PASS_MAX_HYPOTHESES = 8192, 32768
+
+
+def small_pass_eligible(batch: int, n: int, h: int) -> bool:
+    """Whether a pass can run as the two-launch fused small pass (``sfm_ransac_pass_small``): one pair, at most 8192
+    correspondences and 32768 hypotheses, the default two-tier scoring kernel.  ``SFM_SMALL_PASS=0`` keeps the
+    separate calls (for A/B comparisons)."""
+    return (batch == 1 and 8 <= n <= SMALL_PASS_MAX_POINTS and 1 <= h <= SMALL_PASS_MAX_HYPOTHESES
+            and os.environ.get("SFM_SMALL_PASS", "1") != "0"
+            and os.environ.get("SFM_SCORE_KERNEL", "filtered") != "exact")
+
+
+def ransac_pass_small(corr, S, E, flags, cnt, s1, s2, result, mask, workspace, thr: float, min_extra: float,
+                      aggregation: int, h_offset: int = 0, philox=None) -> None:
+    """One whole pass of a small problem in two launches (fit + workspace preparation, scoring + selection + mask).
+    ``philox=(seed, h_begin)``: samples drawn in the kernel (``seed`` an int or an int64 device tensor), else the
+    table already in ``S``.  Same outputs as the separate calls."""
+    if philox is None:
+        seed, seed_dev, use_philox, h_begin = 0, None, False, 0
+    else:
+        seed, h_begin = philox
+        on_device = isinstance(seed, torch.Tensor)
+        seed, seed_dev, use_philox = (0, seed, True) if on_device else (_as_int64(seed), None, True)
+    ops.load().ransac_pass_small_(corr, seed, seed_dev, use_philox, h_begin, float(thr), float(min_extra),
+                                  int(aggregation), h_offset, S, E, flags, cnt, s1, s2, result, mask, workspace)
+
+
 def select_best(cnt, s1, s2, flags, min_extra: float, aggregation: int, h_offset: int = 0, out=None):
     """-> int64 tensor [B,5] viewing the sfm_select_result records."""
     op = ops.load()
@@ -403,6 +430,12 @@ class RansacWorkspace:
         """fit + score + select (+ mask) for the sample table currently in ``self.S`` — or, with
         ``philox=(seed, h_begin, seed_stride)``, for Philox samples drawn inside the fit kernel (which also fills
         ``self.S``); ``seed`` may be an int64 device tensor (read at kernel run time)."""
+        if small_pass_eligible(self.batch, self.n, self.h) and (not with_mask or h_offset == 0):
+            # two launches instead of five (seed_stride only matters for batches)
+            ransac_pass_small(corr, self.S, self.E, self.flags, self.cnt, self.s1, self.s2, self.result,
+                              self.mask if with_mask else None, self.score_ws, thr, min_extra, aggregation, h_offset,
+                              None if philox is None else (philox[0], philox[1]))
+            return
         if philox is None:
             fit_eight_point(corr, self.S, self.E, self.flags)
         else:

@@ -181,10 +181,13 @@ class ShardedRansac:
             self._local_pass(None)  # warm-up outside capture (lazy module loads)
         torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        allocations = torch.cuda.memory_stats(self.corr.device).get("allocation.all.allocated", 0)
+        def allocations():  # host-side counter of the caching allocator (torch's own capture set-up allocates too:
+            return torch.cuda.memory_stats(self.corr.device).get("allocation.all.allocated", 0)  # count only our pass)
+
         with torch.cuda.graph(graph):
+            before = allocations()
             self._local_pass(None)
-        grown = torch.cuda.memory_stats(self.corr.device).get("allocation.all.allocated", 0) - allocations
+            grown = allocations() - before
         if grown:
             # a tensor allocated during capture lives in the graph's private pool and is recycled by later
             # replays: every buffer of the pass must exist before capture (graph replay)

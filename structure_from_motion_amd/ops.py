@@ -37,4 +37,4 @@ def load():
 FUNCTIONAL_OPS = ("normalize_coords", "sample_philox", "fit_eight_point", "score_sed", "select_best", "inlier_mask",
                   "cheirality", "triangulate")
 INPLACE_OPS = ("normalize_coords_", "fit_eight_point_", "sample_fit_philox_", "score_sed_", "select_best_",
-               "inlier_mask_")
+               "inlier_mask_", "ransac_pass_small_")

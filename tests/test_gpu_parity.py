@@ -654,6 +654,70 @@ def test_c4_virtual_shards_full_size(dev):
     assert rel(outs[0].E, orc.fit_hypotheses(corr, S_own[None, :])[0][0]) <= 1e-6
 
 
+@pytest.mark.parametrize("n,h,philox", [(8, 1, True), (130, 3, False), (300, 2000, True), (777, 5, True),
+                                        (1000, 64, False), (5000, 10000, True), (8192, 32768, True), (4099, 1300, False)])
+def test_fused_small_pass_equals_separate_calls(dev, monkeypatch, n, h, philox):
+    """sfm_ransac_pass_small (two launches: fit + workspace preparation, split-point scoring + selection + mask by the
+    last block) against the five separate calls on the same inputs: samples, E, flags, counts, winner record and mask
+    bit-identical; the two sums differ only by summation order (per-wave quarters instead of whole waves); and
+    against the oracle where it finishes in seconds."""
+    from structure_from_motion_amd._native import AGG_RMS, AGG_SUM
+
+    _, _, _, corr = scene(n, seed=40 + n % 7)
+    corr_d = dev.to_device(corr).reshape(1, n, 4)
+    thr, min_extra = 1.5e-6, 10 if n >= 300 else 0
+    table = orc.philox_sample_table(9, 100, h, n)
+    outs = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("SFM_SMALL_PASS", fused)
+        assert dev.small_pass_eligible(1, n, h) == (fused == "1")
+        ws = dev.RansacWorkspace(1, n, h)
+        if philox:
+            ws.run(corr_d, thr, min_extra, AGG_RMS, philox=(9, 100, 1))
+        else:
+            ws.S.copy_(dev.to_device(table, torch.int32).reshape(1, h, 8))
+            ws.run(corr_d, thr, min_extra, AGG_SUM)
+        outs.append({k: getattr(ws, k).cpu().numpy().copy() for k in ("S", "E", "flags", "cnt", "s1", "s2", "result", "mask")})
+    fused, plain = outs
+    for key in ("S", "E", "flags", "cnt", "mask"):
+        np.testing.assert_array_equal(fused[key], plain[key], err_msg=key)
+    np.testing.assert_allclose(fused["s1"], plain["s1"], rtol=1e-13, atol=0, equal_nan=True)
+    np.testing.assert_allclose(fused["s2"], plain["s2"], rtol=1e-13, atol=0, equal_nan=True)
+    np.testing.assert_array_equal(fused["S"][0], table)
+    rec_f, rec_p = fused["result"][0], plain["result"][0]
+    # winner, flag statistics and count identical; the error (words 0 and 2: key, best_err) to summation order
+    assert rec_f[1] == rec_p[1] and rec_f[3] == rec_p[3] and rec_f[4] == rec_p[4]
+    if rec_p[1] >= 0:
+        assert abs(rec_f[2:3].view(np.float64)[0] / rec_p[2:3].view(np.float64)[0] - 1.0) <= 1e-13
+    if n * h <= 2_000_000:
+        ref = orc.ransac_essential(corr, table, thr, min_extra, orc.RMS if philox else orc.SUM)
+        assert ref["best"] == rec_f[1]
+        np.testing.assert_array_equal(fused["cnt"][0], ref["cnt"])
+        if ref["best"] >= 0:
+            np.testing.assert_array_equal(np.nonzero(fused["mask"][0])[0], np.sort(ref["inliers"]))
+
+
+def test_fused_small_pass_repeated_and_offsets(dev):
+    """The arrival ticket is re-armed by every pass (50 passes in a row on one workspace give 50 correct winners), and
+    h_offset / no-mask (the form a multi-GPU shard uses) behaves like sfm_select_best's."""
+    from structure_from_motion_amd._native import AGG_RMS
+
+    n, h = 2000, 700
+    _, _, _, corr = scene(n, seed=3)
+    corr_d = dev.to_device(corr).reshape(1, n, 4)
+    ws = dev.RansacWorkspace(1, n, h)
+    got = []
+    for seed in range(50):
+        ws.run(corr_d, 1.5e-6, 10, AGG_RMS, philox=(seed, 0, 1))
+        got.append(int(ws.result[0, 1].cpu()))
+    for seed in (0, 17, 49):
+        ref = orc.ransac_essential(corr, orc.philox_sample_table(seed, 0, h, n), 1.5e-6, 10, orc.RMS)
+        assert got[seed] == ref["best"]
+    ws.run(corr_d, 1.5e-6, 10, AGG_RMS, h_offset=123_456, with_mask=False, philox=(49, 0, 1))
+    rec = dev.read_select(ws.result)[0]
+    assert rec.best_h == got[49] + 123_456 and rec.n_flagged == 0
+
+
 @pytest.mark.parametrize("n,h", [(300, 2000), (9000, 12000)])
 def test_graph_replay_equals_eager(dev, n, h):
     """A captured HIP graph of the whole pass, replayed with the seed rewritten in device memory, gives the

@@ -47,7 +47,7 @@ def test_meta_kernels_shapes_and_dtypes(op):
     assert op.cheirality(pts, torch.empty((4, 12), **f64), 50.0).shape == (4, n)
     assert op.triangulate(pts, torch.empty((12,), **f64), torch.empty((3, 4), **f64)).shape == (n, 3)
     with pytest.raises(RuntimeError, match=r"S must be \[batch, h, 8\]"):
-        op.fit_eight_point(corr, torch.empty((B, h, 7), dtype=torch.int32, device="meta"))
+        op.fit_eight_point(corr, torch.empty((B, h), dtype=torch.int32, device="meta"))
 
 
 def test_ops_trace_under_fake_tensor_mode(op):
