@@ -419,6 +419,97 @@ __global__ __launch_bounds__(kSelectBlock) void select_block_kernel(
                                        aggregation, result + b, scratch, &winner);
 }
 
+// Selection of a small pass (h_count <= 32768) spread over up to 32 blocks of ONE launch: a single block walking
+// every hypothesis is latency-bound (14 us at 10 000, 35 us at 30 000 hypotheses).  Each block folds its slice and
+// publishes a partial record write-through (sc1); an agent-scope arrival counter (cdna_hip_programming.md Guideline 16,
+// counter form; 32 arrivals, so a single counter does not serialise anything) tells the block that finishes last to
+// take one acquire and fold the partial records into the result record.  Counter and records live in the kPointsPad
+// bytes behind the fp32 points of the scoring workspace (only ever READ by the scoring loop's over-prefetch); the fit
+// launch of the same pass zeroes the counter (sfm_score_ws.h).
+struct PartialSelect {
+    uint64_t key;
+    int64_t best, first_flagged;
+    int32_t n_flagged, pad;
+};
+static_assert(sfmws::kFusedPartialOffset + sfmws::kFusedShards * (int)sizeof(PartialSelect) <= sfmws::kPointsPad,
+              "selection state fits the pad");
+
+__global__ __launch_bounds__(256) void select_sharded_kernel(
+    const int32_t* __restrict__ cnt, const double* __restrict__ s1, const double* __restrict__ s2,
+    const int32_t* __restrict__ flags, int64_t h_count, int64_t h_offset, double min_extra, int aggregation,
+    unsigned char* __restrict__ state, sfm_select_result* __restrict__ result) {
+    __shared__ sfmsel::SelectScratch<256> scratch;
+    __shared__ int last_block;
+    unsigned* counter = reinterpret_cast<unsigned*>(state);
+    PartialSelect* partial = reinterpret_cast<PartialSelect*>(state + sfmws::kFusedPartialOffset);
+    uint64_t key = kNoModelKey;
+    int64_t best = INT64_MAX, first_flag = INT64_MAX;
+    int n_flag = 0;
+    // this block's slice: hypotheses blockIdx.x * 256 + t, + gridDim.x * 256, ... — all loads of a thread in flight together
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    uint64_t k[4];
+    bool flagged[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t h = (int64_t)blockIdx.x * 256 + threadIdx.x + u * stride;
+        flagged[u] = false;
+        k[u] = h < h_count ? hypothesis_key(cnt, s1, s2, flags, h, min_extra, aggregation, flagged[u]) : kNoModelKey;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t h = (int64_t)blockIdx.x * 256 + threadIdx.x + u * stride;
+        if (k[u] < key) {  // increasing h: strict < keeps the earliest
+            key = k[u];
+            best = h;
+        }
+        if (flagged[u]) {
+            first_flag = h < first_flag ? h : first_flag;
+            ++n_flag;
+        }
+    }
+    sfmsel::block_combine<256>(key, best, first_flag, n_flag, scratch);
+    if (threadIdx.x == 0) {
+        PartialSelect* out = partial + blockIdx.x;
+        __hip_atomic_store(&out->key, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&out->best, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&out->first_flagged, first_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&out->n_flagged, (int32_t)n_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned arrived = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool last = arrived == gridDim.x - 1;
+        if (last) {  // acquire: the other blocks' records may sit stale in this CU's L1
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        last_block = last ? 1 : 0;
+    }
+    __syncthreads();
+    if (!last_block) return;
+    key = kNoModelKey;
+    best = INT64_MAX;
+    first_flag = INT64_MAX;
+    n_flag = 0;
+    if (threadIdx.x < gridDim.x) {
+        const PartialSelect p = partial[threadIdx.x];
+        key = p.key;
+        best = p.best;
+        first_flag = p.first_flagged;
+        n_flag = p.n_flagged;
+    }
+    sfmsel::block_combine<256>(key, best, first_flag, n_flag, scratch);
+    if (threadIdx.x == 0) {
+        const bool found = key != kNoModelKey && best != INT64_MAX;
+        sfm_select_result r;
+        r.key = found ? key : kNoModelKey;
+        r.best_h = found ? best + h_offset : -1;
+        r.best_err = found ? __longlong_as_double((long long)key) : INFINITY;
+        r.first_flagged = first_flag != INT64_MAX ? first_flag + h_offset : INT64_MAX;
+        r.n_flagged = n_flag;
+        r.best_cnt = found ? cnt[best] : 0;
+        *result = r;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Inlier mask of the winner (ransac.py:70-76): 1 = surviving non-sample point, 2 = sample point.
 // ------------------------------------------------------------------------------------------------
@@ -713,10 +804,29 @@ int sfm_ransac_pass_small(uint64_t seed, const uint64_t* seed_dev, int use_philo
                        SmallPrep{static_cast<unsigned char*>(workspace), sfmhost::small_pass_a_scale(thr), prep_blocks});
     const int rc = check_launch("fit_eight_point_kernel (fused small pass)");
     if (rc != SFM_OK) return rc;
-    // launch 2: scoring; its last block selects the model and writes the mask
-    return sfmhost::launch_small_score(sfmhost::SmallPass{corr, n, E, S, flags, h_count, thr, min_extra, aggregation,
-                                                          h_offset, cnt, s1, s2, result, mask,
-                                                          static_cast<unsigned char*>(workspace), st});
+    // launch 2: SED scoring
+    const int rc2 = sfmhost::launch_small_score(sfmhost::SmallPass{corr, n, E, S, flags, h_count, thr, min_extra, aggregation,
+                                                                   h_offset, cnt, s1, s2, result, mask,
+                                                                   static_cast<unsigned char*>(workspace), st});
+    if (rc2 != SFM_OK) return rc2;
+    // launch 3: selection — one 1024-thread block up to 4096 hypotheses (6.7 us at 2 000), beyond that up to 32 blocks
+    // x 256 threads x 4 hypotheses folded by the block that arrives last (~8 us flat; the single block needs 14 us at
+    // 10 000 and 35 us at 30 000 hypotheses)
+    if (h_count <= 4096) {
+        hipLaunchKernelGGL(select_block_kernel, dim3(1), dim3(kSelectBlock), 0, st, (const int32_t*)cnt, (const double*)s1,
+                           (const double*)s2, (const int32_t*)flags, h_count, h_offset, min_extra, aggregation, result);
+    } else {
+        const unsigned select_blocks = (unsigned)((h_count + 1023) / 1024);
+        unsigned char* state = static_cast<unsigned char*>(workspace) + sfmws::ws_points_offset(1) + 16 * n;
+        hipLaunchKernelGGL(select_sharded_kernel, dim3(select_blocks), dim3(256), 0, st, (const int32_t*)cnt,
+                           (const double*)s1, (const double*)s2, (const int32_t*)flags, h_count, h_offset, min_extra,
+                           aggregation, state, result);
+    }
+    if (mask == nullptr) return check_launch("select_sharded_kernel");
+    // launch 4: the winner's inlier mask
+    hipLaunchKernelGGL(inlier_mask_kernel, dim3(grid_stride(n, 256, 1024), 1u), dim3(256), 0, st, (const Corr*)corr, n,
+                       (const double*)E, (const int32_t*)S, h_count, (const sfm_select_result*)result, thr, mask);
+    return check_launch("inlier_mask_kernel (fused small pass)");
 }
 
 int sfm_fit_trace_doubles(void) { return kTraceDoubles; }

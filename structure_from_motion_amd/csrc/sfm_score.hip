@@ -44,7 +44,6 @@
 #include "sfm_common.h"
 #include "sfm_math.h"
 #include "sfm_score_ws.h"
-#include "sfm_select.h"
 
 namespace {
 
@@ -435,28 +434,15 @@ __global__ __launch_bounds__(256) void score_class_scatter_kernel(const int32_t*
 // ------------------------------------------------------------------------------------------------
 // Filtered kernel.
 // ------------------------------------------------------------------------------------------------
-// What the last block of a fused small pass needs to select the model and mark the winner's inliers.
-struct FusedTail {
-    const int32_t* flags;
-    double min_extra;
-    int aggregation;
-    int64_t h_offset;
-    sfm_select_result* result;
-    uint8_t* mask;  // may be NULL
-    int prep_blocks;
-};
-
-// FUSED (small problems, one pair): the four waves of a block share the block's HPW hypotheses and take a quarter of
-// the points each (a hypothesis that fits the scene then spreads its tier-2 work over four waves, and a launch of few
-// hypotheses still fills the chip); per-wave totals are combined through LDS in wave order.  The block that finishes
-// last — an agent-scope ticket, cdna_hip_programming.md Guideline 16 in its counter form — then runs the model
-// selection and writes the winner's inlier mask, so the pass needs no further launch.
+// FUSED (the scoring launch of sfm_ransac_pass_small: small problems, one pair): the workspace was prepared by spare
+// blocks of the fit launch, which leave one partial maximum per block of points instead of the data-set maxima
+// (sfm_score_ws.h); everything else is the kernel as usual.
 template <int HPW, bool ONE_SIDED, bool FUSED = false>
 __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
     const Corr* __restrict__ corr, const unsigned char* __restrict__ ws, int n,
     const double* __restrict__ E, const int32_t* __restrict__ S, int h_count, double thr, double a_scale,
     const int32_t* __restrict__ order, int32_t* __restrict__ cnt, double* __restrict__ s1,
-    double* __restrict__ s2, int batch, int blocks_per_pair, FusedTail tail_args) {
+    double* __restrict__ s2, int batch, int blocks_per_pair, int prep_blocks) {
     __shared__ __attribute__((aligned(1024))) int32_t ring[256 / kWave][HPW][kRing];  // each ring = one aligned KiB
     const int lane = threadIdx.x & (kWave - 1);
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
@@ -474,10 +460,9 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
         pair = blockIdx.y;
         block_of_pair = blockIdx.x;
     }
-    // FUSED: all four waves of the block own the same hypotheses (and split the points)
-    const int wave = FUSED ? block_of_pair : block_of_pair * (256 / kWave) + wave_in_block;
+    const int wave = block_of_pair * (256 / kWave) + wave_in_block;
     const int h0 = wave * HPW;  // first of this wave's HPW slots in the processing order
-    if (h0 >= h_count) return;  // block-uniform when FUSED
+    if (h0 >= h_count) return;
     const int64_t b = pair;
     // slot -> hypothesis index (longest-first order from the pre-pass, or the identity)
     // With an order, the list (heaviest first) is dealt column-major over the waves: wave w takes entries
@@ -505,7 +490,7 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
     if (FUSED) {  // the fit launch left one partial maximum per prepared block of points (sfm_score_ws.h)
         const uint32_t* partial = reinterpret_cast<const uint32_t*>(ws + ws_buckets_offset(n, 1));
         uint4 m = make_uint4(0u, 0u, 0u, 0u);
-        if (lane < tail_args.prep_blocks) m = reinterpret_cast<const uint4*>(partial)[lane];
+        if (lane < prep_blocks) m = reinterpret_cast<const uint4*>(partial)[lane];
 #pragma unroll
         for (int off = 8; off > 0; off >>= 1) {  // prep_blocks <= 16: lanes 0..15
             m.x = max(m.x, (uint32_t)__shfl_xor((int)m.x, off, 64));
@@ -647,14 +632,11 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
 
     const int full_chunks = n / kWave;
     const int pairs = full_chunks / 2;
-    // FUSED: this wave's quarter of the chunk pairs; the ragged end of the point set goes to the last wave
-    const int pr_begin = FUSED ? pairs * wave_in_block / 4 : 0;
-    const int pr_end = FUSED ? pairs * (wave_in_block + 1) / 4 : pairs;
-    if (pr_end > pr_begin) {
-        const float4* __restrict__ next = pts32 + pr_begin * 2 * kWave + lane;  // per-lane cursor: one 64-bit add per step, no index clamping
+    if (pairs > 0) {
+        const float4* __restrict__ next = pts32 + lane;  // per-lane cursor: one 64-bit add per step, no index clamping
         float4 p0 = next[0], p1 = next[kWave];
-        int i0 = pr_begin * 2 * kWave + lane;
-        for (int pr = pr_begin; pr < pr_end; ++pr) {
+        int i0 = lane;
+        for (int pr = 0; pr < pairs; ++pr) {
             // prefetch the next pair; the last step reads up to 3 KiB past the pair's points, inside the workspace
             // (the next pair's points, or the kPointsPad bytes behind the last pair's) and never uses them
             next += 2 * kWave;
@@ -666,11 +648,9 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
             i0 += 2 * kWave;
         }
     }
-    if (!FUSED || wave_in_block == 3) {
-        for (int chunk = pairs * 2; chunk * kWave < n; ++chunk) {  // at most two iterations
-            const int i = chunk * kWave + lane;
-            process_tail(pts32[min(i, n - 1)], i, i < n);
-        }
+    for (int chunk = pairs * 2; chunk * kWave < n; ++chunk) {  // at most two iterations
+        const int i = chunk * kWave + lane;
+        process_tail(pts32[min(i, n - 1)], i, i < n);
     }
 #pragma unroll
     for (int k = 0; k < HPW; ++k) {
@@ -678,75 +658,15 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
         if (left > 0) drain(k, left);
     }
 
-    if constexpr (!FUSED) {
 #pragma unroll
-        for (int k = 0; k < HPW; ++k) {
-            const int h = hyp[k];
-            if (slot_valid[k]) {  // wave-uniform: this slot exists
-                double e[9];
+    for (int k = 0; k < HPW; ++k) {
+        const int h = hyp[k];
+        if (slot_valid[k]) {  // wave-uniform: this slot exists
+            double e[9];
 #pragma unroll
-                for (int j = 0; j < 9; ++j) e[j] = Eb[(int64_t)h * 9 + j];
-                const int64_t o = b * (int64_t)h_count + h;
-                finish_hypothesis(pts, Sb + (int64_t)h * 8, e, thr, lane, c[k], a1[k], a2[k], cnt + o, s1 + o, s2 + o);
-            }
-        }
-    } else {
-        // combine the four waves' totals (fixed order: wave 0..3), then wave k finishes hypothesis k of the block
-        __shared__ int part_c[256 / kWave][HPW];
-        __shared__ double part_a1[256 / kWave][HPW], part_a2[256 / kWave][HPW];
-#pragma unroll
-        for (int k = 0; k < HPW; ++k) {
-            const int ck = sfm::wave_sum(c[k]);
-            const double a1k = sfm::wave_sum(a1[k]);
-            const double a2k = sfm::wave_sum(a2[k]);
-            if (lane == 0) {
-                part_c[wave_in_block][k] = ck;
-                part_a1[wave_in_block][k] = a1k;
-                part_a2[wave_in_block][k] = a2k;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < HPW; ++k) {
-            if (k == wave_in_block && slot_valid[k]) {  // wave-uniform
-                const int h = hyp[k];
-                double e[9];
-#pragma unroll
-                for (int j = 0; j < 9; ++j) e[j] = Eb[(int64_t)h * 9 + j];
-                const bool first = lane == 0;
-                const int ct = first ? ((part_c[0][k] + part_c[1][k]) + part_c[2][k]) + part_c[3][k] : 0;
-                const double a1t = first ? ((part_a1[0][k] + part_a1[1][k]) + part_a1[2][k]) + part_a1[3][k] : 0.0;
-                const double a2t = first ? ((part_a2[0][k] + part_a2[1][k]) + part_a2[2][k]) + part_a2[3][k] : 0.0;
-                finish_hypothesis(pts, Sb + (int64_t)h * 8, e, thr, lane, ct, a1t, a2t, cnt + h, s1 + h, s2 + h);
-            }
-        }
-        // ---- arrival ticket: the block that finishes last selects the model and marks its inliers ----
-        // Publish (Guideline 16, counter form): every storing wave drains its stores, the block meets, ONE lane
-        // releases at agent scope (L2 write-back: the reader may sit on another XCD), drains again, then counts.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        __shared__ int last_block;
-        if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            unsigned* ticket = reinterpret_cast<unsigned*>(const_cast<unsigned char*>(ws) + ws_buckets_offset(n, 1)) + kTicketWord;
-            const unsigned arrived = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const bool last = arrived == gridDim.x - 1;
-            if (last) {  // acquire: drop this CU's cached copies of the other blocks' cnt / s1 / s2 lines
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            last_block = last ? 1 : 0;
-        }
-        __syncthreads();
-        if (last_block) {
-            __shared__ sfmsel::SelectScratch<256> scratch;
-            __shared__ int64_t winner;
-            const int64_t best = sfmsel::block_select<256>(cnt, s1, s2, tail_args.flags, h_count, tail_args.h_offset,
-                                                           tail_args.min_extra, tail_args.aggregation, tail_args.result,
-                                                           scratch, &winner);
-            if (tail_args.mask != nullptr)
-                sfmsel::write_inlier_mask(pts, n, E, S, h_count, best, thr, tail_args.mask, threadIdx.x, 256);
+            for (int j = 0; j < 9; ++j) e[j] = Eb[(int64_t)h * 9 + j];
+            const int64_t o = b * (int64_t)h_count + h;
+            finish_hypothesis(pts, Sb + (int64_t)h * 8, e, thr, lane, c[k], a1[k], a2[k], cnt + o, s1 + o, s2 + o);
         }
     }
 }
@@ -807,10 +727,10 @@ int launch_filtered(const FilteredLaunch& a) {
     if (g_event_before) (void)hipEventRecord(g_event_before, a.st);
     if (a.one_sided)
         hipLaunchKernelGGL((score_sed_filtered_kernel<HPW, true>), flat, dim3(256), 0, a.st, a.corr, a.ws, a.n, a.E, a.S,
-                           a.h_count, a.thr, a.a_scale, order_arg, a.cnt, a.s1, a.s2, (int)a.batch, blocks_per_pair, FusedTail{});
+                           a.h_count, a.thr, a.a_scale, order_arg, a.cnt, a.s1, a.s2, (int)a.batch, blocks_per_pair, 0);
     else
         hipLaunchKernelGGL((score_sed_filtered_kernel<HPW, false>), flat, dim3(256), 0, a.st, a.corr, a.ws, a.n, a.E, a.S,
-                           a.h_count, a.thr, a.a_scale, order_arg, a.cnt, a.s1, a.s2, (int)a.batch, blocks_per_pair, FusedTail{});
+                           a.h_count, a.thr, a.a_scale, order_arg, a.cnt, a.s1, a.s2, (int)a.batch, blocks_per_pair, 0);
     if (g_event_after) (void)hipEventRecord(g_event_after, a.st);
     return check_launch("score_sed_filtered_kernel");
 }
@@ -822,20 +742,20 @@ namespace sfmhost {
 double small_pass_a_scale(double thr) { return one_sided_scale(thr); }
 
 int launch_small_score(const SmallPass& p) {
-    // hypotheses per block: 4 amortise the point loads best; fewer when the launch would leave the chip short of waves
-    // (a block is four waves either way: they split the points)
+    // hypotheses per wave as in sfm_score_sed: 4 amortise the point loads best, fewer when the launch would leave
+    // the chip short of waves
     int hpw = kHypPerWave;
-    while (hpw > 1 && 4 * ((p.h_count + hpw - 1) / hpw) < 5120) hpw /= 2;
-    const int64_t blocks = (p.h_count + hpw - 1) / hpw;
+    while (hpw > 1 && (p.h_count + hpw - 1) / hpw < 5120) hpw /= 2;
+    const int64_t waves = (p.h_count + hpw - 1) / hpw;
+    const int64_t blocks = (waves + 256 / kWave - 1) / (256 / kWave);
     SFM_REQUIRE_GRID("sfm_ransac_pass_small", blocks, 1, 256);
-    const FusedTail tail{p.flags, p.min_extra, p.aggregation, p.h_offset, p.result, p.mask,
-                         (int)((p.n + kPrepPoints - 1) / kPrepPoints)};
+    const int prep_blocks = (int)((p.n + kPrepPoints - 1) / kPrepPoints);
     const dim3 grid((unsigned)blocks);
     if (g_event_before) (void)hipEventRecord(g_event_before, p.stream);
 #define SFM_LAUNCH_FUSED(H)                                                                                          \
     hipLaunchKernelGGL((score_sed_filtered_kernel<H, true, true>), grid, dim3(256), 0, p.stream, (const Corr*)p.corr, \
                        p.workspace, (int)p.n, p.E, p.S, (int)p.h_count, p.thr, one_sided_scale(p.thr),               \
-                       (const int32_t*)nullptr, p.cnt, p.s1, p.s2, 1, 0, tail)
+                       (const int32_t*)nullptr, p.cnt, p.s1, p.s2, 1, 0, prep_blocks)
     switch (hpw) {
         case 1: SFM_LAUNCH_FUSED(1); break;
         case 2: SFM_LAUNCH_FUSED(2); break;

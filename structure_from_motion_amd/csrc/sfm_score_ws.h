@@ -25,8 +25,11 @@ constexpr int64_t kPointsPad = 4096;         // bytes after the fp32 points: the
 constexpr int kPrepPoints = 512;             // 64 lanes x 8 points, all loads of a lane in flight together
 constexpr int kSmallMaxPoints = 8192;
 constexpr int kMaxPrepBlocks = kSmallMaxPoints / kPrepPoints;  // 16 partial maxima x 4 words = buckets[0, 64)
-constexpr int kTicketWord = 4 * kMaxPrepBlocks;                // buckets[64]: blocks that have finished scoring
-static_assert(kTicketWord < kBuckets, "partial maxima and ticket live in the class-counter words");
+static_assert(4 * kMaxPrepBlocks <= kBuckets, "the partial maxima live in the class-counter words");
+// state of a small pass's sharded selection (select_sharded_kernel, sfm_kernels.hip) in the kPointsPad bytes behind
+// the fp32 points: an arrival counter on a line of its own, then one 32-byte partial record per selecting block
+constexpr int kFusedShards = 32;             // selecting blocks: 32 x 256 threads x 4 hypotheses = 32768
+constexpr int kFusedPartialOffset = 64;      // bytes: partial records behind the counter's line
 
 __host__ __device__ inline int64_t ws_points_offset(int64_t batch) { return 16 * batch; }
 __host__ __device__ inline int64_t ws_buckets_offset(int64_t n, int64_t batch) {
@@ -46,7 +49,7 @@ __device__ __forceinline__ float4 to_filter_point(const Corr& p, double a_scale)
 }
 
 // One 64-lane block of a fused small pass prepares points [block * 512, ...): fp32 copies and this block's partial
-// maxima; block 0 also zeroes the arrival ticket of the scoring launch that follows (a kernel boundary orders them).
+// maxima; block 0 also zeroes the arrival counter of the pass's selection launch (kernel boundaries order them).
 // NaN coordinates: fmaxf ignores them; such points fail every filter comparison and are decided by the exact tier.
 __device__ __forceinline__ void prepare_small_block(const Corr* __restrict__ pts, int n, double a_scale,
                                                     unsigned char* __restrict__ ws, int block) {
@@ -83,8 +86,8 @@ __device__ __forceinline__ void prepare_small_block(const Corr* __restrict__ pts
         partial[1] = __float_as_uint(m1);
         partial[2] = __float_as_uint(m2);
         partial[3] = __float_as_uint(m3);
-        if (block == 0) buckets[kTicketWord] = 0;
     }
+    if (block == 0 && lane == 0) *reinterpret_cast<unsigned*>(ws + ws_points_offset(1) + 16 * (int64_t)n) = 0u;
 }
 
 }  // namespace sfmws

@@ -37,6 +37,33 @@ struct SelectScratch {
     int flags[THREADS / kWave];
 };
 
+// Block-wide fold of per-thread candidates (key, best index, first flagged index, flag count) with the rule of
+// ransac.py:83-86 (lowest key, then lowest index); on return thread 0 holds the block's result.
+template <int THREADS>
+__device__ __forceinline__ void block_combine(uint64_t& key, int64_t& best, int64_t& first_flag, int& n_flag,
+                                              SelectScratch<THREADS>& sh) {
+    auto combine = [&](uint64_t ok, int64_t ob, int64_t of, int on) {
+        if (ok < key || (ok == key && ob < best)) {
+            key = ok;
+            best = ob;
+        }
+        first_flag = of < first_flag ? of : first_flag;
+        n_flag += on;
+    };
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        combine(__shfl_xor(key, off, 64), __shfl_xor(best, off, 64), __shfl_xor(first_flag, off, 64),
+                __shfl_xor(n_flag, off, 64));
+    const int wave = threadIdx.x / kWave;
+    __syncthreads();  // the scratch may still be read from a previous fold
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        sh.key[wave] = key; sh.best[wave] = best; sh.first[wave] = first_flag; sh.flags[wave] = n_flag;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int w = 1; w < THREADS / kWave; ++w) combine(sh.key[w], sh.best[w], sh.first[w], sh.flags[w]);
+}
+
 // The whole selection over h_count hypotheses by ONE block of THREADS threads: lexicographic minimum of (error bits,
 // index) — lowest aggregated error among gated hypotheses, earliest index on ties — plus the flag statistics.
 // Thread 0 writes the record.  Returns (to every thread) the winner's LOCAL index, or -1.
@@ -108,6 +135,7 @@ __device__ __forceinline__ int64_t block_select(const int32_t* __restrict__ cnt,
 
 // mask[i] = 2 for the 8 sample points of hypothesis h, 1 for the other points with sed <= thr, 0 otherwise; all zero
 // for h outside [0, h_count).  Points i = first, first + stride, ... (a block- or grid-stride walk).
+template <int UNROLL = 1>
 __device__ __forceinline__ void write_inlier_mask(const Corr* __restrict__ pts, int64_t n, const double* __restrict__ E,
                                                   const int32_t* __restrict__ S, int64_t h_count, int64_t h, double thr,
                                                   uint8_t* __restrict__ out, int64_t first, int64_t stride) {
@@ -121,13 +149,25 @@ __device__ __forceinline__ void write_inlier_mask(const Corr* __restrict__ pts, 
     for (int k = 0; k < 9; ++k) e[k] = E[h * 9 + k];
 #pragma unroll
     for (int k = 0; k < 8; ++k) smp[k] = S[h * 8 + k];
-    for (int64_t i = first; i < n; i += stride) {
-        const Corr p = pts[i];
-        const double sed = sfm::sed_value(e, p.xa, p.ya, p.xb, p.yb);
-        bool in_sample = false;
+    // UNROLL points per trip with their loads issued together (a single block walking many points is load-latency bound)
+    for (int64_t i0 = first; i0 < n; i0 += stride * UNROLL) {
+        Corr p[UNROLL];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) in_sample |= (smp[k] == (int32_t)i);
-        out[i] = in_sample ? 2 : ((sed <= thr) ? 1 : 0);
+        for (int u = 0; u < UNROLL; ++u) {
+            const int64_t i = i0 + u * stride;
+            p[u] = pts[i < n ? i : n - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int64_t i = i0 + u * stride;
+            if (i < n) {
+                const double sed = sfm::sed_value(e, p[u].xa, p[u].ya, p[u].xb, p[u].yb);
+                bool in_sample = false;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) in_sample |= (smp[k] == (int32_t)i);
+                out[i] = in_sample ? 2 : ((sed <= thr) ? 1 : 0);
+            }
+        }
     }
 }
 

@@ -228,7 +228,7 @@ SMALL_PASS_MAX_POINTS, SMALL_PASS_MAX_HYPOTHESES = 8192, 32768
 
 
 def small_pass_eligible(batch: int, n: int, h: int) -> bool:
-    """Whether a pass can run as the two-launch fused small pass (``sfm_ransac_pass_small``): one pair, at most 8192
+    """Whether a pass can run as the lean small pass (``sfm_ransac_pass_small``): one pair, at most 8192
     correspondences and 32768 hypotheses, the default two-tier scoring kernel.  ``SFM_SMALL_PASS=0`` keeps the
     separate calls (for A/B comparisons)."""
     return (batch == 1 and 8 <= n <= SMALL_PASS_MAX_POINTS and 1 <= h <= SMALL_PASS_MAX_HYPOTHESES
@@ -238,7 +238,7 @@ def small_pass_eligible(batch: int, n: int, h: int) -> bool:
 
 def ransac_pass_small(corr, S, E, flags, cnt, s1, s2, result, mask, workspace, thr: float, min_extra: float,
                       aggregation: int, h_offset: int = 0, philox=None) -> None:
-    """One whole pass of a small problem in two launches (fit + workspace preparation, scoring + selection + mask).
+    """One whole pass of a small problem with lean launches (fit + workspace preparation, scoring, sharded selection, mask).
     ``philox=(seed, h_begin)``: samples drawn in the kernel (``seed`` an int or an int64 device tensor), else the
     table already in ``S``.  Same outputs as the separate calls."""
     if philox is None:
@@ -431,7 +431,7 @@ class RansacWorkspace:
         ``philox=(seed, h_begin, seed_stride)``, for Philox samples drawn inside the fit kernel (which also fills
         ``self.S``); ``seed`` may be an int64 device tensor (read at kernel run time)."""
         if small_pass_eligible(self.batch, self.n, self.h) and (not with_mask or h_offset == 0):
-            # two launches instead of five (seed_stride only matters for batches)
+            # workspace preparation rides in the fit launch, selection over 32 blocks (seed_stride only matters for batches)
             ransac_pass_small(corr, self.S, self.E, self.flags, self.cnt, self.s1, self.s2, self.result,
                               self.mask if with_mask else None, self.score_ws, thr, min_extra, aggregation, h_offset,
                               None if philox is None else (philox[0], philox[1]))
