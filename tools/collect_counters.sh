@@ -19,7 +19,10 @@ run() {  # name, rocprofv3 options...
     echo "== $name: rocprofv3 $* -- python3 bench.py $ARGS"
     rocprofv3 "$@" --output-format csv -d "$OUT/$name" -o p -- python3 "$REPO/bench.py" $ARGS > "$OUT/$name.log" 2>&1
 }
-run trace --kernel-trace --stats
+# the timing pass runs as long as the default bench (steady clocks: a 7-launch run reads ~10 % slow); counter passes are short
+TRACE_ARGS=${TRACE_ARGS:---steps 200 --warmup 10 --no-cpu-baseline --no-extras}
+echo "== trace: rocprofv3 --kernel-trace --stats -- python3 bench.py $TRACE_ARGS"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o p -- python3 "$REPO/bench.py" $TRACE_ARGS > "$OUT/trace.log" 2>&1
 run fetch --pmc FETCH_SIZE
 run write --pmc WRITE_SIZE
 run sq --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
