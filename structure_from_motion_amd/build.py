@@ -70,7 +70,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH]
+    extra = os.environ.get("SFM_EXTRA_HIPCC_FLAGS", "").split()   # experiment builds (e.g. -DSFM_SCORE_E_IN_VGPR=1)
+    cmd = [hipcc] + FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=CSRC)
