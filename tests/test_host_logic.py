@@ -325,3 +325,37 @@ def test_value_types():
         Transform3D.from_rmat_t(np.eye(3), np.zeros(4))
     with pytest.raises(TypeError):
         T * 3
+
+
+def test_bench_roofline_is_a_valu_issue_bound(monkeypatch, tmp_path):
+    """bench.py's roofline block: bound = valu-issue with frac = priced VALU instructions / (1024 SIMDs x 2.4 GHz x
+    kernel time) <= 1 for the committed counters, both HBM views beside it, and `counters_stale` raised as soon as the
+    record's fingerprint is not the one of the kernel sources in the tree."""
+    import importlib.util
+    import json
+
+    from structure_from_motion_amd import build
+
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rec = json.load(open(os.path.join(REPO, "profiles", "score_traffic.json")))
+    n, h = rec["matches"], rec["hypotheses"]
+    roof = bench.roofline(n, h, kernel_ms=2.4, call_ms=2.5, variant="filtered")
+    assert roof["bound"] == "valu-issue" and 0.3 < roof["frac"] <= 1.0
+    c = rec["counters"]
+    f64 = sum(c[k] for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"))
+    cycles = (c["SQ_INSTS_VALU"] - f64) * 2.0 + f64 * 4.0
+    assert isclose(roof["frac"], cycles / 1024 / 2.4e9 / 2.4e-3, rel_tol=1e-12)
+    assert roof["hbm_algorithmic"]["frac"] > 1.0            # the L2-resident set: reported, labelled "not a bound"
+    assert roof["hbm_physical"]["frac"] < 0.05
+    assert roof["traffic"] == (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+    assert roof["counters_stale"] == (rec["source_sha"] != build.score_source_sha())
+    # a record taken on other sources is flagged, a record for another workload is not used
+    stale = dict(rec, source_sha="0" * 16)
+    path = tmp_path / "score_traffic.json"
+    path.write_text(json.dumps(stale))
+    monkeypatch.setattr(bench, "COUNTERS", str(path))
+    assert bench.roofline(n, h, 2.4, 2.5, "filtered")["counters_stale"] is True
+    other = bench.roofline(n, h + 1, 2.4, 2.5, "filtered")
+    assert other["frac"] is None and other["counters_stale"] is None
