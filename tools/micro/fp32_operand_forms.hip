@@ -15,9 +15,13 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 
+// in-kernel clock of the load: (shader cycles, 100 MHz real-time ticks) of block 0's first lane (guide: DVFS give-back)
+__device__ unsigned long long g_stamp[2];
+
 template <int FORM>
 __global__ __launch_bounds__(256) void k(int iters, float m_in, float c_in, float* out) {
     float r = 0.f;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), w0 = __builtin_amdgcn_s_memrealtime();
     if (FORM <= 3 || FORM >= 5) {
         // chains in v8..v15; m / c pinned per form.  Banks: v8,v12 -> 0; v9,v13 -> 1; v10,v14 -> 2; v11,v15 -> 3.
         asm volatile(
@@ -90,6 +94,16 @@ __global__ __launch_bounds__(256) void k(int iters, float m_in, float c_in, floa
         for (int j = 0; j < 8; ++j) r += f[j];
     }
     if (r == 12345.678f) out[threadIdx.x] = r;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        g_stamp[0] = __builtin_amdgcn_s_memtime() - t0;
+        g_stamp[1] = __builtin_amdgcn_s_memrealtime() - w0;
+    }
+}
+
+double last_clock_ghz() {
+    unsigned long long h[2];
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamp), sizeof(h));
+    return h[1] ? (double)h[0] / (double)h[1] * 0.1 : 0.0;
 }
 
 template <int FORM>
@@ -109,6 +123,10 @@ int main() {
     if (hipMalloc(&out, 1 << 20) != hipSuccess) return 1;
     const int it = 40000;
     for (int w : {8, 5, 2}) {
+        (void)run<0>(256 * w, it, out);
+        printf("%d waves/SIMD: in-kernel clock under the all-VGPR FMA load %.2f GHz", w, last_clock_ghz());
+        (void)run<2>(256 * w, it, out);
+        printf(", under the SGPR-source load %.2f GHz\n", last_clock_ghz());
         const int blocks = 256 * w;
         const double inst = (double)w * 8.0 * it;
         printf("%d waves/SIMD, nominal 2.4 GHz cycles per v_fma_f32: banks all different %.2f | same bank %.2f | sgpr x vgpr + vgpr %.2f | "
