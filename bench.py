@@ -188,7 +188,8 @@ def roofline(n, h, kernel_ms, call_ms, variant):
 def api_timings(device_mod):
     """Wall time of the drop-in call itself — lib.epipolar.epipolar_ransac.estimate_essential_mat_with_ransac as
     reference apps/sfm.py:110-119 calls it (Feature lists in, (E, inlier pairs) out) — at BASELINE configs[0]'s scale
-    (300 x 2000) and configs[1] (5000 x 10000), after one warm-up call each.  Not part of `value`."""
+    (300 x 2000), configs[1] (5000 x 10000) and configs[2] (50000 x 100000), after one warm-up call each.  Not part
+    of `value`."""
     from lib.common.feature import Feature
     from lib.epipolar.eight_point import create_trivial_matches
     from lib.epipolar.epipolar_ransac import estimate_essential_mat_with_ransac
@@ -201,7 +202,8 @@ def api_timings(device_mod):
         for name, n, h, sampler in (("c1_300x2000_pyshuffle", 300, 2000, "pyshuffle"),
                                     ("c2_5000x10000_pyshuffle", 5000, 10000, "pyshuffle"),
                                     ("c2_5000x10000_philox", 5000, 10000, "philox"),
-                                    ("c2_5000x10000_auto", 5000, 10000, None)):
+                                    ("c2_5000x10000_auto", 5000, 10000, None),
+                                    ("c3_50000x100000_auto", 50000, 100000, None)):
             pa, pb, K, *_ = synthetic.two_view_scene(n, seed=6)
             fa = [Feature(x=float(x), y=float(y)) for x, y in pa]
             fb = [Feature(x=float(x), y=float(y)) for x, y in pb]

@@ -1,6 +1,7 @@
 """Glue between the Python call signatures and the device RANSAC engine (host logic only)."""
 from __future__ import annotations
 
+import contextlib
 import copy
 import gc
 import os
@@ -23,6 +24,21 @@ _GET_X, _GET_Y = attrgetter("x"), attrgetter("y")
 # iteration, like the reference's own loop), ~3 ns per draw on the host against microseconds for the whole pass on
 # the GPU.  Every golden vector and the demo (600 matches x 2000 iterations = 1.2e6) stay far below it.
 AUTO_PHILOX_WORK = 10_000_000
+
+
+@contextlib.contextmanager
+def gc_paused():
+    """Pause the cyclic garbage collector for a stretch of bulk object creation (pair tuples, Feature copies): every
+    few hundred new container objects would otherwise start a collection, and the full ones re-scan each live Feature
+    / Match of the caller — at 50 000 matches that is most of a call's time (86 ms of 105 in building the pair list
+    alone).  Nothing created here is cyclic; the collector's previous state is restored on exit."""
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was_enabled:
+            gc.enable()
 
 
 def feature_array(features: Sequence[Feature], out: np.ndarray | None = None) -> np.ndarray:
@@ -51,20 +67,14 @@ def copy_pairs(data, order) -> list:
     """Fresh copies of ``data[i]`` for i in ``order`` — the reference hands back deep copies of the caller's
     features (ransac.py:59 copies the data before shuffling).  Plain ``Feature`` pairs are rebuilt by their
     constructor (same result as ``copy.deepcopy`` for a two-float dataclass, far cheaper); anything else is
-    deep-copied.  The cyclic garbage collector is paused while the copies are made: tens of thousands of new
-    container objects would otherwise trigger full collections that re-scan every live Feature of the caller
-    (measured: 102 ms with the collector running, 19 ms without, for 32 000 pairs out of 50 000)."""
+    deep-copied.  Runs with the cyclic garbage collector paused (``gc_paused``: 102 ms with the collector running,
+    19 ms without, for 32 000 pairs out of 50 000)."""
     picked = [data[i] for i in order]
-    was_enabled = gc.isenabled()
-    gc.disable()
-    try:
+    with gc_paused():
         plain = Feature
         if all(type(p) is tuple and len(p) == 2 and type(p[0]) is plain and type(p[1]) is plain for p in picked):
             return [(plain(a.x, a.y), plain(b.x, b.y)) for a, b in picked]
         return [copy.deepcopy(p) for p in picked]
-    finally:
-        if was_enabled:
-            gc.enable()
 
 
 _warned_auto_philox = False

@@ -10,6 +10,7 @@ import numpy.typing as npt
 from ..common.feature import Feature
 from ..feature_matching.matching import Match
 from ..ransac.ransac import ErrorAggregationMethod, fit_with_ransac
+from . import _engine
 from .eight_point import estimate_essential_mat, to_normalized_image_coords
 from .sed import calculate_symmetric_epipolar_distance
 
@@ -60,17 +61,18 @@ def estimate_essential_mat_with_ransac(
     Raises ``ValueError`` when no hypothesis has enough inliers and ``EightPointCalculationError`` when
     a sampled eight-tuple is degenerate (reference behaviour; ``SFM_DEGENERATE=skip`` ignores such
     hypotheses instead)."""
-    feature_pairs = [(features_a[m.a_index], features_b[m.b_index]) for m in matches]
-    e, inlier_feature_pairs = fit_with_ransac(
-        feature_pairs,
-        model_fit_data_count=8,
-        model_fitter=partial(eight_point_model_fitter, camera_matrix=camera_matrix),
-        inlier_scorer=partial(calculate_sed_inlier_score, camera_matrix=camera_matrix),
-        inlier_threshold=sed_inlier_threshold,
-        min_num_extra_inliers=min_num_extra_inliers,
-        error_aggregation_method=error_aggregation_method,
-        max_iterations=max_iterations,
-    )
+    with _engine.gc_paused():  # bulk creation of pair tuples and inlier copies: see _engine.gc_paused
+        feature_pairs = [(features_a[m.a_index], features_b[m.b_index]) for m in matches]
+        e, inlier_feature_pairs = fit_with_ransac(
+            feature_pairs,
+            model_fit_data_count=8,
+            model_fitter=partial(eight_point_model_fitter, camera_matrix=camera_matrix),
+            inlier_scorer=partial(calculate_sed_inlier_score, camera_matrix=camera_matrix),
+            inlier_threshold=sed_inlier_threshold,
+            min_num_extra_inliers=min_num_extra_inliers,
+            error_aggregation_method=error_aggregation_method,
+            max_iterations=max_iterations,
+        )
     if e is None:
         raise ValueError("Could not estimate Essential Matrix with RANSAC.")
     return e, inlier_feature_pairs
