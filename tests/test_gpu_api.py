@@ -438,3 +438,67 @@ def test_local_optimisation_env_option(monkeypatch):
     assert acc_o >= 1 and len(pairs1) == cnt_o
     assert [lookup[(a.x, a.y)] for a, _ in pairs1] == list(np.nonzero(m_o)[0])
     assert np.max(np.abs(E1 - E_o)) / np.max(np.abs(E_o)) <= 1e-9
+
+
+def test_rccl_accepts_the_record_all_gather():
+    """The one collective of a sharded pass — all_gather_into_tensor of int64 [batch, 5] records — through the "nccl"
+    backend (RCCL) itself, on a single-rank group (one GPU here; the multi-rank logic is covered by the gloo tests):
+    dtype, shapes and the flat views are what RCCL is given at N = 8."""
+    import socket
+
+    import torch.distributed as dist
+
+    from structure_from_motion_amd import distributed
+
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        record = torch.arange(10, dtype=torch.int64, device="cuda").reshape(2, 5)
+        out = torch.empty((1, 2, 5), dtype=torch.int64, device="cuda")
+        dist.all_gather_into_tensor(out.view(-1), record.reshape(-1))
+        torch.cuda.synchronize()
+        assert torch.equal(out[0], record)
+        glob, best_h, single = distributed.fold_records(out)
+        assert glob.shape == (2, 5) and best_h.shape == (2,)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_two_rank_rehearsal(tmp_path):
+    """`bench.py --gpus 2` end to end as the driver launches it (torch.distributed.run, one process per rank), both
+    ranks sharing the one GPU of the box with the collective staged through gloo: the N > 1 path — shard_range
+    partition, 40-byte all-gather, fold, winner re-derivation, max-over-ranks timing — produces one JSON line whose
+    winner equals a single-rank run over the same global hypothesis range."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    common = ["--steps", "3", "--warmup", "1", "--matches", "3000", "--no-cpu-baseline", "--no-extras"]
+    env = dict(os.environ, SFM_DIST_BACKEND="gloo")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(repo, "bench.py"),
+                          "--gpus", "2", "--hypotheses", "4000"] + common, env=env, capture_output=True, text=True,
+                         timeout=600, cwd=repo)
+    assert two.returncode == 0, two.stderr[-2000:]
+    line2 = json.loads(two.stdout.strip().splitlines()[-1])
+    one = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--hypotheses", "8000"] + common,
+                         capture_output=True, text=True, timeout=600, cwd=repo)
+    assert one.returncode == 0, one.stderr[-2000:]
+    line1 = json.loads(one.stdout.strip().splitlines()[-1])
+    assert line2["n_gpus"] == 2 and line2["config"]["global_hypotheses"] == 8000
+    assert line2["config"]["exchange"].startswith("one all_gather")
+    assert line2["result"] == line1["result"]        # same winner, error, inlier count from either partition
+    assert line2["value"] > 0 and line2["roofline"]["bound"] == "valu-issue"
