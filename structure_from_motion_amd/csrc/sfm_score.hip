@@ -54,6 +54,12 @@ using sfmhost::grid_for;
 using sfmhost::grid_stride;
 
 constexpr int kHypPerWave = 4;
+#ifndef SFM_WAVE_STAMPS
+#define SFM_WAVE_STAMPS 0   // diagnostic build (tools/wave_timeline.py): per-wave start / end stamps of the filtered kernel
+#endif
+#if SFM_WAVE_STAMPS
+__device__ unsigned long long g_wave_stamps[2 * 65536];  // read by nothing but sfm_debug_read_wave_stamps
+#endif
 constexpr int kRing = 256;  // entries per (wave, hypothesis) ring; <= 63 left + 128 pushed per step; drained in groups of 64
 
 // ------------------------------------------------------------------------------------------------
@@ -463,6 +469,9 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
     const int wave = block_of_pair * (256 / kWave) + wave_in_block;
     const int h0 = wave * HPW;  // first of this wave's HPW slots in the processing order
     if (h0 >= h_count) return;
+#if SFM_WAVE_STAMPS
+    const unsigned long long stamp_begin = __builtin_amdgcn_s_memrealtime();
+#endif
     const int64_t b = pair;
     // slot -> hypothesis index (longest-first order from the pre-pass, or the identity)
     // With an order, the list (heaviest first) is dealt column-major over the waves: wave w takes entries
@@ -669,6 +678,12 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
             finish_hypothesis(pts, Sb + (int64_t)h * 8, e, thr, lane, c[k], a1[k], a2[k], cnt + o, s1 + o, s2 + o);
         }
     }
+#if SFM_WAVE_STAMPS
+    if (lane == 0 && wave < 65536) {
+        g_wave_stamps[2 * wave] = stamp_begin;
+        g_wave_stamps[2 * wave + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 // Optional HIP events recorded on the launch stream immediately before / after the dominant kernel of the next
@@ -767,6 +782,12 @@ int launch_small_score(const SmallPass& p) {
 }
 
 }  // namespace sfmhost
+
+#if SFM_WAVE_STAMPS
+extern "C" int sfm_debug_read_wave_stamps(unsigned long long* out, int64_t waves) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_stamps), 16 * (size_t)waves) == hipSuccess ? 0 : -2;
+}
+#endif
 
 extern "C" {
 
