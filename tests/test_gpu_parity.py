@@ -555,6 +555,43 @@ def test_virtual_shards_equal_single_run(dev):
     assert all(e.outcome().best_h == ref["best"] for e in tiny)
 
 
+def test_fold_kernel_equals_host_fold(dev):
+    """sfm_fold_select_records (device kernel) == sfm_fold_select_records_host on random gathered records with ties
+    across ranks, no-model ranks and flag statistics: the CPU process-group tests exercise the same routine the GPUs run."""
+    from structure_from_motion_amd import distributed
+    from structure_from_motion_amd._native import INT64_MAX
+
+    rng = np.random.default_rng(17)
+    world, batch = 7, 96
+    gathered = np.zeros((world, batch, 5), dtype=np.int64)
+    errs = rng.choice(np.array([1e-9, 2e-9, 3.5e-7, 0.0, 1.0]), size=(world, batch))   # few distinct values: many ties
+    none = rng.random((world, batch)) < 0.3
+    for r in range(world):
+        for b in range(batch):
+            if none[r, b]:
+                key, best, err, cnt = INT64_MAX, -1, np.inf, 0
+            else:
+                err = errs[r, b]
+                key, best, cnt = int(np.float64(err).view(np.int64)), int(rng.integers(0, 10**7)) + r * 10**7, int(rng.integers(10, 500))
+            flagged = int(rng.integers(0, 3))
+            first = int(rng.integers(0, 10**7)) + r * 10**7 if flagged else INT64_MAX
+            words = np.frombuffer(np.array([key], dtype=np.uint64).tobytes() + np.array([best], dtype=np.int64).tobytes()
+                                  + np.array([err], dtype=np.float64).tobytes() + np.array([first], dtype=np.int64).tobytes()
+                                  + np.array([flagged, cnt], dtype=np.int32).tobytes(), dtype=np.int64)
+            gathered[r, b] = words
+    host = distributed.fold_records(torch.from_numpy(gathered.copy()))
+    device_out = distributed.fold_records(dev.to_device(gathered, torch.int64))
+    for a, b in zip(host, device_out):
+        np.testing.assert_array_equal(a.numpy(), b.cpu().numpy())
+    # and the rule itself, record by record
+    recs = distributed.read_records(host[0])
+    for b, rec in enumerate(recs):
+        cand = [(gathered[r, b, 0], gathered[r, b, 1]) for r in range(world) if gathered[r, b, 1] >= 0]
+        want = min(cand) if cand else (INT64_MAX, -1)
+        assert (rec.key, rec.best_h) == (want[0], want[1])
+        assert rec.n_flagged == int(sum(gathered[r, b, 4] & 0xFFFFFFFF for r in range(world)))
+
+
 def test_virtual_shards_degenerate_sample_reaches_every_rank(dev):
     """A degenerate sample on ONE rank (eight_point.py:415-421) must abort the call on EVERY rank, as it does
     in the reference (ransac.py:65) and in the single-GPU drop-in path; SFM_DEGENERATE=skip drops the hypothesis
