@@ -124,16 +124,17 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
                   int64_t batch, double thr, int32_t* cnt, double* s1, double* s2, void* workspace,
                   int64_t workspace_bytes, void* stream);
 
-/* One whole RANSAC pass of a SMALL problem (one image pair, 8 <= n <= 8192, h_count <= 32768) with leaner launches
- * than sfm_sample_fit_philox / sfm_fit_eight_point -> sfm_score_sed -> sfm_select_best -> sfm_inlier_mask, and the same
+/* One whole RANSAC pass of a SMALL problem (one image pair, 8 <= n <= 8192, h_count <= 32768) in THREE lean launches
+ * instead of the five of sfm_sample_fit_philox / sfm_fit_eight_point -> sfm_score_sed -> sfm_select_best -> sfm_inlier_mask, and the same
  * outputs (S, E, flags, cnt, s1, s2, result, mask) bit for bit:
  *   launch 1  the eight-point fits — use_philox != 0: samples drawn in the kernel from (seed or *seed_dev, h_begin + h)
  *             and stored in S; use_philox == 0: the caller's table in S — and, in spare blocks of the same launch, the
  *             preparation of the scoring workspace (no launch of its own);
  *   launch 2  SED scoring;
  *   launch 3  the selection of ransac.py:75-86 spread over up to 32 blocks, folded by the block that arrives last
- *             (a single block walking all hypotheses is latency-bound: 14 us at 10 000 hypotheses);
- *   launch 4  the winner's inlier mask (skipped when mask is NULL).
+ *             (a single block walking all hypotheses is latency-bound: 14 us at 10 000 hypotheses); when a mask is
+ *             wanted the same launch carries ceil(n / 256) more blocks that wait for the published record and write
+ *             the winner's inlier mask.
  * A small pass is a chain of dependent, latency-bound launches: what shortens it is fewer and leaner ones.
  * h_offset as in sfm_select_best; mask refers to local indices, i.e. needs h_offset == 0 to be meaningful.
  * workspace: sfm_score_workspace_bytes(n, h_count, 1) bytes, 16-byte aligned. */

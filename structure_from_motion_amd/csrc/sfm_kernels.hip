@@ -434,19 +434,65 @@ struct PartialSelect {
 static_assert(sfmws::kFusedPartialOffset + sfmws::kFusedShards * (int)sizeof(PartialSelect) <= sfmws::kPointsPad,
               "selection state fits the pad");
 
+// With a mask requested the same launch carries ceil(n / 256) further blocks behind the selecting ones: each loads its
+// 256 points, waits (one lane, relaxed agent-scope polls with s_sleep, bounded) for the "record published" flag the last
+// selecting block raises, and writes its slice of the winner's inlier mask — the mask costs no launch of its own.  All
+// blocks of the launch (at most 64) are resident together on any MI355X, so the wait cannot deadlock; should the flag
+// not arrive within the bound the slice is filled with 0xFF, a value no mask holds, rather than hanging the GPU.
+constexpr unsigned kSelectDoneWord = 8;   // unsigned index into `state`: counter at [0], flag at [8] (same 64-byte line)
+constexpr int kMaxFlagPolls = 1 << 22;
+
 __global__ __launch_bounds__(256) void select_sharded_kernel(
     const int32_t* __restrict__ cnt, const double* __restrict__ s1, const double* __restrict__ s2,
     const int32_t* __restrict__ flags, int64_t h_count, int64_t h_offset, double min_extra, int aggregation,
-    unsigned char* __restrict__ state, sfm_select_result* __restrict__ result) {
+    unsigned char* __restrict__ state, sfm_select_result* __restrict__ result, int select_blocks,
+    const Corr* __restrict__ corr, int64_t n, const double* __restrict__ E, const int32_t* __restrict__ S, double thr,
+    uint8_t* __restrict__ mask) {
     __shared__ sfmsel::SelectScratch<256> scratch;
     __shared__ int last_block;
     unsigned* counter = reinterpret_cast<unsigned*>(state);
+    unsigned* done = counter + kSelectDoneWord;
     PartialSelect* partial = reinterpret_cast<PartialSelect*>(state + sfmws::kFusedPartialOffset);
+    if ((int)blockIdx.x >= select_blocks) {
+        // ---- mask block: points [256 * m, 256 * m + 256) ----
+        const int64_t i = (int64_t)(blockIdx.x - select_blocks) * 256 + threadIdx.x;
+        const Corr p = corr[i < n ? i : n - 1];   // in flight while waiting
+        if (threadIdx.x == 0) {
+            int polls = 0;
+            while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && polls < kMaxFlagPolls) {
+                __builtin_amdgcn_s_sleep(8);
+                ++polls;
+            }
+            last_block = polls < kMaxFlagPolls ? 1 : 0;   // reused as "record is there"
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (i >= n) return;
+        if (!last_block) {
+            mask[i] = 0xFF;
+            return;
+        }
+        const int64_t h = __hip_atomic_load(&result->best_h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (h < 0 || h >= h_count) {
+            mask[i] = 0;
+            return;
+        }
+        double e[9];
+        bool in_sample = false;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) e[k] = E[h * 9 + k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) in_sample |= (S[h * 8 + k] == (int32_t)i);
+        const double sed = sfm::sed_value(e, p.xa, p.ya, p.xb, p.yb);
+        mask[i] = in_sample ? 2 : ((sed <= thr) ? 1 : 0);
+        return;
+    }
     uint64_t key = kNoModelKey;
     int64_t best = INT64_MAX, first_flag = INT64_MAX;
     int n_flag = 0;
-    // this block's slice: hypotheses blockIdx.x * 256 + t, + gridDim.x * 256, ... — all loads of a thread in flight together
-    const int64_t stride = (int64_t)gridDim.x * 256;
+    // this block's slice: hypotheses blockIdx.x * 256 + t, + select_blocks * 256, ... — all loads of a thread in flight together
+    const int64_t stride = (int64_t)select_blocks * 256;
     uint64_t k[4];
     bool flagged[4];
 #pragma unroll
@@ -476,7 +522,7 @@ __global__ __launch_bounds__(256) void select_sharded_kernel(
         __hip_atomic_store(&out->n_flagged, (int32_t)n_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned arrived = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool last = arrived == gridDim.x - 1;
+        const bool last = arrived == (unsigned)select_blocks - 1;
         if (last) {  // acquire: the other blocks' records may sit stale in this CU's L1
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -489,7 +535,7 @@ __global__ __launch_bounds__(256) void select_sharded_kernel(
     best = INT64_MAX;
     first_flag = INT64_MAX;
     n_flag = 0;
-    if (threadIdx.x < gridDim.x) {
+    if ((int)threadIdx.x < select_blocks) {
         const PartialSelect p = partial[threadIdx.x];
         key = p.key;
         best = p.best;
@@ -499,14 +545,17 @@ __global__ __launch_bounds__(256) void select_sharded_kernel(
     sfmsel::block_combine<256>(key, best, first_flag, n_flag, scratch);
     if (threadIdx.x == 0) {
         const bool found = key != kNoModelKey && best != INT64_MAX;
-        sfm_select_result r;
-        r.key = found ? key : kNoModelKey;
-        r.best_h = found ? best + h_offset : -1;
-        r.best_err = found ? __longlong_as_double((long long)key) : INFINITY;
-        r.first_flagged = first_flag != INT64_MAX ? first_flag + h_offset : INT64_MAX;
-        r.n_flagged = n_flag;
-        r.best_cnt = found ? cnt[best] : 0;
-        *result = r;
+        // the record is read by the waiting mask blocks of this launch: write-through stores, drained, then the flag
+        __hip_atomic_store(&result->key, found ? key : kNoModelKey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&result->best_h, found ? best + h_offset : (int64_t)-1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&result->best_err, found ? __longlong_as_double((long long)key) : (double)INFINITY,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&result->first_flagged, first_flag != INT64_MAX ? first_flag + h_offset : INT64_MAX,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&result->n_flagged, (int32_t)n_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&result->best_cnt, found ? cnt[best] : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -809,24 +858,17 @@ int sfm_ransac_pass_small(uint64_t seed, const uint64_t* seed_dev, int use_philo
                                                                    h_offset, cnt, s1, s2, result, mask,
                                                                    static_cast<unsigned char*>(workspace), st});
     if (rc2 != SFM_OK) return rc2;
-    // launch 3: selection — one 1024-thread block up to 4096 hypotheses (6.7 us at 2 000), beyond that up to 32 blocks
-    // x 256 threads x 4 hypotheses folded by the block that arrives last (~8 us flat; the single block needs 14 us at
-    // 10 000 and 35 us at 30 000 hypotheses)
-    if (h_count <= 4096) {
-        hipLaunchKernelGGL(select_block_kernel, dim3(1), dim3(kSelectBlock), 0, st, (const int32_t*)cnt, (const double*)s1,
-                           (const double*)s2, (const int32_t*)flags, h_count, h_offset, min_extra, aggregation, result);
-    } else {
-        const unsigned select_blocks = (unsigned)((h_count + 1023) / 1024);
-        unsigned char* state = static_cast<unsigned char*>(workspace) + sfmws::ws_points_offset(1) + 16 * n;
-        hipLaunchKernelGGL(select_sharded_kernel, dim3(select_blocks), dim3(256), 0, st, (const int32_t*)cnt,
-                           (const double*)s1, (const double*)s2, (const int32_t*)flags, h_count, h_offset, min_extra,
-                           aggregation, state, result);
-    }
-    if (mask == nullptr) return check_launch("select_sharded_kernel");
-    // launch 4: the winner's inlier mask
-    hipLaunchKernelGGL(inlier_mask_kernel, dim3(grid_stride(n, 256, 1024), 1u), dim3(256), 0, st, (const Corr*)corr, n,
-                       (const double*)E, (const int32_t*)S, h_count, (const sfm_select_result*)result, thr, mask);
-    return check_launch("inlier_mask_kernel (fused small pass)");
+    // launch 3: selection spread over up to 32 blocks x 256 threads x 4 hypotheses, folded by the block that arrives last
+    // (a single block needs 14 us at 10 000 and 35 us at 30 000 hypotheses), and — behind them in the same launch — the
+    // blocks that write the winner's inlier mask once the record is published
+    const int select_blocks = (int)((h_count + 1023) / 1024);
+    const int mask_blocks = mask != nullptr ? (int)((n + 255) / 256) : 0;
+    unsigned char* state = static_cast<unsigned char*>(workspace) + sfmws::ws_points_offset(1) + 16 * n;
+    hipLaunchKernelGGL(select_sharded_kernel, dim3((unsigned)(select_blocks + mask_blocks)), dim3(256), 0, st,
+                       (const int32_t*)cnt, (const double*)s1, (const double*)s2, (const int32_t*)flags, h_count, h_offset,
+                       min_extra, aggregation, state, result, select_blocks, (const Corr*)corr, n, (const double*)E,
+                       (const int32_t*)S, thr, mask);
+    return check_launch("select_sharded_kernel");
 }
 
 int sfm_fit_trace_doubles(void) { return kTraceDoubles; }

@@ -27,7 +27,8 @@ constexpr int kSmallMaxPoints = 8192;
 constexpr int kMaxPrepBlocks = kSmallMaxPoints / kPrepPoints;  // 16 partial maxima x 4 words = buckets[0, 64)
 static_assert(4 * kMaxPrepBlocks <= kBuckets, "the partial maxima live in the class-counter words");
 // state of a small pass's sharded selection (select_sharded_kernel, sfm_kernels.hip) in the kPointsPad bytes behind
-// the fp32 points: an arrival counter on a line of its own, then one 32-byte partial record per selecting block
+// the fp32 points: one 64-byte line with the arrival counter and the "record published" flag, then one 32-byte partial
+// record per selecting block
 constexpr int kFusedShards = 32;             // selecting blocks: 32 x 256 threads x 4 hypotheses = 32768
 constexpr int kFusedPartialOffset = 64;      // bytes: partial records behind the counter's line
 
@@ -87,7 +88,8 @@ __device__ __forceinline__ void prepare_small_block(const Corr* __restrict__ pts
         partial[2] = __float_as_uint(m2);
         partial[3] = __float_as_uint(m3);
     }
-    if (block == 0 && lane == 0) *reinterpret_cast<unsigned*>(ws + ws_points_offset(1) + 16 * (int64_t)n) = 0u;
+    if (block == 0 && lane < 16)   // the line holding the arrival counter and the "record published" flag
+        reinterpret_cast<unsigned*>(ws + ws_points_offset(1) + 16 * (int64_t)n)[lane] = 0u;
 }
 
 }  // namespace sfmws
