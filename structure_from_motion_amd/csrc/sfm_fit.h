@@ -234,7 +234,8 @@ SFM_DEVICE void smallest_eigenvector_psd9(const double (&a)[45], double (&x)[9])
 }
 
 // rank-2 enforcement (eight_point.py:430-446): drop the smallest singular direction of f (row-major 3x3)
-SFM_DEVICE void enforce_rank2(const double (&f)[9], double (&fr)[3][3]) {
+// `ratio2` (optional) receives (sigma_3 / sigma_1)^2 of f: how far the unconstrained estimate was from rank 2.
+SFM_DEVICE void enforce_rank2(const double (&f)[9], double (&fr)[3][3], double* ratio2 = nullptr) {
     double g[3][3], vv[3][3];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
@@ -245,6 +246,7 @@ SFM_DEVICE void enforce_rank2(const double (&f)[9], double (&fr)[3][3]) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) n2[c] = g[c][0] * g[c][0] + g[c][1] * g[c][1] + g[c][2] * g[c][2];
     const int drop = (n2[0] <= n2[1] && n2[0] <= n2[2]) ? 0 : ((n2[1] <= n2[2]) ? 1 : 2);
+    if (ratio2 != nullptr) *ratio2 = fmin(n2[0], fmin(n2[1], n2[2])) / fmax(n2[0], fmax(n2[1], n2[2]));
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll

@@ -128,6 +128,7 @@ struct SmallPrep {
     unsigned char* ws;
     double a_scale;
     int blocks;
+    int32_t* order;   // scoring order of the pass that follows (see fit_eight_point_kernel), or NULL
 };
 
 template <bool TRACE>
@@ -199,7 +200,47 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     const bool need_second = TRACE || (lambda2 != nullptr);
     const int flag = null_vector_of_design(xa, ya, xb, yb, need_second, f, second, sq);
     double fr[3][3];
-    enforce_rank2(f, fr);
+    double ratio2 = 0.0;
+    enforce_rank2(f, fr, &ratio2);
+    if (prep.order != nullptr) {  // wave-uniform (small pass)
+        // Scoring order for the launch that follows, for free: a sample of eight inliers gives an estimate that is
+        // almost rank 2 already, so (sigma_3 / sigma_1)^2 of the unconstrained F predicts which hypotheses will fit the
+        // scene — the ones whose scoring takes several times the average (their exact tier handles half the points).
+        // On the bench scene the lowest quarter of this ratio holds every such hypothesis.  Each wave puts the
+        // quarter of its hypotheses with the lowest ratio in front: slots [16 w, 16 w + 16) of the order, the rest
+        // behind all fronts — closed-form offsets, no atomics; only the last wave can be partial.  The scoring launch
+        // walks the order front first, so the expensive hypotheses start with the launch instead of at its tail.
+        // Results are written at each hypothesis' own index: the order changes timing only.
+        // non-negative floats order like unsigned ints; 16 bits (sign, exponent, 7 mantissa bits: 1 % resolution) are
+        // plenty for a scheduling hint and halve the bisection below
+        unsigned key = __float_as_uint((float)ratio2) >> 16;
+        if (!(ratio2 == ratio2) || !active) key = 0xFFFFu;   // NaN and the padding lanes of the last wave go last
+        const int64_t waves = (h_count + kWave - 1) / kWave;
+        const int64_t w = blockIdx.x;
+        const int64_t active_here = w == waves - 1 ? h_count - (waves - 1) * kWave : kWave;
+        const int64_t front_here = (active_here + 3) / 4;
+        const int64_t front_last = (h_count - (waves - 1) * kWave + 3) / 4;
+        const int64_t front_total = 16 * (waves - 1) + front_last;
+        // the front_here smallest keys of the wave (ties by lane): bisection on the key value with ballots — scalar work
+        // beside the fit's fp64 chain — then ranks inside the two classes by prefix counts
+        unsigned lo = 0u, hi = 0xFFFFu;
+        while (lo < hi) {  // wave-uniform, <= 16 rounds: smallest T with count(key <= T) >= front_here
+            const unsigned mid = lo + (hi - lo) / 2u;
+            if ((int64_t)__popcll(__builtin_amdgcn_ballot_w64(key <= mid)) >= front_here) hi = mid; else lo = mid + 1u;
+        }
+        const unsigned long long below = __builtin_amdgcn_ballot_w64(key < hi);
+        const unsigned long long equal = __builtin_amdgcn_ballot_w64(key == hi);
+        const int take_equal = (int)front_here - (int)__popcll(below);   // how many of the lanes at the threshold still fit
+        const int equal_rank = __builtin_amdgcn_mbcnt_hi((unsigned)(equal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)equal, 0));
+        const bool in_front = key < hi || (key == hi && equal_rank < take_equal);
+        const unsigned long long front = __builtin_amdgcn_ballot_w64(in_front);
+        const unsigned long long mine = in_front ? front : ~front;
+        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mine >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mine, 0));
+        if (active) {
+            const int64_t slot = in_front ? 16 * w + rank : front_total + 48 * w + rank;
+            prep.order[slot] = (int32_t)h_raw;
+        }
+    }
     if constexpr (TRACE) {
         if (active) {
 #pragma unroll
@@ -806,7 +847,7 @@ int sfm_fit_eight_point(const double* corr, int64_t n, const int32_t* S, int64_t
     SFM_REQUIRE_GRID("sfm_fit_eight_point", h_count, kWave, kWave, batch);
     hipLaunchKernelGGL(fit_eight_point_kernel<false>, dim3(grid_for(h_count, kWave), (unsigned)batch),
                        dim3(kWave), 0, (hipStream_t)stream, (const Corr*)corr, n, const_cast<int32_t*>(S), h_count, E,
-                       flags, lambda2, (double*)nullptr, PhiloxSource{nullptr, 0, 0, 0, 0}, SmallPrep{nullptr, 0.0, 0});
+                       flags, lambda2, (double*)nullptr, PhiloxSource{nullptr, 0, 0, 0, 0}, SmallPrep{nullptr, 0.0, 0, nullptr});
     return check_launch("fit_eight_point_kernel");
 }
 
@@ -821,7 +862,7 @@ int sfm_sample_fit_philox(uint64_t seed, const uint64_t* seed_dev, uint64_t seed
     hipLaunchKernelGGL(fit_eight_point_kernel<false>, dim3(grid_for(h_count, kWave), (unsigned)batch),
                        dim3(kWave), 0, (hipStream_t)stream, (const Corr*)corr, n, S, h_count, E, flags,
                        (double*)nullptr, (double*)nullptr, PhiloxSource{seed_dev, seed, seed_stride, h_begin, 1},
-                       SmallPrep{nullptr, 0.0, 0});
+                       SmallPrep{nullptr, 0.0, 0, nullptr});
     return check_launch("fit_eight_point_kernel (philox)");
 }
 
@@ -850,7 +891,8 @@ int sfm_ransac_pass_small(uint64_t seed, const uint64_t* seed_dev, int use_philo
     hipLaunchKernelGGL(fit_eight_point_kernel<false>, dim3(fit_blocks + (unsigned)prep_blocks, 1u), dim3(kWave), 0, st,
                        (const Corr*)corr, n, S, h_count, E, flags, (double*)nullptr, (double*)nullptr,
                        PhiloxSource{seed_dev, seed, 0, h_begin, use_philox ? 1 : 0},
-                       SmallPrep{static_cast<unsigned char*>(workspace), sfmhost::small_pass_a_scale(thr), prep_blocks});
+                       SmallPrep{static_cast<unsigned char*>(workspace), sfmhost::small_pass_a_scale(thr), prep_blocks,
+                                 sfmhost::small_pass_order(static_cast<unsigned char*>(workspace), n, h_count)});
     const int rc = check_launch("fit_eight_point_kernel (fused small pass)");
     if (rc != SFM_OK) return rc;
     // launch 2: SED scoring
@@ -882,7 +924,7 @@ int sfm_fit_eight_point_traced(const double* corr, int64_t n, const int32_t* S, 
     SFM_REQUIRE_GRID("sfm_fit_eight_point_traced", h_count, kWave, kWave, batch);
     hipLaunchKernelGGL(fit_eight_point_kernel<true>, dim3(grid_for(h_count, kWave), (unsigned)batch),
                        dim3(kWave), 0, (hipStream_t)stream, (const Corr*)corr, n, const_cast<int32_t*>(S), h_count, E,
-                       flags, (double*)nullptr, trace, PhiloxSource{nullptr, 0, 0, 0, 0}, SmallPrep{nullptr, 0.0, 0});
+                       flags, (double*)nullptr, trace, PhiloxSource{nullptr, 0, 0, 0, 0}, SmallPrep{nullptr, 0.0, 0, nullptr});
     return check_launch("fit_eight_point_kernel<trace>");
 }
 

@@ -756,6 +756,12 @@ namespace sfmhost {
 
 double small_pass_a_scale(double thr) { return one_sided_scale(thr); }
 
+int32_t* small_pass_order(unsigned char* workspace, int64_t n, int64_t h_count) {
+    // with every wave of the scoring launch resident at once (one generation) the order cannot change anything
+    if (h_count <= 4096) return nullptr;
+    return reinterpret_cast<int32_t*>(workspace + ws_order_offset(n, 1));
+}
+
 int launch_small_score(const SmallPass& p) {
     // hypotheses per wave as in sfm_score_sed: 4 amortise the point loads best, fewer when the launch would leave
     // the chip short of waves
@@ -770,7 +776,7 @@ int launch_small_score(const SmallPass& p) {
 #define SFM_LAUNCH_FUSED(H)                                                                                          \
     hipLaunchKernelGGL((score_sed_filtered_kernel<H, true, true>), grid, dim3(256), 0, p.stream, (const Corr*)p.corr, \
                        p.workspace, (int)p.n, p.E, p.S, (int)p.h_count, p.thr, one_sided_scale(p.thr),               \
-                       (const int32_t*)nullptr, p.cnt, p.s1, p.s2, 1, 0, prep_blocks)
+                       (const int32_t*)small_pass_order(p.workspace, p.n, p.h_count), p.cnt, p.s1, p.s2, 1, 0, prep_blocks)
     switch (hpw) {
         case 1: SFM_LAUNCH_FUSED(1); break;
         case 2: SFM_LAUNCH_FUSED(2); break;
