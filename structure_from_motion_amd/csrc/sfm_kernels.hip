@@ -206,39 +206,26 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         // Scoring order for the launch that follows, for free: a sample of eight inliers gives an estimate that is
         // almost rank 2 already, so (sigma_3 / sigma_1)^2 of the unconstrained F predicts which hypotheses will fit the
         // scene — the ones whose scoring takes several times the average (their exact tier handles half the points).
-        // On the bench scene the lowest quarter of this ratio holds every such hypothesis.  Each wave puts the
-        // quarter of its hypotheses with the lowest ratio in front: slots [16 w, 16 w + 16) of the order, the rest
-        // behind all fronts — closed-form offsets, no atomics; only the last wave can be partial.  The scoring launch
-        // walks the order front first, so the expensive hypotheses start with the launch instead of at its tail.
+        // On the bench scene the lowest quarter of this ratio holds every such hypothesis.  The scoring launch walks
+        // the order from its front, so the expensive hypotheses start with the launch instead of at its tail.
         // Results are written at each hypothesis' own index: the order changes timing only.
-        // non-negative floats order like unsigned ints; 16 bits (sign, exponent, 7 mantissa bits: 1 % resolution) are
-        // plenty for a scheduling hint and halve the bisection below
-        unsigned key = __float_as_uint((float)ratio2) >> 16;
-        if (!(ratio2 == ratio2) || !active) key = 0xFFFFu;   // NaN and the padding lanes of the last wave go last
+        unsigned key = __float_as_uint((float)ratio2);       // non-negative floats order like unsigned ints
+        if (!(ratio2 == ratio2) || !active) key = 0xFFFFFFFFu;  // NaN and the padding lanes of the last wave go last
+        // rank of this lane's key within the wave (ties by lane)
+        int rank = 0;
+        for (int j = 0; j < kWave; ++j) {
+            const unsigned other = (unsigned)__builtin_amdgcn_readlane((int)key, j);
+            rank += (other < key || (other == key && j < (int)threadIdx.x)) ? 1 : 0;
+        }
+        // rank-major layout: first every wave's lowest ratio, then every wave's second lowest, ... — an approximate
+        // global sort by quantile with closed-form slots and no atomics; only the last wave can be partial, so layer r
+        // holds one entry per wave for r < active_last and one fewer beyond
         const int64_t waves = (h_count + kWave - 1) / kWave;
         const int64_t w = blockIdx.x;
-        const int64_t active_here = w == waves - 1 ? h_count - (waves - 1) * kWave : kWave;
-        const int64_t front_here = (active_here + 3) / 4;
-        const int64_t front_last = (h_count - (waves - 1) * kWave + 3) / 4;
-        const int64_t front_total = 16 * (waves - 1) + front_last;
-        // the front_here smallest keys of the wave (ties by lane): bisection on the key value with ballots — scalar work
-        // beside the fit's fp64 chain — then ranks inside the two classes by prefix counts
-        unsigned lo = 0u, hi = 0xFFFFu;
-        while (lo < hi) {  // wave-uniform, <= 16 rounds: smallest T with count(key <= T) >= front_here
-            const unsigned mid = lo + (hi - lo) / 2u;
-            if ((int64_t)__popcll(__builtin_amdgcn_ballot_w64(key <= mid)) >= front_here) hi = mid; else lo = mid + 1u;
-        }
-        const unsigned long long below = __builtin_amdgcn_ballot_w64(key < hi);
-        const unsigned long long equal = __builtin_amdgcn_ballot_w64(key == hi);
-        const int take_equal = (int)front_here - (int)__popcll(below);   // how many of the lanes at the threshold still fit
-        const int equal_rank = __builtin_amdgcn_mbcnt_hi((unsigned)(equal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)equal, 0));
-        const bool in_front = key < hi || (key == hi && equal_rank < take_equal);
-        const unsigned long long front = __builtin_amdgcn_ballot_w64(in_front);
-        const unsigned long long mine = in_front ? front : ~front;
-        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mine >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mine, 0));
+        const int64_t active_last = h_count - (waves - 1) * kWave;
         if (active) {
-            const int64_t slot = in_front ? 16 * w + rank : front_total + 48 * w + rank;
-            prep.order[slot] = (int32_t)h_raw;
+            const int64_t layer = (int64_t)rank * waves - (rank > active_last ? rank - active_last : 0);
+            prep.order[layer + w] = (int32_t)h_raw;
         }
     }
     if constexpr (TRACE) {
