@@ -763,10 +763,12 @@ int32_t* small_pass_order(unsigned char* workspace, int64_t n, int64_t h_count) 
 }
 
 int launch_small_score(const SmallPass& p) {
-    // hypotheses per wave as in sfm_score_sed: 4 amortise the point loads best, fewer when the launch would leave
-    // the chip short of waves
-    int hpw = kHypPerWave;
-    while (hpw > 1 && (p.h_count + hpw - 1) / hpw < 5120) hpw /= 2;
+    // hypotheses per wave: at most 32768 hypotheses are a few generations of waves at best, where two per wave (7
+    // waves per SIMD) beat four (5 per SIMD; measured at 20 000 and 30 000 hypotheses: 80 vs 85 and 186 vs 198 us per
+    // pass) and one per wave wins as long as two would leave the chip short of waves (profiles/r02/small_pass_hpw.log)
+    int hpw = (p.h_count + 1) / 2 >= 5120 ? 2 : 1;
+    const int hpw_env = getenv("SFM_SCORE_HPW") ? atoi(getenv("SFM_SCORE_HPW")) : 0;
+    if (hpw_env == 1 || hpw_env == 2 || hpw_env == 4) hpw = hpw_env;
     const int64_t waves = (p.h_count + hpw - 1) / hpw;
     const int64_t blocks = (waves + 256 / kWave - 1) / (256 / kWave);
     SFM_REQUIRE_GRID("sfm_ransac_pass_small", blocks, 1, 256);
