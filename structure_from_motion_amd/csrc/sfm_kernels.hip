@@ -209,14 +209,22 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         // On the bench scene the lowest quarter of this ratio holds every such hypothesis.  The scoring launch walks
         // the order from its front, so the expensive hypotheses start with the launch instead of at its tail.
         // Results are written at each hypothesis' own index: the order changes timing only.
-        unsigned key = __float_as_uint((float)ratio2);       // non-negative floats order like unsigned ints
-        if (!(ratio2 == ratio2) || !active) key = 0xFFFFFFFFu;  // NaN and the padding lanes of the last wave go last
-        // rank of this lane's key within the wave (ties by lane)
+        // non-negative floats order like unsigned ints; their top 16 bits (exponent + 7 mantissa bits: 1 % resolution)
+        // are plenty for a scheduling hint
+        unsigned key = __float_as_uint((float)ratio2) >> 16;
+        if (!(ratio2 == ratio2) || !active) key = 0xFFFFu;   // NaN and the padding lanes of the last wave go last
+        // rank of this lane's key within the wave (ties by lane), bit by bit from the top: `same` = lanes whose key agrees
+        // with mine on the bits seen so far; where my bit is 1, the lanes of `same` with a 0 are smaller than me
+        unsigned long long same = ~0ull;
         int rank = 0;
-        for (int j = 0; j < kWave; ++j) {
-            const unsigned other = (unsigned)__builtin_amdgcn_readlane((int)key, j);
-            rank += (other < key || (other == key && j < (int)threadIdx.x)) ? 1 : 0;
+#pragma unroll
+        for (int bit = 15; bit >= 0; --bit) {
+            const unsigned long long ones = __builtin_amdgcn_ballot_w64(((key >> bit) & 1u) != 0u);
+            const bool mine = ((key >> bit) & 1u) != 0u;
+            rank += mine ? (int)__popcll(same & ~ones) : 0;
+            same &= mine ? ones : ~ones;
         }
+        rank += (int)__popcll(same & ((1ull << threadIdx.x) - 1ull));   // equal keys: lower lanes first
         // rank-major layout: first every wave's lowest ratio, then every wave's second lowest, ... — an approximate
         // global sort by quantile with closed-form slots and no atomics; only the last wave can be partial, so layer r
         // holds one entry per wave for r < active_last and one fewer beyond
