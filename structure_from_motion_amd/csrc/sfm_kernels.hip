@@ -455,6 +455,20 @@ __global__ __launch_bounds__(kSelectBlock) void select_block_kernel(
                                        aggregation, result + b, scratch, &winner);
 }
 
+// Smallest passes (the reference's own workload: a few hundred matches, 2000 iterations): one 1024-thread block selects
+// and then writes the winner's mask itself — no cross-block hand-off at all.
+__global__ __launch_bounds__(kSelectBlock) void select_block_mask_kernel(
+    const int32_t* __restrict__ cnt, const double* __restrict__ s1, const double* __restrict__ s2,
+    const int32_t* __restrict__ flags, int64_t h_count, int64_t h_offset, double min_extra, int aggregation,
+    sfm_select_result* __restrict__ result, const Corr* __restrict__ corr, int64_t n, const double* __restrict__ E,
+    const int32_t* __restrict__ S, double thr, uint8_t* __restrict__ mask) {
+    __shared__ sfmsel::SelectScratch<kSelectBlock> scratch;
+    __shared__ int64_t winner;
+    const int64_t best = sfmsel::block_select<kSelectBlock>(cnt, s1, s2, flags, h_count, h_offset, min_extra, aggregation,
+                                                            result, scratch, &winner);
+    if (mask != nullptr) sfmsel::write_inlier_mask<4>(corr, n, E, S, h_count, best, thr, mask, threadIdx.x, kSelectBlock);
+}
+
 // Selection of a small pass (h_count <= 32768) spread over up to 32 blocks of ONE launch: a single block walking
 // every hypothesis is latency-bound (14 us at 10 000, 35 us at 30 000 hypotheses).  Each block folds its slice and
 // publishes a partial record write-through (sc1); an agent-scope arrival counter (cdna_hip_programming.md Guideline 16,
@@ -898,6 +912,12 @@ int sfm_ransac_pass_small(uint64_t seed, const uint64_t* seed_dev, int use_philo
     // launch 3: selection spread over up to 32 blocks x 256 threads x 4 hypotheses, folded by the block that arrives last
     // (a single block needs 14 us at 10 000 and 35 us at 30 000 hypotheses), and — behind them in the same launch — the
     // blocks that write the winner's inlier mask once the record is published
+    if (h_count <= 4096 && n <= 4096) {  // one block does both: 7 us instead of 10 at 300 x 2000
+        hipLaunchKernelGGL(select_block_mask_kernel, dim3(1), dim3(kSelectBlock), 0, st, (const int32_t*)cnt,
+                           (const double*)s1, (const double*)s2, (const int32_t*)flags, h_count, h_offset, min_extra,
+                           aggregation, result, (const Corr*)corr, n, (const double*)E, (const int32_t*)S, thr, mask);
+        return check_launch("select_block_mask_kernel");
+    }
     const int select_blocks = (int)((h_count + 1023) / 1024);
     const int mask_blocks = mask != nullptr ? (int)((n + 255) / 256) : 0;
     unsigned char* state = static_cast<unsigned char*>(workspace) + sfmws::ws_points_offset(1) + 16 * n;
