@@ -131,8 +131,15 @@ def load_counters(n, h):
         rec = json.load(open(COUNTERS))
     except (OSError, ValueError):
         return None, None
-    if rec.get("matches") != n or rec.get("hypotheses") != h or "counters" not in rec:
+    if rec.get("matches") != n or "counters" not in rec or not rec.get("hypotheses"):
         return None, None
+    if rec["hypotheses"] != h:
+        # same point set, another hypothesis count (the per-rank shard of a multi-GPU run): every per-launch counter of
+        # the scoring kernel is proportional to the number of hypotheses — scale, and say so
+        factor = float(h) / float(rec["hypotheses"])
+        rec = dict(rec, counters={k: (v * factor if k != "profiled_kernel_ms" and k != "GRBM_GUI_ACTIVE" else v)
+                                  for k, v in rec["counters"].items()}, scaled_from_hypotheses=rec["hypotheses"])
+        rec["counters"].pop("profiled_kernel_ms", None)   # the clock estimate does not carry over
     return rec, rec.get("source_sha") != build.score_source_sha()
 
 
@@ -181,7 +188,7 @@ def roofline(n, h, kernel_ms, call_ms, variant):
                                "frac": traffic / seconds / 1e9 / HBM_PEAK_GBS,
                                "note": "rocprofv3 PMC: 2 x FETCH_SIZE (gfx950 counts 128-B requests as 64 B) + "
                                        "WRITE_SIZE, KiB, per launch"}
-    out["counters_from"] = {k: rec.get(k) for k in ("git", "source_sha", "abi", "collected")}
+    out["counters_from"] = {k: rec.get(k) for k in ("git", "source_sha", "abi", "collected", "scaled_from_hypotheses")}
     return out
 
 

@@ -330,7 +330,7 @@ def test_value_types():
 def test_bench_roofline_is_a_valu_issue_bound(monkeypatch, tmp_path):
     """bench.py's roofline block: bound = valu-issue with frac = priced VALU instructions / (1024 SIMDs x 2.4 GHz x
     kernel time) <= 1 for the committed counters, both HBM views beside it, and `counters_stale` raised as soon as the
-    record's fingerprint is not the one of the kernel sources in the tree."""
+    record's fingerprint is not the one of the kernel sources in the tree; per-rank shards scale the record."""
     import importlib.util
     import json
 
@@ -357,5 +357,10 @@ def test_bench_roofline_is_a_valu_issue_bound(monkeypatch, tmp_path):
     path.write_text(json.dumps(stale))
     monkeypatch.setattr(bench, "COUNTERS", str(path))
     assert bench.roofline(n, h, 2.4, 2.5, "filtered")["counters_stale"] is True
-    other = bench.roofline(n, h + 1, 2.4, 2.5, "filtered")
+    # another hypothesis count on the same point set (a multi-GPU shard): counters scale with the hypotheses, and say so
+    shard = bench.roofline(n, h * 5 // 4, 3.0, 3.1, "filtered")
+    assert shard["counters_from"]["scaled_from_hypotheses"] == h
+    assert isclose(shard["frac"], 1.25 * cycles / 1024 / 2.4e9 / 3.0e-3, rel_tol=1e-12)
+    # another point set: the record does not apply
+    other = bench.roofline(n + 1, h, 2.4, 2.5, "filtered")
     assert other["frac"] is None and other["counters_stale"] is None
