@@ -158,6 +158,20 @@ SFM_DEVICE int jacobi_eig9(double* a, double* v, double* w) {
     return sweep;
 }
 
+// Rotation parameters for one-sided Jacobi from the Gram entries alpha = |g_i|^2, beta = |g_j|^2,
+// gamma = g_i . g_j, with one square root, one division and one reciprocal square root:
+//   t = 2 gamma sign(beta - alpha) / (|beta - alpha| + sqrt((beta - alpha)^2 + 4 gamma^2)),  c = rsqrt(1 + t^2), s = t c.
+// (Same t as jacobi_cs; c^2 + s^2 = 1 to a couple of ulps, which only rescales the rotated pair uniformly.)
+SFM_DEVICE void jacobi_cs_gram(double alpha, double beta, double gamma, bool rot, double& c, double& s) {
+    const double diff = beta - alpha;
+    const double den = fabs(diff) + sqrt(diff * diff + 4.0 * (gamma * gamma));
+    double t = (2.0 * gamma) / den;
+    t = (diff < 0.0) ? -t : t;
+    t = (rot && t == t) ? t : 0.0;  // no rotation (or 0/0): identity
+    c = rsqrt(1.0 + t * t);
+    s = t * c;
+}
+
 // --------------------------------------------------------------------------------------------------
 // One-sided (Hestenes) Jacobi SVD of an NxN matrix stored column-wise: g[col][row].
 // On return the columns of g are sigma_k * u_k (mutually orthogonal) and v[col][row] holds V.
@@ -172,10 +186,13 @@ SFM_DEVICE bool hestenes_rotate(double (&g)[N][N], double (&v)[N][N]) {
         beta += g[J][k] * g[J][k];
         gamma += g[I][k] * g[J][k];
     }
-    // relative orthogonality test; columns that are exactly zero are left alone
-    const bool rot = fabs(gamma) > 1e-15 * sqrt(alpha * beta);
-    double c, s, t;
-    jacobi_cs(alpha, beta, rot ? gamma : 0.0, c, s, t);
+    // relative orthogonality test |gamma| > 1e-15 sqrt(alpha beta), squared (no square root); columns that are exactly
+    // zero are left alone.  Rotation parameters with one square root, one division and one reciprocal square root
+    // (jacobi_cs_gram) instead of the two divisions and two square roots of jacobi_cs: these rotations are most of the
+    // eight-point fit's dependent chain (3 x 3 rank-2 enforcement: ~6 sweeps of 3).
+    const bool rot = gamma * gamma > 1e-30 * (alpha * beta);
+    double c, s;
+    jacobi_cs_gram(alpha, beta, gamma, rot, c, s);
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         const double gi = g[I][k], gj = g[J][k];
@@ -220,9 +237,9 @@ SFM_DEVICE bool hestenes_rotate_novec(double (&g)[N][N]) {
         beta += g[J][k] * g[J][k];
         gamma += g[I][k] * g[J][k];
     }
-    const bool rot = fabs(gamma) > 1e-15 * sqrt(alpha * beta);
-    double c, s, t;
-    jacobi_cs(alpha, beta, rot ? gamma : 0.0, c, s, t);
+    const bool rot = gamma * gamma > 1e-30 * (alpha * beta);
+    double c, s;
+    jacobi_cs_gram(alpha, beta, gamma, rot, c, s);
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         const double gi = g[I][k], gj = g[J][k];
@@ -314,20 +331,6 @@ SFM_DEVICE void qr_null_vector(double (&col)[8][9], double (&rdiag)[8], double (
 // Replaces `np.linalg.svd(A)[2][-1]` of reference triangulation.py:34-35 (sign and scale are irrelevant: the
 // caller divides by the last component).
 // --------------------------------------------------------------------------------------------------
-// Rotation parameters for one-sided Jacobi from the Gram entries alpha = |g_i|^2, beta = |g_j|^2,
-// gamma = g_i . g_j, with one square root, one division and one reciprocal square root:
-//   t = 2 gamma sign(beta - alpha) / (|beta - alpha| + sqrt((beta - alpha)^2 + 4 gamma^2)),  c = rsqrt(1 + t^2), s = t c.
-// (Same t as jacobi_cs; c^2 + s^2 = 1 to a couple of ulps, which only rescales the rotated pair uniformly.)
-SFM_DEVICE void jacobi_cs_gram(double alpha, double beta, double gamma, bool rot, double& c, double& s) {
-    const double diff = beta - alpha;
-    const double den = fabs(diff) + sqrt(diff * diff + 4.0 * (gamma * gamma));
-    double t = (2.0 * gamma) / den;
-    t = (diff < 0.0) ? -t : t;
-    t = (rot && t == t) ? t : 0.0;  // no rotation (or 0/0): identity
-    c = rsqrt(1.0 + t * t);
-    s = t * c;
-}
-
 template <int I, int J>
 SFM_DEVICE bool rotate_rows4(double (&g)[4][4]) {
     double alpha = 0.0, beta = 0.0, gamma = 0.0;
