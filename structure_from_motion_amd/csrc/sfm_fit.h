@@ -105,7 +105,7 @@ SFM_DEVICE int null_vector_of_design(const double (&xa)[8], const double (&ya)[8
     // divisions fewer shorten every lane's dependent chain (the fit is latency-bound: one wave per SIMD)
     double inv_diag[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) inv_diag[i] = 1.0 / rdiag[i];
+    for (int i = 0; i < 8; ++i) inv_diag[i] = sfm::rcp_newton(rdiag[i]);
     double fro2 = 0.0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {

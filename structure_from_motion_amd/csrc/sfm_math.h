@@ -158,17 +158,34 @@ SFM_DEVICE int jacobi_eig9(double* a, double* v, double* w) {
     return sweep;
 }
 
+// ~1 ulp reciprocal and reciprocal square root (hardware seed + two Newton steps); used where the result feeds an
+// iteration that is checked for convergence anyway, not where the reference's rounding must be reproduced.
+SFM_DEVICE double rcp_newton(double d) {
+    double y = __builtin_amdgcn_rcp(d);
+    y = fma(fma(-d, y, 1.0), y, y);
+    return fma(fma(-d, y, 1.0), y, y);
+}
+SFM_DEVICE double rsqrt_newton(double a) {
+    double y = __builtin_amdgcn_rsq(a);
+    y = y * fma(-0.5 * a * y, y, 1.5);
+    return y * fma(-0.5 * a * y, y, 1.5);
+}
+
 // Rotation parameters for one-sided Jacobi from the Gram entries alpha = |g_i|^2, beta = |g_j|^2,
 // gamma = g_i . g_j, with one square root, one division and one reciprocal square root:
 //   t = 2 gamma sign(beta - alpha) / (|beta - alpha| + sqrt((beta - alpha)^2 + 4 gamma^2)),  c = rsqrt(1 + t^2), s = t c.
 // (Same t as jacobi_cs; c^2 + s^2 = 1 to a couple of ulps, which only rescales the rotated pair uniformly.)
 SFM_DEVICE void jacobi_cs_gram(double alpha, double beta, double gamma, bool rot, double& c, double& s) {
+    // The square root, the division and the reciprocal square root go through the hardware seeds + Newton steps
+    // (~1 ulp each, a third of the instructions of the IEEE sequences): an error of an ulp in t leaves a residual
+    // gamma of the size the rotation's own roundings leave anyway, and the sweeps run until none is needed.
     const double diff = beta - alpha;
-    const double den = fabs(diff) + sqrt(diff * diff + 4.0 * (gamma * gamma));
-    double t = (2.0 * gamma) / den;
+    const double q = fma(diff, diff, 4.0 * (gamma * gamma));
+    const double den = fabs(diff) + q * rsqrt_newton(q);  // q = 0: NaN, caught below
+    double t = (2.0 * gamma) * rcp_newton(den);
     t = (diff < 0.0) ? -t : t;
     t = (rot && t == t) ? t : 0.0;  // no rotation (or 0/0): identity
-    c = rsqrt(1.0 + t * t);
+    c = rsqrt_newton(fma(t, t, 1.0));
     s = t * c;
 }
 
@@ -289,6 +306,8 @@ SFM_DEVICE void qr_null_vector(double (&col)[8][9], double (&rdiag)[8], double (
         double norm2 = 0.0;
 #pragma unroll
         for (int i = 0; i < 9; ++i) norm2 += (i >= J) ? col[J][i] * col[J][i] : 0.0;
+        // (IEEE square root and division here: the Newton forms that pay in the Jacobi rotations made this kernel
+        // slower at full occupancy — 111 vs 90 us for 256 x 2000 fits, profiles/r02/README.md)
         const double norm = sqrt(norm2);
         const double x0 = col[J][J];
         const double alpha = (x0 > 0.0) ? -norm : norm;
@@ -350,19 +369,6 @@ SFM_DEVICE bool rotate_rows4(double (&g)[4][4]) {
         g[J][k] = s * gi + c * gj;
     }
     return rot;
-}
-
-// ~1 ulp reciprocal and reciprocal square root (hardware seed + two Newton steps); used where the result feeds an
-// iteration that is checked for convergence anyway, not where the reference's rounding must be reproduced.
-SFM_DEVICE double rcp_newton(double d) {
-    double y = __builtin_amdgcn_rcp(d);
-    y = fma(fma(-d, y, 1.0), y, y);
-    return fma(fma(-d, y, 1.0), y, y);
-}
-SFM_DEVICE double rsqrt_newton(double a) {
-    double y = __builtin_amdgcn_rsq(a);
-    y = y * fma(-0.5 * a * y, y, 1.5);
-    return y * fma(-0.5 * a * y, y, 1.5);
 }
 
 // Fast path for the DLT null vector: Householder QR of A (no squaring of the condition number), the null-vector

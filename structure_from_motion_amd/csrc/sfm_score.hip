@@ -58,7 +58,7 @@ constexpr int kHypPerWave = 4;
 #define SFM_WAVE_STAMPS 0   // diagnostic build (tools/wave_timeline.py): per-wave start / end stamps of the filtered kernel
 #endif
 #if SFM_WAVE_STAMPS
-__device__ unsigned long long g_wave_stamps[2 * 65536];  // read by nothing but sfm_debug_read_wave_stamps
+__device__ unsigned long long g_wave_stamps[4 * 65536];  // begin, end, first hypothesis, exact-tier batches; read by nothing but sfm_debug_read_wave_stamps
 #endif
 constexpr int kRing = 256;  // entries per (wave, hypothesis) ring; <= 63 left + 128 pushed per step; drained in groups of 64
 
@@ -443,6 +443,9 @@ __global__ __launch_bounds__(256) void score_class_scatter_kernel(const int32_t*
 // FUSED (the scoring launch of sfm_ransac_pass_small: small problems, one pair): the workspace was prepared by spare
 // blocks of the fit launch, which leave one partial maximum per block of points instead of the data-set maxima
 // (sfm_score_ws.h); everything else is the kernel as usual.
+#ifndef SFM_SCORE_PREFETCH_DEPTH
+#define SFM_SCORE_PREFETCH_DEPTH 2   // steps of point loads in flight in one-hypothesis waves (1 = the plain loop)
+#endif
 template <int HPW, bool ONE_SIDED, bool FUSED = false>
 __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
     const Corr* __restrict__ corr, const unsigned char* __restrict__ ws, int n,
@@ -552,6 +555,8 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
     }
 
     // tier 2: exact fp64 evaluation of `count` (<= 64) queued points of hypothesis k
+    // (Deferring the evaluation by one drain, so that the gather of the fp64 records overlaps the next steps' tier 1,
+    // changed nothing at any size: profiles/r02/README.md.)
     auto drain = [&](int k, int count) __attribute__((always_inline)) {
         const int h = hyp[k];
         double e[9];
@@ -641,7 +646,42 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
 
     const int full_chunks = n / kWave;
     const int pairs = full_chunks / 2;
-    if (pairs > 0) {
+    // One hypothesis per wave is the kernel of small launches (at most two generations of waves): whenever a SIMD holds
+    // few of them — the waves that could not start with the first generation — a step costs one L2 round trip for the
+    // points (~800 cycles against ~300 of work: profiles/r02/README.md, small_pass_timeline.log).  Two steps of point
+    // loads in flight instead of one; the stages rotate by unrolling, not by register moves.
+    constexpr int kDepth = SFM_SCORE_PREFETCH_DEPTH;
+    if constexpr (HPW == 1 && kDepth > 1) {
+        constexpr int kStages = kDepth + 1;
+        static_assert(2048 * kDepth <= kPointsPad, "the prefetch runs this far past a pair's last full step");
+        const float4* __restrict__ next = pts32 + lane;
+        float4 stage[kStages][2];
+#pragma unroll
+        for (int d = 0; d < kDepth; ++d) {  // reads inside the workspace even when pairs < kDepth (points, then the pad)
+            stage[d][0] = next[0];
+            stage[d][1] = next[kWave];
+            next += 2 * kWave;
+        }
+        int i0 = lane;
+        int pr = 0;
+        for (; pr + kStages <= pairs; pr += kStages) {
+#pragma unroll
+            for (int u = 0; u < kStages; ++u) {
+                stage[(u + kDepth) % kStages][0] = next[0];
+                stage[(u + kDepth) % kStages][1] = next[kWave];
+                next += 2 * kWave;
+                process_pair(stage[u][0], stage[u][1], i0);
+                i0 += 2 * kWave;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kDepth; ++u) {  // the last pairs - pr <= kDepth steps are loaded already
+            if (pr + u < pairs) {
+                process_pair(stage[u][0], stage[u][1], i0);
+                i0 += 2 * kWave;
+            }
+        }
+    } else if (pairs > 0) {
         const float4* __restrict__ next = pts32 + lane;  // per-lane cursor: one 64-bit add per step, no index clamping
         float4 p0 = next[0], p1 = next[kWave];
         int i0 = lane;
@@ -680,8 +720,10 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
     }
 #if SFM_WAVE_STAMPS
     if (lane == 0 && wave < 65536) {
-        g_wave_stamps[2 * wave] = stamp_begin;
-        g_wave_stamps[2 * wave + 1] = __builtin_amdgcn_s_memrealtime();
+        g_wave_stamps[4 * wave] = stamp_begin;
+        g_wave_stamps[4 * wave + 1] = __builtin_amdgcn_s_memrealtime();
+        g_wave_stamps[4 * wave + 2] = (unsigned long long)hyp[0];
+        g_wave_stamps[4 * wave + 3] = (unsigned long long)(head[0] + 63) / 64;
     }
 #endif
 }
@@ -793,7 +835,7 @@ int launch_small_score(const SmallPass& p) {
 
 #if SFM_WAVE_STAMPS
 extern "C" int sfm_debug_read_wave_stamps(unsigned long long* out, int64_t waves) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_stamps), 16 * (size_t)waves) == hipSuccess ? 0 : -2;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_stamps), 32 * (size_t)waves) == hipSuccess ? 0 : -2;
 }
 #endif
 

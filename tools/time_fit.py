@@ -3,7 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from structure_from_motion_amd import device as dev, synthetic
-for (B, n, h) in [(1, 50000, 100000), (256, 10000, 2000)]:
+for (B, n, h) in [(1, 50000, 100000), (256, 10000, 2000), (1, 5000, 10000), (1, 300, 2000)]:
     pa, pb, K, *_ = synthetic.two_view_scene(n, seed=6)
     corr = dev.normalize_correspondences(dev.to_device(pa), dev.to_device(pb), K).reshape(1, n, 4).repeat(B, 1, 1).contiguous()
     S = dev.sample_philox(5, 0, h, n, batch=B)

@@ -26,7 +26,7 @@ hpw = 4
 while hpw > 1 and (h + hpw - 1) // hpw < 5120:
     hpw //= 2
 waves = (h + hpw - 1) // hpw
-st = np.zeros((waves, 2), dtype=np.uint64)
+st = np.zeros((waves, 4), dtype=np.uint64)
 assert lib.sfm_debug_read_wave_stamps(st.ctypes.data, waves) == 0
 t0 = st[:, 0].min()
 begin = (st[:, 0] - t0).astype(np.float64) * 0.01   # us
