@@ -409,6 +409,15 @@ class RansacOutcome:
     extra_inliers: int
 
 
+def checked_mask(mask: np.ndarray) -> np.ndarray:
+    """Inlier mask as read back from the device (0 out, 1 inlier, 2 sample).  The mask blocks of a small pass's
+    selection launch wait for the selecting blocks' record with a bounded number of polls and fill their slice with
+    0xFF if it never arrives (``select_sharded_kernel``): that must surface here, not as an empty inlier list."""
+    if mask.size and int(mask.max()) > 2:
+        raise RuntimeError("sfm_hip: the inlier mask was not written (the selection record of the pass never arrived)")
+    return mask
+
+
 class RansacWorkspace:
     """Pre-allocated device buffers for B pairs x H hypotheses x N correspondences."""
 
@@ -456,7 +465,7 @@ class RansacWorkspace:
         local = int(rec.best_h) - h_offset
         E = self.E[b, local].cpu().numpy().reshape(3, 3).copy()
         sample = self.S[b, local].cpu().numpy().astype(np.int64)
-        mask = self.mask[b].cpu().numpy().copy()
+        mask = checked_mask(self.mask[b].cpu().numpy().copy())
         return RansacOutcome(int(rec.best_h), float(rec.best_err), E, sample, mask, int(rec.n_flagged),
                              first, int(rec.best_cnt))
 

@@ -246,4 +246,5 @@ class ShardedRansac:
         else:
             E = self.win_E.cpu().numpy().reshape(3, 3)
             sample = self.win_S.cpu().numpy().reshape(8).astype(np.int64)
-        return ShardedOutcome(best, float(rec.best_err), E, sample, self.ws.mask.cpu().numpy()[0], n_flagged, first)
+        return ShardedOutcome(best, float(rec.best_err), E, sample, device.checked_mask(self.ws.mask.cpu().numpy()[0]),
+                              n_flagged, first)

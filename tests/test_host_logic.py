@@ -254,6 +254,18 @@ def test_numeric_entry_points_fail_loudly_without_gpu(native_lib):
         calculate_symmetric_epipolar_distance(fa[0], fa[1], np.eye(3))
 
 
+def test_unwritten_mask_is_an_error():
+    """The 0xFF fill of a mask slice whose selection record never arrived (select_sharded_kernel's bounded wait)
+    surfaces as an error on the host, not as an empty inlier list."""
+    from structure_from_motion_amd import device
+
+    ok = np.array([0, 1, 2, 1, 0], dtype=np.uint8)
+    assert device.checked_mask(ok) is ok
+    assert device.checked_mask(np.zeros(0, dtype=np.uint8)).size == 0
+    with pytest.raises(RuntimeError, match="inlier mask was not written"):
+        device.checked_mask(np.array([0, 1, 0xFF, 0xFF], dtype=np.uint8))
+
+
 def test_missing_library_is_an_error(monkeypatch, tmp_path):
     from structure_from_motion_amd import _native
 
