@@ -1,4 +1,6 @@
 """Build recipe for libsfm_hip.so (hipcc, gfx950 only, in-tree)."""
+import contextlib
+import fcntl
 import os
 import subprocess
 import sys
@@ -33,12 +35,47 @@ OPS_LIB_PATH = os.path.join(CSRC, "libsfm_torch_ops.so")
 OPS_SOURCE = os.path.join(CSRC, "sfm_torch_ops.cpp")
 
 
+@contextlib.contextmanager
+def _build_lock():
+    """One builder at a time per checkout: the ranks of a multi-GPU launch import the package together, and a stale
+    library must be rebuilt once, not by every rank into the same file."""
+    fd = None
+    try:
+        fd = os.open(os.path.join(CSRC, ".build.lock"), os.O_CREAT | os.O_RDWR, 0o644)
+        fcntl.flock(fd, fcntl.LOCK_EX)
+    except OSError:
+        fd = fd if fd is None else (os.close(fd) or None)   # read-only tree: build unlocked
+    try:
+        yield
+    finally:
+        if fd is not None:
+            fcntl.flock(fd, fcntl.LOCK_UN)
+            os.close(fd)
+
+
+def _compile(cmd, target: str, verbose: bool) -> None:
+    """Run the compiler into a private file next to `target`, then rename: readers never see a half-written library."""
+    tmp = f"{target}.tmp{os.getpid()}"
+    cmd = [tmp if c == target else c for c in cmd]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    try:
+        subprocess.run(cmd, check=True, cwd=CSRC)
+        os.replace(tmp, target)
+    finally:
+        if os.path.exists(tmp):
+            os.unlink(tmp)
+
+
 def build_ops(force: bool = False, verbose: bool = False) -> str:
     """Compile csrc/sfm_torch_ops.cpp — TORCH_LIBRARY(sfm_hip): the PyTorch-ROCm custom-op registration above the
     C ABI — into csrc/libsfm_torch_ops.so.  Host code only (g++), linked against libsfm_hip.so and torch's libraries."""
     deps = [OPS_SOURCE, os.path.join(CSRC, "..", "..", "include", "sfm_hip.h"), os.path.abspath(__file__)]
-    if not force and os.path.exists(OPS_LIB_PATH) and all(
-            os.path.getmtime(d) <= os.path.getmtime(OPS_LIB_PATH) for d in deps):
+
+    def fresh() -> bool:
+        return os.path.exists(OPS_LIB_PATH) and all(os.path.getmtime(d) <= os.path.getmtime(OPS_LIB_PATH) for d in deps)
+
+    if not force and fresh():
         return OPS_LIB_PATH
     import torch
 
@@ -51,9 +88,9 @@ def build_ops(force: bool = False, verbose: bool = False) -> str:
            f"-I{troot}/include", f"-I{troot}/include/torch/csrc/api/include", f"-I{rocm}/include",
            OPS_SOURCE, "-o", OPS_LIB_PATH, f"-L{CSRC}", "-l:libsfm_hip.so", "-Wl,-rpath,$ORIGIN",
            f"-L{troot}/lib", "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch"]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True, cwd=CSRC)
+    with _build_lock():
+        if force or not fresh():   # another process may have built it while this one waited
+            _compile(cmd, OPS_LIB_PATH, verbose)
     return OPS_LIB_PATH
 
 
@@ -72,9 +109,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     extra = os.environ.get("SFM_EXTRA_HIPCC_FLAGS", "").split()   # experiment builds (e.g. -DSFM_SCORE_E_IN_VGPR=1)
     cmd = [hipcc] + FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True, cwd=CSRC)
+    with _build_lock():
+        if force or _stale():   # another process may have built it while this one waited
+            _compile(cmd, LIB_PATH, verbose)
     return LIB_PATH
 
 
