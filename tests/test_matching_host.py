@@ -74,6 +74,37 @@ def test_empty_inputs():
     assert matching.match_brute_force(fa, [], lambda a, b: 0.0, validation_strategies={ratio, cross}) == []
 
 
+def test_crosscheck_with_nan_scores():
+    """A NaN best score: the reference's cross-check compares `Match` objects with `==` (matching.py:113-117), and a
+    claimant compared with itself is equal through the identity shortcut of tuple comparison even when its score is
+    NaN — the row stays; a NaN claimant is never displaced (`nan > x` is false, :105-110)."""
+    import math
+
+    fa = [Feature(0.0, 0.0), Feature(1.0, 0.0), Feature(2.0, 0.0)]
+    fb = [Feature(0.0, 1.0), Feature(1.0, 1.0)]
+    nan = float("nan")
+    table = {0: {0: nan, 1: 5.0}, 1: {0: 1.0, 1: 7.0}, 2: {0: 9.0, 1: 2.0}}
+    got = matching.match_brute_force(fa, fb, _table_function(fa, fb, table),
+                                     validation_strategies=matching.ValidationStrategy.CROSSCHECK)
+    # literal restatement of the reference's two steps on heaps of Match objects
+    import heapq
+    heaps = []
+    for a in range(3):
+        heap = []
+        for b in range(2):
+            heapq.heappush(heap, matching.Match(a_index=a, b_index=b, match_score=table[a][b]))
+        heaps.append(heap)
+    best_for_b = {}
+    for heap in heaps:
+        m = heap[0]
+        if m.b_index not in best_for_b or best_for_b[m.b_index].match_score > m.match_score:
+            best_for_b[m.b_index] = m
+    want = [heap[0] for heap in heaps if heap[0] == best_for_b[heap[0].b_index]]
+    key = lambda m: (m.a_index, m.b_index, "nan" if math.isnan(m.match_score) else m.match_score)  # noqa: E731
+    assert [key(m) for m in got] == [key(m) for m in want]
+    assert any(math.isnan(m.match_score) for m in want)   # the case is exercised
+
+
 def test_score_function_recognition():
     ia, ib = np.zeros((20, 30)), np.ones((20, 30))
     spec = _device_score_spec(ImagePairScore(ia, ib, ncc.calculate_ncc, 9))
