@@ -246,5 +246,5 @@ class ShardedRansac:
         else:
             E = self.win_E.cpu().numpy().reshape(3, 3)
             sample = self.win_S.cpu().numpy().reshape(8).astype(np.int64)
-        return ShardedOutcome(best, float(rec.best_err), E, sample, device.checked_mask(self.ws.mask.cpu().numpy()[0]),
-                              n_flagged, first)
+        mask = self.device_api.checked_mask(self.ws.mask.cpu().numpy()[0])
+        return ShardedOutcome(best, float(rec.best_err), E, sample, mask, n_flagged, first)

@@ -296,6 +296,54 @@ def test_product_code_does_not_import_the_oracle():
     assert "/root/reference" not in bench
 
 
+def test_no_function_reads_an_undefined_global():
+    """GPU-only code paths cannot run in the build container: at least every global a function reads must exist at
+    module level (a name imported locally in one method and used in another is the typical slip)."""
+    import ast
+    import builtins
+    import dis
+    import types
+
+    def module_level_names(tree):
+        names = set(dir(builtins)) | {"__file__", "__name__", "__doc__", "__spec__", "__package__", "__builtins__"}
+        stack = [(tree, True)]
+        while stack:
+            node, top = stack.pop()
+            for child in ast.iter_child_nodes(node):
+                inner = top and not isinstance(child, (ast.FunctionDef, ast.AsyncFunctionDef, ast.ClassDef, ast.Lambda))
+                if top:
+                    if isinstance(child, (ast.FunctionDef, ast.AsyncFunctionDef, ast.ClassDef)):
+                        names.add(child.name)
+                    elif isinstance(child, (ast.Import, ast.ImportFrom)):
+                        names.update((a.asname or a.name).split(".")[0] for a in child.names)
+                    elif isinstance(child, ast.Name) and isinstance(child.ctx, ast.Store):
+                        names.add(child.id)
+                stack.append((child, inner))
+        return names
+
+    def functions(code):
+        for const in code.co_consts:
+            if isinstance(const, types.CodeType):
+                is_class_body = "__qualname__" in const.co_names and "__module__" in const.co_names
+                if not is_class_body:
+                    yield const
+                yield from functions(const)
+
+    files = [os.path.join(REPO, "bench.py"), os.path.join(REPO, "__graft_entry__.py"), os.path.join(REPO, "main.py")]
+    for top in ("structure_from_motion_amd", "lib", "apps", "tools"):
+        for root, _, names in os.walk(os.path.join(REPO, top)):
+            files += [os.path.join(root, f) for f in names if f.endswith(".py")]
+    problems = []
+    for path in files:
+        source = open(path).read()
+        known = module_level_names(ast.parse(source, path))
+        for fn in functions(compile(source, path, "exec")):
+            for ins in dis.get_instructions(fn):
+                if ins.opname in ("LOAD_GLOBAL", "LOAD_NAME") and ins.argval not in known:
+                    problems.append(f"{os.path.relpath(path, REPO)}: {fn.co_name} reads {ins.argval}")
+    assert not problems, problems
+
+
 # ------------------------------------------------------------------------------------------------------
 # boundary value types (reference a20)
 # ------------------------------------------------------------------------------------------------------
