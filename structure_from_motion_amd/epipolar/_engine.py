@@ -4,6 +4,7 @@ from __future__ import annotations
 import contextlib
 import copy
 import gc
+import logging
 import os
 import random
 import warnings
@@ -119,6 +120,9 @@ def local_optimisation_rounds() -> int:
     return rounds
 
 
+logger = logging.getLogger(__name__)   # one line per call, never per hypothesis
+
+
 def ransac_feature_pairs(data, camera_matrix, threshold, min_extra, aggregation, iterations):
     """Device route of fit_with_ransac for (Feature, Feature) pairs.  Returns (E or None, inlier pairs).
 
@@ -154,6 +158,10 @@ def ransac_feature_pairs(data, camera_matrix, threshold, min_extra, aggregation,
             "More than one eigenvalue of Y.T @ Y is small. Cannot confidently estimate"
             f" fundamental matrix. (hypothesis {outcome.first_flagged}, {outcome.n_flagged} in total)"
         )
+    if logger.isEnabledFor(logging.DEBUG):
+        logger.debug("RANSAC-E: %d matches x %d hypotheses (%s sampler): best hypothesis %d, %d extra inliers, "
+                     "aggregated error %.6g, %d degenerate sample(s)", n, iterations, sampler, outcome.best_h,
+                     outcome.extra_inliers, outcome.error, outcome.n_flagged)
     if outcome.best_h < 0:
         return None, []
     rounds = local_optimisation_rounds()

@@ -167,14 +167,20 @@ def test_ransac_degenerate_sample_policy(golden, monkeypatch):
         epipolar_ransac.estimate_essential_mat_with_ransac(g["K"], fa, fb, matches, 0.01, max_iterations=3)
 
 
-def test_ransac_philox_sampler(monkeypatch):
+def test_ransac_philox_sampler(monkeypatch, caplog):
     monkeypatch.setenv("SFM_SAMPLER", "philox")
     monkeypatch.setenv("SFM_SEED", "5")
     n, h = 400, 300
     pa, pb, K, *_ = orc.synthetic_two_view(n, seed=6)
     matches = eight_point.create_trivial_matches(n)
-    e, pairs = epipolar_ransac.estimate_essential_mat_with_ransac(
-        K, feats(pa), feats(pb), matches, 1.5e-6, min_num_extra_inliers=10, max_iterations=h)
+    import logging
+
+    with caplog.at_level(logging.DEBUG, logger="structure_from_motion_amd.epipolar._engine"):
+        e, pairs = epipolar_ransac.estimate_essential_mat_with_ransac(
+            K, feats(pa), feats(pb), matches, 1.5e-6, min_num_extra_inliers=10, max_iterations=h)
+    # one log line per call, never per hypothesis
+    lines = [r.getMessage() for r in caplog.records if r.name.endswith("epipolar._engine")]
+    assert len(lines) == 1 and f"{n} matches x {h} hypotheses (philox sampler)" in lines[0], lines
     corr = orc.pack_correspondences(orc.to_normalized_image_coords(pa, K), orc.to_normalized_image_coords(pb, K))
     ref = orc.ransac_essential(corr, orc.philox_sample_table(5, 0, h, n), 1.5e-6, 10, orc.RMS)
     assert rel(e, ref["E"]) <= 1e-6
