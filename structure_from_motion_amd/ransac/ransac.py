@@ -101,7 +101,12 @@ def _host_loop(data, k, model_fitter, inlier_scorer, threshold, min_extra, metho
     """Host driver for arbitrary callables (reference ransac.py:55-86)."""
     pool = copy.deepcopy(data)
     best_model, best_inliers, best_error = None, [], inf
-    for _ in range(iterations):
+    steps = range(iterations)
+    if os.environ.get("SFM_PROGRESS", "0") not in ("", "0"):   # the reference always draws this bar (ransac.py:61)
+        from tqdm import tqdm
+
+        steps = tqdm(steps)
+    for _ in steps:
         random.shuffle(pool)
         sample, rest = pool[:k], pool[k:]
         model = model_fitter(sample)
