@@ -60,7 +60,7 @@ constexpr int kHypPerWave = 4;
 #if SFM_WAVE_STAMPS
 __device__ unsigned long long g_wave_stamps[4 * 65536];  // begin, end, first hypothesis, exact-tier batches; read by nothing but sfm_debug_read_wave_stamps
 #endif
-constexpr int kRing = 256;  // entries per (wave, hypothesis) ring; <= 63 left + 128 pushed per step; drained in groups of 64
+constexpr int kRing = 256;  // entries per (wave, hypothesis) survivor stack; <= 63 left + 128 pushed per step; popped in groups of 64
 
 // ------------------------------------------------------------------------------------------------
 // Epilogue shared by both kernels: fixed-order wave reduction + sample fix-up + store.
@@ -452,7 +452,10 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
     const double* __restrict__ E, const int32_t* __restrict__ S, int h_count, double thr, double a_scale,
     const int32_t* __restrict__ order, int32_t* __restrict__ cnt, double* __restrict__ s1,
     double* __restrict__ s2, int batch, int blocks_per_pair, int prep_blocks) {
-    __shared__ __attribute__((aligned(1024))) int32_t ring[256 / kWave][HPW][kRing];  // each ring = one aligned KiB
+    // survivors' indices, one stack per (wave, hypothesis): pushes append at the top, the exact tier pops the top 64 —
+    // which 64 of the queued points a batch takes does not matter (only the summation order depends on it, and that is
+    // fixed), and a stack needs neither a wrap-around nor a second cursor
+    __shared__ int32_t ring[256 / kWave][HPW][kRing];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     // XCD-aware block -> (pair, block of the pair) map.  Workgroups are dealt round-robin over the 8 XCDs by linear
@@ -474,6 +477,7 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
     if (h0 >= h_count) return;
 #if SFM_WAVE_STAMPS
     const unsigned long long stamp_begin = __builtin_amdgcn_s_memrealtime();
+    int stamp_batches = 0;  // exact-tier batches of the wave's first hypothesis
 #endif
     const int64_t b = pair;
     // slot -> hypothesis index (longest-first order from the pre-pass, or the identity)
@@ -544,14 +548,13 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
 
     int c[HPW];
     double a1[HPW], a2[HPW];
-    int head[HPW], tail[HPW];  // wave-uniform ring cursors (monotone; slots are taken modulo kRing)
+    int top[HPW];  // wave-uniform stack heights
 #pragma unroll
     for (int k = 0; k < HPW; ++k) {
         c[k] = 0;
         a1[k] = 0.0;
         a2[k] = 0.0;
-        head[k] = 0;
-        tail[k] = 0;
+        top[k] = 0;
     }
 
     // tier 2: exact fp64 evaluation of `count` (<= 64) queued points of hypothesis k
@@ -563,48 +566,48 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
 #pragma unroll
         for (int j = 0; j < 9; ++j) e[j] = Eb[(int64_t)h * 9 + j];
         const bool active = lane < count;
-        const int slot = (head[k] + lane) & (kRing - 1);
-        const int idx = active ? ring[wave_in_block][k][slot] : 0;
+        const int idx = active ? ring[wave_in_block][k][top[k] - count + lane] : 0;
         const Corr p = pts[idx];
         const double sed = sfm::sed_value(e, p.xa, p.ya, p.xb, p.yb);
         const bool ok = active && (sed <= thr);
         c[k] += ok ? 1 : 0;
         a1[k] += ok ? sed : 0.0;
         a2[k] += ok ? sed * sed : 0.0;
-        head[k] += count;
+        top[k] -= count;
+#if SFM_WAVE_STAMPS
+        if (k == 0) ++stamp_batches;
+#endif
     };
 
-    // Append the lanes flagged in `mask` to the ring of hypothesis k: lane l of the mask writes `i` to slot
-    // (tail + number of flagged lanes below l) mod kRing.  Hand-written: the mask itself becomes the exec mask for the
-    // four address instructions and the LDS write, so no per-lane predicate has to be rebuilt from it (the compiled
-    // form spends three more VALU instructions per push on that, ~9 % of the kernel's VALU issue; a push happens for
-    // most (chunk pair, hypothesis) combinations even when the hypothesis fits nothing).
-    static_assert(kRing == 256, "slot mask in the inline assembly");
-    unsigned ring_base[HPW];  // LDS byte address of each hypothesis' ring (wave-uniform, kept in a VGPR: the
-                              // and-or below already spends its one scalar operand on the wrap mask)
+    // Push the lanes flagged in `mask` onto the stack of hypothesis k: lane l of the mask writes `i` to slot
+    // top + (number of flagged lanes below l).  Hand-written: the mask itself becomes the exec mask for the three address
+    // instructions and the LDS write, so no per-lane predicate has to be rebuilt from it (the compiled form spends three
+    // more VALU instructions per push on that; a push happens for most (chunk pair, hypothesis) combinations even when
+    // the hypothesis fits nothing).  The byte address of the top slot is scalar (stack base + 4 top), so the slot
+    // address is ONE shift-add on the prefix count.
+    static_assert(kRing >= (kWave - 1) + 2 * kWave, "a step pushes up to 128 survivors on top of at most 63 left over");
+    unsigned ring_base[HPW];  // LDS byte address of each hypothesis' stack (wave-uniform -> scalar registers)
 #pragma unroll
     for (int k = 0; k < HPW; ++k)
-        ring_base[k] = (unsigned)(size_t)(__attribute__((address_space(3))) int32_t*)&ring[wave_in_block][k][0];
+        ring_base[k] = __builtin_amdgcn_readfirstlane(
+            (unsigned)(size_t)(__attribute__((address_space(3))) int32_t*)&ring[wave_in_block][k][0]);
     auto push = [&](int k, unsigned long long mask, int i) __attribute__((always_inline)) {
         const unsigned lo = (unsigned)mask, hi = (unsigned)(mask >> 32);
-        const unsigned tail4 = (unsigned)tail[k] << 2;  // scalar
+        const unsigned top_address = ring_base[k] + ((unsigned)top[k] << 2);  // scalar
         unsigned scratch;
         unsigned long long saved;
-        // slot byte address = ring base | ((4 tail + 4 rank) & 0x3fc): the ring is 1 KiB-aligned, so OR is ADD
         asm volatile(
             "s_mov_b64 %[saved], exec\n\t"
             "s_mov_b64 exec, %[mask]\n\t"
             "v_mbcnt_lo_u32_b32 %[t], %[lo], 0\n\t"
             "v_mbcnt_hi_u32_b32 %[t], %[hi], %[t]\n\t"
-            "v_lshl_add_u32 %[t], %[t], 2, %[tail4]\n\t"
-            "v_and_or_b32 %[t], %[t], %[wrap], %[base]\n\t"
+            "v_lshl_add_u32 %[t], %[t], 2, %[top_address]\n\t"
             "ds_write_b32 %[t], %[index]\n\t"
             "s_mov_b64 exec, %[saved]"
             : [t] "=&v"(scratch), [saved] "=&s"(saved)
-            : [mask] "s"(mask), [lo] "s"(lo), [hi] "s"(hi), [tail4] "s"(tail4), [wrap] "s"(0x3fcu),
-              [base] "v"(ring_base[k]), [index] "v"(i)
+            : [mask] "s"(mask), [lo] "s"(lo), [hi] "s"(hi), [top_address] "s"(top_address), [index] "v"(i)
             : "memory");
-        tail[k] += (int)__popcll(mask);  // scalar arithmetic on a wave-uniform mask
+        top[k] += (int)__popcll(mask);  // scalar arithmetic on a wave-uniform mask
     };
 
     // Steady state: two full 64-point chunks per step (no validity masks), so the scalar bookkeeping and
@@ -624,7 +627,7 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
                 push(k, m0, i0);
                 push(k, m1, i0 + kWave);
                 __builtin_amdgcn_wave_barrier();
-                while (tail[k] - head[k] >= kWave) drain(k, kWave);  // wave-uniform, at most twice
+                while (top[k] >= kWave) drain(k, kWave);  // wave-uniform, at most twice
             }
         }
     };
@@ -639,7 +642,7 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
             if (mask != 0ull) {
                 push(k, mask, i);
                 __builtin_amdgcn_wave_barrier();
-                if (tail[k] - head[k] >= kWave) drain(k, kWave);
+                if (top[k] >= kWave) drain(k, kWave);
             }
         }
     };
@@ -708,7 +711,7 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
 #pragma unroll
     for (int k = 0; k < HPW; ++k) {
         const int h = hyp[k];
-        const int left = tail[k] - head[k];   // 0..63, wave-uniform
+        const int left = top[k];   // 0..63, wave-uniform
         double e[9];
 #pragma unroll
         for (int j = 0; j < 9; ++j) e[j] = Eb[(int64_t)h * 9 + j];
@@ -717,7 +720,7 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
             const bool queued = lane < left;
             const bool sample = !queued && lane < left + 8;
             int idx = 0;
-            if (queued) idx = ring[wave_in_block][k][(head[k] + lane) & (kRing - 1)];
+            if (queued) idx = ring[wave_in_block][k][lane];
             if (sample) idx = Sb[(int64_t)h * 8 + (lane - left)];
             const Corr p = pts[idx];
             const double sed = sfm::sed_value(e, p.xa, p.ya, p.xb, p.yb);
@@ -729,7 +732,10 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
             c[k] += queued ? (in ? 1 : 0) : ((sample && in) ? -1 : 0);
             a1[k] += add ? sed : 0.0;
             a2[k] += add ? sed * sed : 0.0;
-            head[k] += left;
+            top[k] = 0;
+#if SFM_WAVE_STAMPS
+            if (k == 0 && left > 0) ++stamp_batches;
+#endif
             if (slot_valid[k]) {  // wave-uniform: this slot exists
                 const int ck = sfm::wave_sum(c[k]);
                 const double s1k = sfm::wave_sum(a1[k]);
@@ -751,7 +757,7 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
         g_wave_stamps[4 * wave] = stamp_begin;
         g_wave_stamps[4 * wave + 1] = __builtin_amdgcn_s_memrealtime();
         g_wave_stamps[4 * wave + 2] = (unsigned long long)hyp[0];
-        g_wave_stamps[4 * wave + 3] = (unsigned long long)(head[0] + 63) / 64;
+        g_wave_stamps[4 * wave + 3] = (unsigned long long)stamp_batches;
     }
 #endif
 }
