@@ -9,8 +9,8 @@
 //   score_sed_filtered_kernel  two tiers.  Tier 1 evaluates a CONSERVATIVE fp32 lower bound of the
 //                              SED for every (hypothesis, point) and rejects the pair only when the
 //                              bound proves sed > thr.  Survivors (about the inlier fraction, a few
-//                              percent for a typical hypothesis) are compacted through a per-wave LDS
-//                              ring and tier 2 evaluates them with exactly the fp64 routine of the
+//                              percent for a typical hypothesis) are compacted onto a per-wave LDS
+//                              stack and tier 2 evaluates them with exactly the fp64 routine of the
 //                              exact kernel.  Every point whose fp64 SED could be <= thr reaches
 //                              tier 2, so counts and inlier decisions are identical to the exact
 //                              kernel bit for bit; only the summation order of the two sums differs.
@@ -60,7 +60,7 @@ constexpr int kHypPerWave = 4;
 #if SFM_WAVE_STAMPS
 __device__ unsigned long long g_wave_stamps[4 * 65536];  // begin, end, first hypothesis, exact-tier batches; read by nothing but sfm_debug_read_wave_stamps
 #endif
-constexpr int kRing = 256;  // entries per (wave, hypothesis) survivor stack; <= 63 left + 128 pushed per step; popped in groups of 64
+constexpr int kStack = 256;  // entries per (wave, hypothesis) survivor stack; <= 63 left + 128 pushed per step; popped in groups of 64
 
 // ------------------------------------------------------------------------------------------------
 // Epilogue shared by both kernels: fixed-order wave reduction + sample fix-up + store.
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
     // survivors' indices, one stack per (wave, hypothesis): pushes append at the top, the exact tier pops the top 64 —
     // which 64 of the queued points a batch takes does not matter (only the summation order depends on it, and that is
     // fixed), and a stack needs neither a wrap-around nor a second cursor
-    __shared__ int32_t ring[256 / kWave][HPW][kRing];
+    __shared__ int32_t stack[256 / kWave][HPW][kStack];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     // XCD-aware block -> (pair, block of the pair) map.  Workgroups are dealt round-robin over the 8 XCDs by linear
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
 #pragma unroll
         for (int j = 0; j < 9; ++j) e[j] = Eb[(int64_t)h * 9 + j];
         const bool active = lane < count;
-        const int idx = active ? ring[wave_in_block][k][top[k] - count + lane] : 0;
+        const int idx = active ? stack[wave_in_block][k][top[k] - count + lane] : 0;
         const Corr p = pts[idx];
         const double sed = sfm::sed_value(e, p.xa, p.ya, p.xb, p.yb);
         const bool ok = active && (sed <= thr);
@@ -585,15 +585,15 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
     // more VALU instructions per push on that; a push happens for most (chunk pair, hypothesis) combinations even when
     // the hypothesis fits nothing).  The byte address of the top slot is scalar (stack base + 4 top), so the slot
     // address is ONE shift-add on the prefix count.
-    static_assert(kRing >= (kWave - 1) + 2 * kWave, "a step pushes up to 128 survivors on top of at most 63 left over");
-    unsigned ring_base[HPW];  // LDS byte address of each hypothesis' stack (wave-uniform -> scalar registers)
+    static_assert(kStack >= (kWave - 1) + 2 * kWave, "a step pushes up to 128 survivors on top of at most 63 left over");
+    unsigned stack_base[HPW];  // LDS byte address of each hypothesis' stack (wave-uniform -> scalar registers)
 #pragma unroll
     for (int k = 0; k < HPW; ++k)
-        ring_base[k] = __builtin_amdgcn_readfirstlane(
-            (unsigned)(size_t)(__attribute__((address_space(3))) int32_t*)&ring[wave_in_block][k][0]);
+        stack_base[k] = __builtin_amdgcn_readfirstlane(
+            (unsigned)(size_t)(__attribute__((address_space(3))) int32_t*)&stack[wave_in_block][k][0]);
     auto push = [&](int k, unsigned long long mask, int i) __attribute__((always_inline)) {
         const unsigned lo = (unsigned)mask, hi = (unsigned)(mask >> 32);
-        const unsigned top_address = ring_base[k] + ((unsigned)top[k] << 2);  // scalar
+        const unsigned top_address = stack_base[k] + ((unsigned)top[k] << 2);  // scalar
         unsigned scratch;
         unsigned long long saved;
         asm volatile(
@@ -720,7 +720,7 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
             const bool queued = lane < left;
             const bool sample = !queued && lane < left + 8;
             int idx = 0;
-            if (queued) idx = ring[wave_in_block][k][lane];
+            if (queued) idx = stack[wave_in_block][k][lane];
             if (sample) idx = Sb[(int64_t)h * 8 + (lane - left)];
             const Corr p = pts[idx];
             const double sed = sfm::sed_value(e, p.xa, p.ya, p.xb, p.yb);
