@@ -612,7 +612,7 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
 
     // Steady state: two full 64-point chunks per step (no validity masks), so the scalar bookkeeping and
     // the drain test are paid once per 128 evaluations of a hypothesis.
-    auto process_pair = [&](const float4 p0, const float4 p1, int i0) __attribute__((always_inline)) {
+    auto process_pair = [&](const float4 p0, const float4 p1, int i0, int i1) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < HPW; ++k) {
             unsigned long long m0, m1;  // survivors of the two chunks
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
             }
             if ((m0 | m1) != 0ull) {  // wave-uniform
                 push(k, m0, i0);
-                push(k, m1, i0 + kWave);
+                push(k, m1, i1);
                 __builtin_amdgcn_wave_barrier();
                 while (top[k] >= kWave) drain(k, kWave);  // wave-uniform, at most twice
             }
@@ -649,15 +649,19 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
 
     const int full_chunks = n / kWave;
     const int pairs = full_chunks / 2;
-    // One hypothesis per wave is the kernel of small launches (at most two generations of waves): whenever a SIMD holds
-    // few of them — the waves that could not start with the first generation — a step costs one L2 round trip for the
-    // points (~800 cycles against ~300 of work: profiles/r02/README.md, small_pass_timeline.log).  Two steps of point
-    // loads in flight instead of one; the stages rotate by unrolling, not by register moves.
-    constexpr int kDepth = SFM_SCORE_PREFETCH_DEPTH;
-    if constexpr (HPW == 1 && kDepth > 1) {
+    // The point loads run kDepth steps ahead of the step being processed, in kDepth + 1 register stages that rotate by
+    // unrolling, not by register moves (the plain "p = q" loop spent four 64-bit moves per step on that).  One
+    // hypothesis per wave is the kernel of small launches (at most two generations of waves): whenever a SIMD holds few of
+    // them — the waves that could not start with the first generation — a step costs one L2 round trip for the points
+    // (~800 cycles against ~300 of work: profiles/r02/README.md, small_pass_timeline.log), so there two steps are in
+    // flight; with more hypotheses per wave one step ahead is enough and the registers are needed elsewhere.
+    constexpr int kDepth = HPW == 1 ? SFM_SCORE_PREFETCH_DEPTH : 1;
+    {
         constexpr int kStages = kDepth + 1;
+        // a prefetch reads up to kDepth steps past a pair's last full step: inside the workspace (the next pair's
+        // points, or the kPointsPad bytes behind the last pair's) and never used
         static_assert(2048 * kDepth <= kPointsPad, "the prefetch runs this far past a pair's last full step");
-        const float4* __restrict__ next = pts32 + lane;
+        const float4* __restrict__ next = pts32 + lane;  // per-lane cursor: one 64-bit add per step, no index clamping
         float4 stage[kStages][2];
 #pragma unroll
         for (int d = 0; d < kDepth; ++d) {  // reads inside the workspace even when pairs < kDepth (points, then the pad)
@@ -665,7 +669,7 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
             stage[d][1] = next[kWave];
             next += 2 * kWave;
         }
-        int i0 = lane;
+        int i0 = lane, i1 = lane + kWave;  // both chunks' point indices are carried: one add each per step, not one per hypothesis
         int pr = 0;
         for (; pr + kStages <= pairs; pr += kStages) {
 #pragma unroll
@@ -673,31 +677,18 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
                 stage[(u + kDepth) % kStages][0] = next[0];
                 stage[(u + kDepth) % kStages][1] = next[kWave];
                 next += 2 * kWave;
-                process_pair(stage[u][0], stage[u][1], i0);
+                process_pair(stage[u][0], stage[u][1], i0, i1);
                 i0 += 2 * kWave;
+                i1 += 2 * kWave;
             }
         }
 #pragma unroll
         for (int u = 0; u < kDepth; ++u) {  // the last pairs - pr <= kDepth steps are loaded already
             if (pr + u < pairs) {
-                process_pair(stage[u][0], stage[u][1], i0);
+                process_pair(stage[u][0], stage[u][1], i0, i1);
                 i0 += 2 * kWave;
+                i1 += 2 * kWave;
             }
-        }
-    } else if (pairs > 0) {
-        const float4* __restrict__ next = pts32 + lane;  // per-lane cursor: one 64-bit add per step, no index clamping
-        float4 p0 = next[0], p1 = next[kWave];
-        int i0 = lane;
-        for (int pr = 0; pr < pairs; ++pr) {
-            // prefetch the next pair; the last step reads up to 3 KiB past the pair's points, inside the workspace
-            // (the next pair's points, or the kPointsPad bytes behind the last pair's) and never uses them
-            next += 2 * kWave;
-            const float4 q0 = next[0];
-            const float4 q1 = next[kWave];
-            process_pair(p0, p1, i0);
-            p0 = q0;
-            p1 = q1;
-            i0 += 2 * kWave;
         }
     }
     for (int chunk = pairs * 2; chunk * kWave < n; ++chunk) {  // at most two iterations
