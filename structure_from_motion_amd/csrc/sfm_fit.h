@@ -91,6 +91,7 @@ SFM_DEVICE int null_vector_of_yty(double (&a)[45], double (&f)[9], double (&w)[9
 SFM_DEVICE int null_vector_of_design(const double (&xa)[8], const double (&ya)[8], const double (&xb)[8],
                                      const double (&yb)[8], bool need_second, double (&f)[9], double& second,
                                      double (&sq)[8]) {
+#pragma clang fp contract(fast)   // QR, back substitution: no reference rounding to reproduce (sfm_math.h, hestenes_rotate)
     double col[8][9];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -241,6 +242,7 @@ SFM_DEVICE void smallest_eigenvector_psd9(const double (&a)[45], double (&x)[9])
 // rank-2 enforcement (eight_point.py:430-446): drop the smallest singular direction of f (row-major 3x3)
 // `ratio2` (optional) receives (sigma_3 / sigma_1)^2 of f: how far the unconstrained estimate was from rank 2.
 SFM_DEVICE void enforce_rank2(const double (&f)[9], double (&fr)[3][3], double* ratio2 = nullptr) {
+#pragma clang fp contract(fast)
     double g[3][3], vv[3][3];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
@@ -265,6 +267,7 @@ SFM_DEVICE void enforce_rank2(const double (&f)[9], double (&fr)[3][3], double* 
 
 // E = T2^T F T1 (eight_point.py:163) for forward Hartley transforms t1 (first image), t2 (second image)
 SFM_DEVICE void unnormalise(const double (&fr)[3][3], const Hartley& t1, const Hartley& t2, double (&e)[9]) {
+#pragma clang fp contract(fast)
     const double tx1 = -t1.scale * t1.cx, ty1 = -t1.scale * t1.cy;
     const double tx2 = -t2.scale * t2.cx, ty2 = -t2.scale * t2.cy;
     double m[3][3];

@@ -196,6 +196,9 @@ SFM_DEVICE void jacobi_cs_gram(double alpha, double beta, double gamma, bool rot
 // --------------------------------------------------------------------------------------------------
 template <int N, int I, int J>
 SFM_DEVICE bool hestenes_rotate(double (&g)[N][N], double (&v)[N][N]) {
+    // No reference rounding to reproduce in here (the result is a converged iteration): let multiplies and adds fuse.
+    // The translation unit is compiled with -ffp-contract=off for the NumPy-order arithmetic of the SED / Hartley code.
+#pragma clang fp contract(fast)
     double alpha = 0.0, beta = 0.0, gamma = 0.0;
 #pragma unroll
     for (int k = 0; k < N; ++k) {
@@ -247,6 +250,7 @@ SFM_DEVICE void hestenes_svd(double (&g)[N][N], double (&v)[N][N]) {
 // the singular values.
 template <int N, int I, int J>
 SFM_DEVICE bool hestenes_rotate_novec(double (&g)[N][N]) {
+#pragma clang fp contract(fast)
     double alpha = 0.0, beta = 0.0, gamma = 0.0;
 #pragma unroll
     for (int k = 0; k < N; ++k) {
@@ -298,6 +302,8 @@ SFM_DEVICE void singular_values_sq(double (&g)[N][N], double (&sq)[N]) {
 // On return col[j][i], i <= j, holds R(i, j); nullvec = Q e_9 (unit norm).
 // --------------------------------------------------------------------------------------------------
 SFM_DEVICE void qr_null_vector(double (&col)[8][9], double (&rdiag)[8], double (&nullvec)[9]) {
+    // dot products and rank-one updates as fused multiply-adds: half the instructions, and one rounding less each
+#pragma clang fp contract(fast)
     // Reflection J: H = I - beta v v^T with v = x - alpha e_J kept in col[J][J..8]; alpha = R(J,J) goes to rdiag.
     // alpha takes the sign opposite to x_J, so v_J = x_J - alpha has no cancellation.
     double beta[8];
@@ -352,6 +358,7 @@ SFM_DEVICE void qr_null_vector(double (&col)[8][9], double (&rdiag)[8], double (
 // --------------------------------------------------------------------------------------------------
 template <int I, int J>
 SFM_DEVICE bool rotate_rows4(double (&g)[4][4]) {
+#pragma clang fp contract(fast)   // converged iterations / tolerance-checked: multiplies and adds may fuse
     double alpha = 0.0, beta = 0.0, gamma = 0.0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -379,6 +386,7 @@ SFM_DEVICE bool rotate_rows4(double (&g)[4][4]) {
 // of the C5 batch still fell through to Jacobi).  Returns false if they did not converge (rays nearly parallel, or
 // gross outliers): the caller then uses the Jacobi route for the whole wave.
 SFM_DEVICE bool null_vector4_qr(const double rows[4][4], double x[4]) {
+#pragma clang fp contract(fast)   // converged iterations / tolerance-checked: multiplies and adds may fuse
     double r[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -453,6 +461,7 @@ SFM_DEVICE bool null_vector4_qr(const double rows[4][4], double x[4]) {
 }
 
 SFM_DEVICE void null_vector4_jacobi(const double rows[4][4], double x[4]) {
+#pragma clang fp contract(fast)   // converged iterations / tolerance-checked: multiplies and adds may fuse
     // One-sided Jacobi on the ROWS of A.  Orthogonalising rows is a left multiplication by an orthogonal matrix
     // (A = U S V^T  =>  U^T A = S V^T), so at convergence the rows are sigma_k v_k^T: nothing has to be
     // accumulated.  The wanted vector v_4 is then formed as the 4-D cross product of the three dominant rows,
