@@ -278,6 +278,16 @@ SFM_DEVICE bool hestenes_sweep_novec_from(double (&g)[N][N]) {
     return any;
 }
 
+// one-sided Jacobi without V: on return the columns of g are orthogonal (g = G V for some orthogonal V)
+template <int N>
+SFM_DEVICE void hestenes_orthogonalise(double (&g)[N][N]) {
+#pragma unroll 1
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        const bool rotated = hestenes_sweep_novec_from<N, 0, 1>(g);
+        if (!__any(rotated)) break;
+    }
+}
+
 // squared singular values of the NxN matrix whose columns are g[col][.] (g is destroyed)
 template <int N>
 SFM_DEVICE void singular_values_sq(double (&g)[N][N], double (&sq)[N]) {
