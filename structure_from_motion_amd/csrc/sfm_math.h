@@ -3,7 +3,9 @@
 // Everything here is per-lane register math: all array indices are compile-time constants after
 // unrolling, so the small matrices live in VGPRs (no scratch).  The translation unit is compiled with
 // -ffp-contract=off: every multiply and add rounds separately, matching the NumPy elementwise
-// semantics of the reference; fused operations are written explicitly with fma() where wanted.
+// semantics of the reference; fused operations are written explicitly with fma() where wanted, and the routines
+// that have no reference rounding to reproduce (QR, Jacobi rotations, DLT null vectors: converged iterations checked
+// by tolerance) re-enable contraction for their own bodies with `#pragma clang fp contract(fast)`.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

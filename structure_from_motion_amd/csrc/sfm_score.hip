@@ -76,8 +76,9 @@ SFM_DEVICE void finish_hypothesis(const Corr* __restrict__ pts, const int32_t* _
         const double sed = sfm::sed_value(e, p.xa, p.ya, p.xb, p.yb);
         const bool counted = sed <= thr;  // already in (c, a1, a2)
         c += counted ? -1 : 0;
-        a1 += counted ? 0.0 : sed;  // NaN / inf propagate: such a model never wins
-        a2 += counted ? 0.0 : sed * sed;
+        const double extra = counted ? 0.0 : sed;  // NaN / inf propagate: such a model never wins
+        a1 += extra;
+        a2 += extra * extra;   // the square of the masked value: one select instead of two, same bits
     }
     const int ck = sfm::wave_sum(c);
     const double s1k = sfm::wave_sum(a1);
@@ -129,8 +130,9 @@ __global__ __launch_bounds__(256) void score_sed_exact_kernel(
             const double sed = sfm::sed_value(e[k], p.xa, p.ya, p.xb, p.yb);
             const bool ok = sed <= thr;
             c[k] += ok ? 1 : 0;
-            a1[k] += ok ? sed : 0.0;
-            a2[k] += ok ? sed * sed : 0.0;
+            const double kept = ok ? sed : 0.0;   // masked once; its square is the masked square (same bits, one select less)
+            a1[k] += kept;
+            a2[k] += kept * kept;
         }
     }
 #pragma unroll
@@ -571,8 +573,9 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
         const double sed = sfm::sed_value(e, p.xa, p.ya, p.xb, p.yb);
         const bool ok = active && (sed <= thr);
         c[k] += ok ? 1 : 0;
-        a1[k] += ok ? sed : 0.0;
-        a2[k] += ok ? sed * sed : 0.0;
+        const double kept = ok ? sed : 0.0;   // masked once; its square is the masked square (same bits, one select less)
+        a1[k] += kept;
+        a2[k] += kept * kept;
         top[k] -= count;
 #if SFM_WAVE_STAMPS
         if (k == 0) ++stamp_batches;
@@ -721,8 +724,9 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
             // NaN / inf propagate: such a model never wins
             const bool add = queued ? in : (sample && !in);
             c[k] += queued ? (in ? 1 : 0) : ((sample && in) ? -1 : 0);
-            a1[k] += add ? sed : 0.0;
-            a2[k] += add ? sed * sed : 0.0;
+            const double kept = add ? sed : 0.0;
+            a1[k] += kept;
+            a2[k] += kept * kept;
             top[k] = 0;
 #if SFM_WAVE_STAMPS
             if (k == 0 && left > 0) ++stamp_batches;
