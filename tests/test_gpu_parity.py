@@ -819,6 +819,24 @@ def test_filtered_score_equals_exact(dev, n, h, thr):
         np.testing.assert_allclose(filt[2], s2_o, rtol=1e-13)
 
 
+@pytest.mark.parametrize("hpw", [1, 2, 4])
+def test_filtered_score_every_loop_remainder(dev, monkeypatch, hpw):
+    """Every hypotheses-per-wave variant of the two-tier kernel (forced with SFM_SCORE_HPW: small launches would always
+    pick one per wave) over point counts that hit each exit of the staged point-load loop — 0, 1, 2, ... full steps of
+    128 (the loop is unrolled over 2 or 3 stages), with 0, 1 or 2 tail chunks, full and partial — and hypothesis counts
+    that leave slots of the last wave empty.  Counts equal to the all-fp64 kernel's, sums to summation order; a high
+    threshold so that the exact tier runs every few steps, a low one so that it almost never does."""
+    monkeypatch.setenv("SFM_SCORE_HPW", str(hpw))
+    for n in (8, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 320, 383, 384, 385, 449, 512, 640, 767, 1000):
+        _, _, _, corr = scene(n, seed=n)
+        for h in (1, 3, 4, 5, 9):
+            S = orc.philox_sample_table(n + h, 0, h, n)
+            E, _, _ = orc.fit_hypotheses(corr, S)
+            for thr in (1.5e-6, 1e-2):
+                exact, filt = _score_both(dev, corr, E, S, thr)
+                _assert_same_scores(exact, filt)
+
+
 @pytest.mark.parametrize("scale", [1e-30, 1e-20, 1e-3, 1e3, 1e20, 1e36, 1e40, 1e150, 1e-150, 1e-300])
 def test_filtered_score_extreme_matrix_scales(dev, scale):
     """SED is scale-free in E, but the fp32 tier over/underflows: every such pair must fall through to
