@@ -693,7 +693,9 @@ def test_c4_virtual_shards_full_size(dev):
 
 @pytest.mark.parametrize("n,h,philox", [(8, 1, True), (130, 3, False), (300, 2000, True), (777, 5, True),
                                         (1000, 64, False), (5000, 10000, True), (8192, 32768, True), (4099, 1300, False),
-                                        (600, 4097, True), (2500, 5121, False)])
+                                        (600, 4097, True), (2500, 5121, False),
+                                        # two hypotheses per wave (>= 10240 hypotheses) with odd step counts and tail chunks
+                                        (1001, 11000, True), (450, 10241, False)])
 def test_fused_small_pass_equals_separate_calls(dev, monkeypatch, n, h, philox):
     """sfm_ransac_pass_small (workspace preparation inside the fit launch, scoring from per-block partial maxima,
     selection spread over up to 32 blocks folded by the last arriver) against the five separate calls on the same
