@@ -258,7 +258,35 @@ SFM_DEVICE void enforce_rank2(const double (&f)[9], double (&fr)[3][3], double* 
 #pragma unroll
     for (int c = 0; c < 3; ++c) n2[c] = g[c][0] * g[c][0] + g[c][1] * g[c][1] + g[c][2] * g[c][2];
     const int drop = (n2[0] <= n2[1] && n2[0] <= n2[2]) ? 0 : ((n2[1] <= n2[2]) ? 1 : 2);
-    if (ratio2 != nullptr) *ratio2 = fmin(n2[0], fmin(n2[1], n2[2])) / fmax(n2[0], fmax(n2[1], n2[2]));
+    const double smallest = fmin(n2[0], fmin(n2[1], n2[2])), largest = fmax(n2[0], fmax(n2[1], n2[2]));
+    if (ratio2 != nullptr) *ratio2 = smallest / largest;
+    // The direction of a kept column is accurate to ~eps sigma_1 / sigma_k: fine for any F an eight-point sample of
+    // real correspondences gives (sigma_2 ~ sigma_1 after Hartley normalisation), not for a nearly rank-ONE matrix.
+    // There (sigma_2 < 1e-6 sigma_1 in some lane: wave-uniform, practically never) the wave takes the route that
+    // accumulates V, whose error is eps sigma_1 whatever the singular values are.
+    const double middle = ((n2[0] + n2[1]) + n2[2]) - (smallest + largest);
+    if (__any(!(middle > 1e-12 * largest))) {
+        double vv[3][3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int r = 0; r < 3; ++r) g[c][r] = f[r * 3 + c];
+        sfm::hestenes_svd<3>(g, vv);
+        double m2[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) m2[c] = g[c][0] * g[c][0] + g[c][1] * g[c][1] + g[c][2] * g[c][2];
+        const int out = (m2[0] <= m2[1] && m2[0] <= m2[2]) ? 0 : ((m2[1] <= m2[2]) ? 1 : 2);
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) acc += (k == out) ? 0.0 : g[k][r] * vv[k][c];
+                fr[r][c] = acc;
+            }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll

@@ -380,6 +380,32 @@ def test_fit_stages_against_reference_golden(golden):
     np.testing.assert_allclose(T2, d["Tb"], rtol=2e-16, atol=1e-16)
 
 
+def test_enforce_rank2_on_hard_matrices():
+    """_enforce_fundamental_mat_constraints (eight_point.py:430-446) against LAPACK's truncated SVD on matrices the
+    eight-point fit rarely sees: graded singular values down to a nearly rank-ONE matrix (where the kernel's
+    projection from the two large Jacobi columns would lose sigma_1 / sigma_2 in accuracy and the wave takes the
+    V-accumulating route instead), exact rank one, exact rank two, zero, and random well-conditioned ones."""
+    rng = np.random.default_rng(12)
+
+    def with_singular_values(s):
+        u, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        v, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        return u @ np.diag(s) @ v.T
+
+    cases = [rng.normal(size=(3, 3)) for _ in range(6)]
+    cases += [with_singular_values(s) for s in ([1.0, 0.5, 1e-3], [1.0, 1e-3, 1e-9], [1.0, 1e-5, 1e-6], [1.0, 1e-7, 1e-12],
+                                                [1.0, 1e-9, 1e-10], [1.0, 1e-13, 1e-16], [2.0, 1.0, 0.0], [3.0, 0.0, 0.0])]
+    cases += [np.outer([1.0, -2.0, 0.5], [0.25, 4.0, -1.0]), np.zeros((3, 3))]
+    for f in cases:
+        got = eight_point._enforce_fundamental_mat_constraints(f)
+        u, s_, vh = np.linalg.svd(f)
+        s_[2] = 0.0
+        want = u @ np.diag(s_) @ vh
+        scale = max(np.abs(f).max(), 1e-300)
+        assert np.abs(got - want).max() <= 1e-13 * scale, (f, got, want)
+        assert np.linalg.matrix_rank(got, tol=1e-12 * scale) <= 2
+
+
 def test_traced_fit_intermediates_bit_exact(golden):
     """Inside the fused fit kernel: Hartley normalisation and Y^T Y equal the real reference's values bit for
     bit (golden g8: _normalize_coords / _get_yT_y on the same 8 pairs); eigenvalues and E to LAPACK accuracy."""
