@@ -239,6 +239,20 @@ SFM_DEVICE void smallest_eigenvector_psd9(const double (&a)[45], double (&x)[9])
     }
 }
 
+// Exact scaling of a matrix of arbitrary magnitude into the range the Jacobi routines are written for: the power of two
+// that brings the largest entry into [0.5, 1) (their convergence test compares squared quantities, which under- or
+// overflow for entries beyond ~1e+-77; the eight-point fit's own matrices are unit-norm, a caller's E or F need not be).
+// Multiplying by it and dividing the results back is exact.  1 for a zero / non-finite matrix.
+SFM_DEVICE double pow2_unit_scale(const double* m9) {
+    double largest = 0.0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) largest = fmax(largest, fabs(m9[k]));
+    if (!(largest > 0.0) || !(largest < INFINITY)) return 1.0;
+    int exponent;
+    (void)frexp(largest, &exponent);
+    return ldexp(1.0, -exponent);
+}
+
 // rank-2 enforcement (eight_point.py:430-446): drop the smallest singular direction of f (row-major 3x3).
 // One-sided Jacobi on the columns of F leaves G = F V with orthogonal columns g_k = sigma_k u_k; the projection is
 //   F_r = sum over the two columns kept of  u_k u_k^T F = g_k (g_k^T F) / |g_k|^2,

@@ -304,14 +304,16 @@ __global__ __launch_bounds__(kWave) void fit_stage_kernel(int stage, const doubl
             out[18] = (double)flag;
         }
     } else {
+        // a caller's F can have any magnitude: scaled exactly into the unit range and back (pow2_unit_scale)
+        const double scale = pow2_unit_scale(in);
         double f[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) f[k] = in[k];
+        for (int k = 0; k < 9; ++k) f[k] = in[k] * scale;
         double fr[3][3];
         enforce_rank2(f, fr);
         if (threadIdx.x == 0) {
 #pragma unroll
-            for (int k = 0; k < 9; ++k) out[k] = fr[k / 3][k % 3];
+            for (int k = 0; k < 9; ++k) out[k] = fr[k / 3][k % 3] / scale;
         }
     }
 }
@@ -700,15 +702,18 @@ __global__ __launch_bounds__(kWave) void decompose_essential_kernel(const double
     const bool active = b_raw < batch;
     const int64_t b = active ? b_raw : batch - 1;
     const double* e = E + b * 9;
+    // E can have any magnitude (the reference's SVD does not care): scaled exactly into the unit range for the Jacobi
+    // sweeps, singular values scaled back for the sigma_3 ~ 0 test, which is absolute (pow2_unit_scale)
+    const double scale = sfmfit::pow2_unit_scale(e);
     double g[3][3], v[3][3];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
-        for (int r = 0; r < 3; ++r) g[c][r] = e[r * 3 + c];
+        for (int r = 0; r < 3; ++r) g[c][r] = e[r * 3 + c] * scale;
     sfm::hestenes_svd<3>(g, v);
     double sig[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) sig[c] = sqrt(g[c][0] * g[c][0] + g[c][1] * g[c][1] + g[c][2] * g[c][2]);
+    for (int c = 0; c < 3; ++c) sig[c] = sqrt(g[c][0] * g[c][0] + g[c][1] * g[c][1] + g[c][2] * g[c][2]);  // of the scaled E
     // order columns by decreasing singular value: (i0, i1, i2)
     int i0 = 0, i1 = 1, i2 = 2;
     if (sig[i0] < sig[i1]) { int t = i0; i0 = i1; i1 = t; }
@@ -761,7 +766,8 @@ __global__ __launch_bounds__(kWave) void decompose_essential_kernel(const double
         vt[2][2] = -vt[2][2];
     }
     // np.isclose(0, s[-1]) with atol 1e-8 (eight_point.py:268)
-    const int st = (s2v <= 1e-8 + 1e-5 * s2v) ? 0 : 1;
+    const double s2_true = s2v / scale;   // exact: scale is a power of two
+    const int st = (s2_true <= 1e-8 + 1e-5 * s2_true) ? 0 : 1;
     // R1 = U W^T V^T, R2 = U W V^T with W = [[0,-1,0],[1,0,0],[0,0,1]]:
     //   U W^T = [-u2, u1, u3] columns -> R1 = -u2 v1^T + u1 v2^T + u3 v3^T
     //   U W   = [ u2,-u1, u3]         -> R2 =  u2 v1^T - u1 v2^T + u3 v3^T

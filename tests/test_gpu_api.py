@@ -396,6 +396,8 @@ def test_enforce_rank2_on_hard_matrices():
     cases += [with_singular_values(s) for s in ([1.0, 0.5, 1e-3], [1.0, 1e-3, 1e-9], [1.0, 1e-5, 1e-6], [1.0, 1e-7, 1e-12],
                                                 [1.0, 1e-9, 1e-10], [1.0, 1e-13, 1e-16], [2.0, 1.0, 0.0], [3.0, 0.0, 0.0])]
     cases += [np.outer([1.0, -2.0, 0.5], [0.25, 4.0, -1.0]), np.zeros((3, 3))]
+    # any magnitude: the SVD is scale-equivariant, the kernel scales by an exact power of two and back
+    cases += [cases[0] * 1e-100, cases[1] * 1e-140, cases[2] * 1e100, cases[3] * 1e140, cases[7] * 1e-200]
     for f in cases:
         got = eight_point._enforce_fundamental_mat_constraints(f)
         u, s_, vh = np.linalg.svd(f)
@@ -404,6 +406,23 @@ def test_enforce_rank2_on_hard_matrices():
         scale = max(np.abs(f).max(), 1e-300)
         assert np.abs(got - want).max() <= 1e-13 * scale, (f, got, want)
         assert np.linalg.matrix_rank(got, tol=1e-12 * scale) <= 2
+
+
+def test_decompose_essential_at_any_magnitude():
+    """_recover_all_r_t (eight_point.py:245-280) is scale-free below the absolute sigma_3 ~ 0 test (:268-271): an E
+    scaled down by 1e-60 ... 1e-140 gives the same rotations and translation direction; scaled up by 1e60 its third
+    singular value (1e-16 of the first) exceeds the reference's atol of 1e-8 and the reference raises — so do we."""
+    R = orc.euler_xy(-5.0, -10.0)
+    t = np.array([0.5, 0.05, 0.1])
+    t /= np.linalg.norm(t)
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    E = tx @ R
+    for scale in (1.0, 1e-60, 1e-100, 1e-140, 1e-250):
+        r1, r2, tt = eight_point._recover_all_r_t(E * scale)
+        assert min(np.abs(r1 - R).max(), np.abs(r2 - R).max()) <= 1e-12, scale
+        assert min(np.abs(tt - t).max(), np.abs(tt + t).max()) <= 1e-12, scale
+    with pytest.raises(eight_point.EightPointCalculationError):
+        eight_point._recover_all_r_t(E * 1e60)
 
 
 def test_traced_fit_intermediates_bit_exact(golden):
