@@ -64,9 +64,10 @@ def parse():
 
 def cpu_baseline(corr: np.ndarray, seed: int, target_seconds: float):
     """Times the CPU oracle (numpy eight-point fit + plain-C/OpenMP SED scoring + numpy selection) on a
-    bounded number of hypotheses of the same workload.  The oracle is only the thing timed here.  The fit is a
-    single-threaded numpy restatement and the scoring leg an OpenMP C loop, so both legs are also reported on
-    their own: `value` is the whole stage the metric names, `score_leg_value` the H x N loop alone."""
+    bounded number of hypotheses of the same workload, on all the cores of the box's CPU share: the fit runs over
+    contiguous hypothesis blocks in a pool of `cores` worker processes (BASELINE.md section 3 ii), the scoring loop on
+    `cores` OpenMP threads.  The oracle is only the thing timed here.  Both legs are also reported on their own:
+    `value` is the whole stage the metric names, `score_leg_value` the H x N loop alone."""
     from oracle import sfm_oracle as orc
 
     # build output (if any) goes to stderr: stdout carries exactly one JSON line
@@ -80,35 +81,35 @@ def cpu_baseline(corr: np.ndarray, seed: int, target_seconds: float):
     threads = int(os.environ.get("SFM_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16)))
     legs = {"fit": 0.0, "score": 0.0, "select": 0.0}
 
-    def run(h, h_begin, record=True):
-        t0 = time.perf_counter()
-        S = orc.philox_sample_table(seed, h_begin, h, n)
-        E, deg, _ = orc.fit_hypotheses(corr, S)
-        E = np.ascontiguousarray(E.reshape(h, 9))
-        t1 = time.perf_counter()
-        cnt = np.zeros(h, dtype=np.int32)
-        s1 = np.zeros(h)
-        s2 = np.zeros(h)
-        used = lib.sfm_oracle_score(corr.ctypes.data, n, E.ctypes.data, S.ctypes.data, h, THR,
-                                    cnt.ctypes.data, s1.ctypes.data, s2.ctypes.data, threads)
-        t2 = time.perf_counter()
-        best, err = orc.select_best(orc.aggregate(cnt, s1, s2, orc.RMS), cnt, MIN_EXTRA)
-        t3 = time.perf_counter()
-        if record:
-            legs["fit"] += t1 - t0
-            legs["score"] += t2 - t1
-            legs["select"] += t3 - t2
-        return used, err
+    with orc.FitPool(corr, threads) as pool:   # worker start-up (interpreter + numpy import) is not timed
+        def run(h, h_begin, record=True):
+            t0 = time.perf_counter()
+            S, E, deg, _ = pool.sample_and_fit(seed, h_begin, h)
+            E = np.ascontiguousarray(E.reshape(h, 9))
+            t1 = time.perf_counter()
+            cnt = np.zeros(h, dtype=np.int32)
+            s1 = np.zeros(h)
+            s2 = np.zeros(h)
+            used = lib.sfm_oracle_score(corr.ctypes.data, n, E.ctypes.data, S.ctypes.data, h, THR,
+                                        cnt.ctypes.data, s1.ctypes.data, s2.ctypes.data, threads)
+            t2 = time.perf_counter()
+            best, err = orc.select_best(orc.aggregate(cnt, s1, s2, orc.RMS), cnt, MIN_EXTRA)
+            t3 = time.perf_counter()
+            if record:
+                legs["fit"] += t1 - t0
+                legs["score"] += t2 - t1
+                legs["select"] += t3 - t2
+            return used, err
 
-    run(64, 0, record=False)  # warm the caches / thread pool
-    chunk, done, used = 10_000, 0, 1
-    t0 = time.perf_counter()
-    while True:
-        used, _ = run(chunk, done)
-        done += chunk
-        elapsed = time.perf_counter() - t0
-        if elapsed >= target_seconds or done >= 2_000_000:
-            break
+        run(64 * threads, 0, record=False)  # warm the caches / thread pool / workers
+        chunk, done, used = 40_000, 0, 1
+        t0 = time.perf_counter()
+        while True:
+            used, _ = run(chunk, done)
+            done += chunk
+            elapsed = time.perf_counter() - t0
+            if elapsed >= target_seconds or done >= 4_000_000:
+                break
     return {
         "value": n * done / elapsed,
         "unit": "correspondence-evals/s",
@@ -116,9 +117,10 @@ def cpu_baseline(corr: np.ndarray, seed: int, target_seconds: float):
         "kind": "port",
         "score_leg_value": n * done / legs["score"] if legs["score"] > 0 else None,
         "seconds": {k: round(v, 3) for k, v in legs.items()},
-        "sample": f"{done} hypotheses x {n} matches of the same workload in {elapsed:.1f} s: numpy eight-point "
-                  f"fit (1 thread, {legs['fit']:.1f} s) + C/OpenMP SED scoring ({used} threads, "
-                  f"{legs['score']:.1f} s) + numpy selection; score_leg_value = the H x N loop alone",
+        "sample": f"{done} hypotheses x {n} matches of the same workload in {elapsed:.1f} s: Philox table + numpy "
+                  f"eight-point fit over hypothesis blocks in {pool.workers} worker processes ({legs['fit']:.1f} s) + "
+                  f"C/OpenMP SED scoring ({used} threads, {legs['score']:.1f} s) + numpy selection; "
+                  f"score_leg_value = the H x N loop alone",
     }
 
 
@@ -145,6 +147,9 @@ def load_counters(n, h):
 
 def roofline(n, h, kernel_ms, call_ms, variant):
     evals = float(n) * float(h)
+    if not kernel_ms or kernel_ms <= 0:   # nothing was timed (--steps 0)
+        return {"bound": "valu-issue", "kernel_ms": None, "achieved": None, "peak": SIMDS * CLOCK_GHZ, "frac": None,
+                "traffic": None, "unit": "G wave-instruction issue cycles/s"}
     seconds = kernel_ms * 1e-3
     algorithmic = evals * BYTES_PER_EVAL
     rec, stale = load_counters(n, h)
@@ -209,16 +214,13 @@ def api_timings(device_mod):
         for name, n, h, sampler in (("c1_300x2000_pyshuffle", 300, 2000, "pyshuffle"),
                                     ("c2_5000x10000_pyshuffle", 5000, 10000, "pyshuffle"),
                                     ("c2_5000x10000_philox", 5000, 10000, "philox"),
-                                    ("c2_5000x10000_auto", 5000, 10000, None),
-                                    ("c3_50000x100000_auto", 50000, 100000, None)):
+                                    ("c2_5000x10000_auto", 5000, 10000, "auto"),
+                                    ("c3_50000x100000_auto", 50000, 100000, "auto")):
             pa, pb, K, *_ = synthetic.two_view_scene(n, seed=6)
             fa = [Feature(x=float(x), y=float(y)) for x, y in pa]
             fb = [Feature(x=float(x), y=float(y)) for x, y in pb]
             matches = create_trivial_matches(n)
-            if sampler is None:
-                os.environ.pop("SFM_SAMPLER", None)
-            else:
-                os.environ["SFM_SAMPLER"] = sampler
+            os.environ["SFM_SAMPLER"] = sampler   # "auto" = the explicit size switch (pyshuffle up to 1e7 draws)
             os.environ["SFM_SEED"] = "5"
             times = []
             for rep in range(4):
@@ -239,8 +241,82 @@ def api_timings(device_mod):
     return out
 
 
+def other_configs(torch, device, distributed, synthetic, agg):
+    """The other BASELINE.json configurations on the same line (outside `value`): configs[1] C2 = 5 000 x 10 000 on one
+    GPU (the lean small pass, us per pass), configs[3]'s per-rank share C4 = 125 000 hypotheses x 50 000 matches (one
+    of eight ranks' local pass: sample -> fit -> score -> select, no exchange), configs[4] C5 = 256 pairs x 10 000 x
+    2 000 through the batched device pipeline (E + pose vote + triangulation).  Reference call sites: apps/sfm.py:110-119,
+    133-138, 181-186."""
+    from structure_from_motion_amd import batched
+
+    def wall(fn, reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for r in range(reps):
+            fn(r)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    out = {}
+    # C2: median over 10 groups of 20 passes
+    n, h = 5_000, 10_000
+    pa, pb, K, *_ = synthetic.two_view_scene(n, seed=6)
+    corr = device.normalize_correspondences(device.to_device(pa), device.to_device(pb), K)
+    eng = distributed.ShardedRansac(corr, h, THR, MIN_EXTRA, agg)
+    wall(lambda r: eng.step(50 + r), 20)
+    groups = [wall(lambda r, g=g: eng.step(1000 + 20 * g + r), 20) for g in range(10)]
+    us = float(np.median(groups)) * 1e6
+    res = eng.outcome()
+    out["c2_5000x10000"] = {"pass_us": us, "evals_per_s": n * h / us * 1e6, "passes": 200, "best_h": res.best_h,
+                            "inliers": int((res.mask != 0).sum())}
+    # C4 per-rank share
+    n, total, world = 50_000, C4_TOTAL, 8
+    pa, pb, K, *_ = synthetic.two_view_scene(n, seed=6)
+    corr = device.normalize_correspondences(device.to_device(pa), device.to_device(pb), K)
+    eng = distributed.ShardedRansac(corr, None, THR, MIN_EXTRA, agg, rank=0, world=world, total_hypotheses=total)
+    wall(lambda r: eng.step_local(50 + r), 3)
+    sec = wall(lambda r: eng.step_local(1000 + r), 10)
+    out["c4_shard_125000x50000"] = {"ms": sec * 1e3, "evals_per_s": n * eng.h / sec,
+                                    "note": "rank 0 of 8: local pass over its 125 000 hypotheses of the 1 M stream"}
+    del eng
+    # C5
+    B, n, h = 256, 10_000, 2_000
+    base = [synthetic.two_view_scene(n, seed=300 + b, outlier_fraction=0.25) for b in range(16)]
+    pix_a = device.to_device(np.stack([base[b % 16][0] for b in range(B)]))
+    pix_b = device.to_device(np.stack([base[b % 16][1] for b in range(B)]))
+    pipe = batched.TwoViewBatch(B, n, h)
+    run = lambda r: pipe.run(pix_a, pix_b, base[0][2], seed=70 + 1000 * r, thr=THR, min_extra=MIN_EXTRA, aggregation=agg)
+    wall(run, 2)
+    sec = wall(run, 5)
+    ok = sum(r.status == batched.OK for r in pipe.results())
+    out["c5_256x10000x2000"] = {"batch_ms": sec * 1e3, "evals_per_s": B * n * h / sec, "pairs_per_s": B / sec,
+                                "pairs_ok": ok, "note": "E estimation + pose vote + triangulation, one enqueue"}
+    del pipe
+    torch.cuda.empty_cache()
+    return out
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` typed without a launcher: start the N ranks as CHILD processes through
+    torch.distributed.run (one per GPU, rendezvous on 127.0.0.1) and relay their output and exit code.  Nothing in this
+    process has touched the GPU yet, and it never will: rank 0 of the children prints the one JSON line."""
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     import torch
     import torch.distributed as dist
 
@@ -248,7 +324,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # SFM_DIST_BACKEND=gloo lets several ranks share one GPU for a rehearsal (collective staged through the host)
     backend = os.environ.get("SFM_DIST_BACKEND", "nccl")
     local_device = local_rank % max(torch.cuda.device_count(), 1) if backend == "gloo" else local_rank
@@ -289,22 +365,36 @@ def main():
             b.record()
         return evs
 
-    kernel_ev, call_ev = make_events(args.steps), make_events(args.steps)
+    n_events = max(args.steps, 3)
+    kernel_ev, call_ev = make_events(n_events), make_events(n_events)
     score = device.score_sed
-    state = {"i": -1}
+    state = {"i": -1, "calls": 0}
 
     def timed_score(*a, **k):
+        # brackets the whole scoring call (workspace preparation + ordering pre-pass + kernel); the lean small pass
+        # (n <= 8192, h <= 32768) has no separate scoring call and never comes through here
         i = state["i"]
         if i >= 0:
-            device.score_timing_events(*kernel_ev[i])
             call_ev[i][0].record()
         out = score(*a, **k)
         if i >= 0:
             call_ev[i][1].record()
-            device.score_timing_events(None, None)
+            state["calls"] += 1
         return out
 
     device.score_sed = timed_score
+
+    def timed_step(i, seed):
+        """One engine step with the scoring kernel of that step bracketed by kernel_ev[i]: the events are recorded
+        inside the library immediately around the scoring kernel, on its launch stream — by sfm_score_sed and by the
+        scoring launch of sfm_ransac_pass_small alike."""
+        state["i"] = i
+        if i >= 0:
+            device.score_timing_events(*kernel_ev[i])
+        engine.step(seed)
+        if i >= 0:
+            device.score_timing_events(None, None)
+        state["i"] = -1
 
     def barrier():
         if world > 1:
@@ -325,11 +415,9 @@ def main():
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for s in range(3):
-                state["i"] = s
-                engine.step(args.seed + 80 + s)
+                timed_step(s, args.seed + 80 + s)
             torch.cuda.synchronize()
             wall = (time.perf_counter() - t0) / 3
-            state["i"] = -1
             variants[name] = {"ms_per_step": wall * 1e3, "value": float(n) * h / wall,
                               "kernel_ms": float(np.mean([a.elapsed_time(b) for a, b in kernel_ev[:3]]))}
         os.environ.pop("SFM_SCORE_KERNEL", None)
@@ -339,23 +427,21 @@ def main():
         # per-kernel events cannot be recorded inside a replayed graph: time the score kernel on a few
         # eager steps first, then capture
         timed = min(args.steps, 10)
+        state["calls"] = 0
         for s in range(timed):
-            state["i"] = s
-            engine.step(args.seed + 500 + s)
-        state["i"] = -1
+            timed_step(s, args.seed + 500 + s)
         torch.cuda.synchronize()
-        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in kernel_ev[:timed]]))
-        call_ms = float(np.mean([a.elapsed_time(b) for a, b in call_ev[:timed]]))
+        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in kernel_ev[:timed]])) if timed else None
+        call_ms = float(np.mean([a.elapsed_time(b) for a, b in call_ev[:timed]])) if state["calls"] else None
         engine.capture()
         engine.step(args.seed + 999)
+    state["calls"] = 0
     barrier()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        state["i"] = -1 if args.graph else s
-        engine.step(args.seed + 1000 + s)
+        timed_step(-1 if args.graph else s, args.seed + 1000 + s)
     barrier()
     elapsed = time.perf_counter() - t0
-    state["i"] = -1
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -363,8 +449,10 @@ def main():
 
     out = engine.outcome()
     if not args.graph:
-        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in kernel_ev])) if args.steps else float("nan")
-        call_ms = float(np.mean([a.elapsed_time(b) for a, b in call_ev])) if args.steps else float("nan")
+        ev = kernel_ev[:args.steps]
+        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else None
+        # no separate scoring call in a lean small pass: nothing re-recorded the call events
+        call_ms = float(np.mean([a.elapsed_time(b) for a, b in call_ev[:args.steps]])) if state["calls"] else None
     value = float(n) * float(total_h) * args.steps / elapsed
 
     if rank == 0:
@@ -400,6 +488,7 @@ def main():
             line["variants"] = variants
         if world == 1 and not args.no_extras:
             device.score_sed = score
+            line["configs"] = other_configs(torch, device, distributed, synthetic, AGG_RMS)
             line["api_ms"] = api_timings(device)
         if not args.no_cpu_baseline and world == 1:
             corr_host = corr.cpu().numpy()

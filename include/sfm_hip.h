@@ -54,6 +54,10 @@ typedef struct sfm_select_result {
     int32_t best_cnt;      /* extra-inlier count of the winner */
 } sfm_select_result;
 
+/* Version of this interface: libsfm_hip.so reports the one it was compiled from (sfm_abi_version), the Python binding
+ * and the torch op library (sfm_torch_ops_abi_version) refuse a library of another version. */
+#define SFM_ABI_VERSION 8
+
 const char* sfm_last_error(void);
 int sfm_abi_version(void);
 
@@ -136,7 +140,8 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
  *             wanted the same launch carries ceil(n / 256) more blocks that wait for the published record and write
  *             the winner's inlier mask.
  * A small pass is a chain of dependent, latency-bound launches: what shortens it is fewer and leaner ones.
- * h_offset as in sfm_select_best; mask refers to local indices, i.e. needs h_offset == 0 to be meaningful.
+ * h_offset as in sfm_select_best (the record carries global indices = local + h_offset); the mask is always the
+ * winner's, whatever h_offset: the kernels index E and S with the local winner.
  * workspace: sfm_score_workspace_bytes(n, h_count, 1) bytes, 16-byte aligned. */
 int sfm_ransac_pass_small(uint64_t seed, const uint64_t* seed_dev, int use_philox, int64_t h_begin, const double* corr,
                           int64_t n, int64_t h_count, double thr, double min_extra, int aggregation, int64_t h_offset,

@@ -151,6 +151,74 @@ def fit_hypotheses(corr: np.ndarray, S: np.ndarray):
     return fit_from_sample_coords(pts[..., 0:2], pts[..., 2:4])
 
 
+_POOL_CORR = None  # the correspondence set of a FitPool worker (set once per worker process)
+
+
+def _fit_pool_init(corr: np.ndarray) -> None:
+    global _POOL_CORR
+    _POOL_CORR = corr
+
+
+def _fit_pool_block(S_block: np.ndarray):
+    return fit_hypotheses(_POOL_CORR, S_block)
+
+
+def _fit_pool_philox_block(args):
+    seed, h_begin, h_count = args
+    S = philox_sample_table(seed, h_begin, h_count, _POOL_CORR.shape[0])
+    return (S,) + tuple(fit_hypotheses(_POOL_CORR, S))
+
+
+class FitPool:
+    """fit_hypotheses over contiguous hypothesis blocks on ``workers`` processes (BASELINE.md §3 ii: the all-core
+    form of the same numpy restatement; results are those of fit_hypotheses block by block, i.e. identical).
+    Workers are spawned, not forked: the parent may hold an initialised GPU runtime."""
+
+    def __init__(self, corr: np.ndarray, workers: int):
+        import multiprocessing as mp
+        import os
+
+        self.workers = max(1, int(workers))
+        saved = {k: os.environ.get(k) for k in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS")}
+        os.environ["OPENBLAS_NUM_THREADS"] = "1"   # one LAPACK thread per worker: the pool is the parallelism
+        os.environ["OMP_NUM_THREADS"] = "1"
+        try:
+            self.pool = mp.get_context("spawn").Pool(self.workers, initializer=_fit_pool_init,
+                                                     initargs=(np.ascontiguousarray(corr),))
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+
+    def fit(self, S: np.ndarray, block: int = 0):
+        h = S.shape[0]
+        if block <= 0:   # ~2000 hypotheses per block keep the batched LAPACK working set in cache (2x faster than 80 000)
+            block = min(2500, max(256, -(-h // (4 * self.workers))))
+        parts = self.pool.map(_fit_pool_block, [S[i:i + block] for i in range(0, h, block)])
+        return tuple(np.concatenate([p[k] for p in parts]) for k in range(3))
+
+    def sample_and_fit(self, seed: int, h_begin: int, h_count: int, block: int = 0):
+        """(S, E, degenerate, lambda2) for hypotheses [h_begin, h_begin + h_count) of the Philox stream: the table is
+        counter-based, so every worker draws its own block of it."""
+        if block <= 0:
+            block = min(2500, max(256, -(-h_count // (4 * self.workers))))
+        jobs = [(seed, h_begin + i, min(block, h_count - i)) for i in range(0, h_count, block)]
+        parts = self.pool.map(_fit_pool_philox_block, jobs)
+        return tuple(np.concatenate([p[k] for p in parts]) for k in range(4))
+
+    def close(self):
+        self.pool.close()
+        self.pool.join()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
 def estimate_fundamental_mat(coords_a: np.ndarray, coords_b: np.ndarray) -> np.ndarray:
     """Single 8-point fit; raises like eight_point.py:417-421 on a degenerate sample."""
     if coords_a.shape != (8, 2) or coords_b.shape != (8, 2):

@@ -15,7 +15,7 @@ AGG_SUM, AGG_SQUARE, AGG_MEAN, AGG_RMS = 0, 1, 2, 3
 FIT_DEGENERATE = 1
 MATCH_NCC, MATCH_SSD = 0, 1
 INT64_MAX = (1 << 63) - 1
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class SelectResult(C.Structure):

@@ -17,18 +17,39 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp
          "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 
 
-def score_source_sha() -> str:
-    """Fingerprint of the sources the scoring kernels are compiled from; profiles/score_traffic.json is stamped
-    with it so that bench.py can tell when the committed PMC counters were taken on an older kernel."""
+def _extra_flags():
+    return os.environ.get("SFM_EXTRA_HIPCC_FLAGS", "").split()   # experiment builds (e.g. -DSFM_SCORE_E_IN_VGPR=1)
+
+
+def score_source_sha(extra=None) -> str:
+    """Fingerprint of what the scoring kernels are compiled from — sfm_score.hip, every csrc/*.h it can include, the
+    public header and the compiler flags INCLUDING the extra flags of an experiment build; profiles/score_traffic.json
+    is stamped with it so that bench.py can tell when the committed PMC counters were taken on another kernel.
+    ``extra=None`` reads the flags the in-tree library was built with (its stamp file), so a bench running an experiment
+    build reports that build's fingerprint, not the default's."""
     import hashlib
 
+    if extra is None:
+        extra = built_flags()
     h = hashlib.sha256()
-    for name in ("sfm_score.hip", "sfm_math.h", "sfm_common.h"):
+    for name in ["sfm_score.hip"] + HEADERS:
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(f.read())
-    for flag in FLAGS:
+    for flag in FLAGS + list(extra):
         h.update(flag.encode())
     return h.hexdigest()[:16]
+
+
+STAMP_PATH = os.path.join(CSRC, "libsfm_hip.flags")
+
+
+def built_flags():
+    """The extra hipcc flags the in-tree libsfm_hip.so was built with ([] for the default build or an unstamped one)."""
+    try:
+        with open(STAMP_PATH) as f:
+            return f.read().split()
+    except OSError:
+        return []
 
 
 OPS_LIB_PATH = os.path.join(CSRC, "libsfm_torch_ops.so")
@@ -99,7 +120,9 @@ def _stale() -> bool:
         return True
     built = os.path.getmtime(LIB_PATH)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > built for d in deps)
+    if any(os.path.getmtime(d) > built for d in deps):
+        return True
+    return built_flags() != _extra_flags()   # an experiment build left behind (or wanted now): the flags differ
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -107,11 +130,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    extra = os.environ.get("SFM_EXTRA_HIPCC_FLAGS", "").split()   # experiment builds (e.g. -DSFM_SCORE_E_IN_VGPR=1)
+    extra = _extra_flags()
     cmd = [hipcc] + FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH]
     with _build_lock():
         if force or _stale():   # another process may have built it while this one waited
             _compile(cmd, LIB_PATH, verbose)
+            with open(STAMP_PATH, "w") as f:   # what this library was built with: _stale() and score_source_sha() read it
+                f.write(" ".join(extra))
     return LIB_PATH
 
 

@@ -511,13 +511,13 @@ __global__ __launch_bounds__(256) void select_sharded_kernel(
         const Corr p = corr[i < n ? i : n - 1];   // in flight while waiting
         if (threadIdx.x == 0) {
             int polls = 0;
-            while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && polls < kMaxFlagPolls) {
+            // acquire loads at agent scope pair with the release store of the flag below: once the flag reads 1 the
+            // record written before it is visible to this block
+            while (__hip_atomic_load(done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u && polls < kMaxFlagPolls) {
                 __builtin_amdgcn_s_sleep(8);
                 ++polls;
             }
             last_block = polls < kMaxFlagPolls ? 1 : 0;   // reused as "record is there"
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
         if (i >= n) return;
@@ -525,8 +525,10 @@ __global__ __launch_bounds__(256) void select_sharded_kernel(
             mask[i] = 0xFF;
             return;
         }
-        const int64_t h = __hip_atomic_load(&result->best_h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (h < 0 || h >= h_count) {
+        // the record carries the GLOBAL index (local winner + h_offset); E and S are this launch's local arrays
+        const int64_t global_h = __hip_atomic_load(&result->best_h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int64_t h = global_h - h_offset;
+        if (global_h < 0 || h < 0 || h >= h_count) {
             mask[i] = 0;
             return;
         }
@@ -572,14 +574,10 @@ __global__ __launch_bounds__(256) void select_sharded_kernel(
         __hip_atomic_store(&out->best, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&out->first_flagged, first_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&out->n_flagged, (int32_t)n_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned arrived = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool last = arrived == (unsigned)select_blocks - 1;
-        if (last) {  // acquire: the other blocks' records may sit stale in this CU's L1
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        last_block = last ? 1 : 0;
+        // arrival: release (this block's partial record is visible before the count) + acquire (the block that
+        // arrives last sees every other block's record)
+        const unsigned arrived = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last_block = arrived == (unsigned)select_blocks - 1 ? 1 : 0;
     }
     __syncthreads();
     if (!last_block) return;
@@ -606,8 +604,7 @@ __global__ __launch_bounds__(256) void select_sharded_kernel(
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&result->n_flagged, (int32_t)n_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&result->best_cnt, found ? cnt[best] : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // publishes the record above
     }
 }
 
@@ -804,7 +801,7 @@ __global__ __launch_bounds__(kWave) void decompose_essential_kernel(const double
 extern "C" {
 
 const char* sfm_last_error(void) { return sfmhost::error_buffer(); }
-int sfm_abi_version(void) { return 7; }
+int sfm_abi_version(void) { return SFM_ABI_VERSION; }
 
 int sfm_normalize_correspondences(const double* pix_a, const double* pix_b, int64_t count, double fx,
                                   double fy, double cx, double cy, double* corr, void* stream) {

@@ -11,6 +11,7 @@
 //
 // Built by structure_from_motion_amd/build.py into csrc/libsfm_torch_ops.so (host code only: no kernels here).
 #include <ATen/ATen.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
@@ -22,7 +23,30 @@ namespace {
 
 using at::Tensor;
 
-void* current_stream() { return (void*)c10::hip::getCurrentHIPStream().stream(); }
+// Every op runs on the device of its first tensor argument (sample_philox: of its `device` argument), not on whatever
+// device happens to be current: OpDevice makes that device current for the op's duration (the C ABI launches on the
+// current device), current_stream() is that device's current torch stream, and need() refuses a tensor that lives
+// elsewhere — a kernel handed pointers of two GPUs would fault or race.
+thread_local const c10::Device* g_op_device = nullptr;
+
+struct OpDevice {
+    c10::Device device;
+    c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard;
+    const c10::Device* outer;
+    explicit OpDevice(const c10::Device& d) : device(d), outer(g_op_device) {
+        TORCH_CHECK(d.is_cuda(), "sfm_hip: expected a ROCm device, got ", d);
+        guard.set_device(d);
+        g_op_device = &device;
+    }
+    explicit OpDevice(const Tensor& first) : OpDevice(first.device()) {}
+    ~OpDevice() { g_op_device = outer; }
+    OpDevice(const OpDevice&) = delete;
+    OpDevice& operator=(const OpDevice&) = delete;
+};
+
+void* current_stream() {
+    return (void*)c10::hip::getCurrentHIPStream(g_op_device ? g_op_device->index() : (c10::DeviceIndex)-1).stream();
+}
 
 void ok(int status, const char* what) {
     TORCH_CHECK(status == SFM_OK, what, " failed (", status, "): ", sfm_last_error());
@@ -30,6 +54,8 @@ void ok(int status, const char* what) {
 
 void need(const Tensor& t, const char* name, at::ScalarType dtype) {
     TORCH_CHECK(t.is_cuda(), "sfm_hip: ", name, " must be a ROCm device tensor");
+    TORCH_CHECK(g_op_device == nullptr || t.device() == *g_op_device, "sfm_hip: ", name, " is on ", t.device(),
+                " but the op runs on ", *g_op_device, ": all tensor arguments must live on one device");
     TORCH_CHECK(t.scalar_type() == dtype, "sfm_hip: ", name, " must have dtype ", dtype, ", got ", t.scalar_type());
     TORCH_CHECK(t.is_contiguous(), "sfm_hip: ", name, " must be contiguous");
 }
@@ -73,6 +99,7 @@ void check_E(const Tensor& E, const Dims& d) {
 // ---- normalize_coords ------------------------------------------------------------------------------------------
 void normalize_coords_out(const Tensor& pix_a, const Tensor& pix_b, double fx, double fy, double cx, double cy,
                           Tensor& out) {
+    const OpDevice scope(pix_a);
     need(pix_a, "pix_a", at::kDouble);
     need(pix_b, "pix_b", at::kDouble);
     need(out, "out", at::kDouble);
@@ -112,6 +139,7 @@ Tensor normalize_coords_meta(const Tensor& pix_a, const Tensor& pix_b, double, d
 Tensor sample_philox(int64_t seed, int64_t seed_stride, int64_t h_begin, int64_t h_count, int64_t n, int64_t batch,
                      at::Device device) {
     TORCH_CHECK(device.is_cuda(), "sfm_hip::sample_philox: device must be a ROCm device");
+    const OpDevice scope(device);
     Tensor S = at::empty({batch, h_count, 8}, at::TensorOptions().dtype(at::kInt).device(device));
     ok(sfm_sample_philox((uint64_t)seed, (uint64_t)seed_stride, h_begin, h_count, n, batch, ptr<int32_t>(S),
                          current_stream()),
@@ -121,6 +149,7 @@ Tensor sample_philox(int64_t seed, int64_t seed_stride, int64_t h_begin, int64_t
 
 // ---- fit_eight_point -------------------------------------------------------------------------------------------
 void fit_eight_point_out(const Tensor& corr, const Tensor& S, Tensor& E, Tensor& flags) {
+    const OpDevice scope(corr);
     need(corr, "corr", at::kDouble);
     need(S, "S", at::kInt);
     need(E, "E", at::kDouble);
@@ -155,6 +184,7 @@ std::tuple<Tensor, Tensor> fit_eight_point_meta(const Tensor& corr, const Tensor
 // Philox sampling fused into the fit launch; `seed_dev` (int64 [1] on the device) is read at kernel run time when given
 void sample_fit_philox_out(const Tensor& corr, int64_t seed, const std::optional<Tensor>& seed_dev, int64_t seed_stride,
                            int64_t h_begin, Tensor& S, Tensor& E, Tensor& flags) {
+    const OpDevice scope(corr);
     need(corr, "corr", at::kDouble);
     need(S, "S", at::kInt);
     need(E, "E", at::kDouble);
@@ -171,6 +201,7 @@ void sample_fit_philox_out(const Tensor& corr, int64_t seed, const std::optional
 // ---- score_sed -------------------------------------------------------------------------------------------------
 void score_sed_out(const Tensor& corr, const Tensor& E, const Tensor& S, double thr, Tensor& cnt, Tensor& s1, Tensor& s2,
                    const std::optional<Tensor>& workspace) {
+    const OpDevice scope(corr);
     need(corr, "corr", at::kDouble);
     need(E, "E", at::kDouble);
     need(S, "S", at::kInt);
@@ -217,6 +248,7 @@ void ransac_pass_small_out(const Tensor& corr, int64_t seed, const std::optional
                            int64_t h_begin, double thr, double min_extra, int64_t aggregation, int64_t h_offset,
                            Tensor& S, Tensor& E, Tensor& flags, Tensor& cnt, Tensor& s1, Tensor& s2, Tensor& result,
                            const std::optional<Tensor>& mask, Tensor& workspace) {
+    const OpDevice scope(corr);
     need(corr, "corr", at::kDouble);
     need(S, "S", at::kInt);
     need(E, "E", at::kDouble);
@@ -246,6 +278,7 @@ void ransac_pass_small_out(const Tensor& corr, int64_t seed, const std::optional
 // ---- select_best -----------------------------------------------------------------------------------------------
 void select_best_out(const Tensor& cnt, const Tensor& s1, const Tensor& s2, const std::optional<Tensor>& flags,
                      double min_extra, int64_t aggregation, int64_t h_offset, Tensor& result) {
+    const OpDevice scope(cnt);
     need(cnt, "cnt", at::kInt);
     need(s1, "s1", at::kDouble);
     need(s2, "s2", at::kDouble);
@@ -277,6 +310,7 @@ Tensor select_best_meta(const Tensor& cnt, const Tensor&, const Tensor&, const s
 // ---- inlier_mask -----------------------------------------------------------------------------------------------
 void inlier_mask_out(const Tensor& corr, const Tensor& E, const Tensor& S, const Tensor& result, double thr,
                      Tensor& mask) {
+    const OpDevice scope(corr);
     need(corr, "corr", at::kDouble);
     need(E, "E", at::kDouble);
     need(S, "S", at::kInt);
@@ -306,6 +340,7 @@ Tensor inlier_mask_meta(const Tensor& corr, const Tensor&, const Tensor&, const 
 
 // ---- cheirality / triangulate ------------------------------------------------------------------------------------
 Tensor cheirality(const Tensor& corr, const Tensor& pose_rt, double distance_threshold) {
+    const OpDevice scope(corr);
     need(corr, "corr", at::kDouble);
     need(pose_rt, "pose_rt", at::kDouble);
     TORCH_CHECK(corr.dim() == 2 && corr.size(1) == 4, "sfm_hip: corr must be [m, 4]");
@@ -323,6 +358,7 @@ Tensor cheirality_meta(const Tensor& corr, const Tensor& pose_rt, double) {
 }
 
 Tensor triangulate(const Tensor& corr, const Tensor& P1, const Tensor& P2) {
+    const OpDevice scope(corr);
     need(corr, "corr", at::kDouble);
     need(P1, "P1", at::kDouble);
     need(P2, "P2", at::kDouble);
@@ -341,6 +377,10 @@ Tensor triangulate_meta(const Tensor& corr, const Tensor&, const Tensor&) {
 }
 
 }  // namespace
+
+// the C-ABI version this op library was compiled against (include/sfm_hip.h); ops.load() compares it with the
+// libsfm_hip.so it finds next to it
+extern "C" int sfm_torch_ops_abi_version(void) { return SFM_ABI_VERSION; }
 
 TORCH_LIBRARY(sfm_hip, m) {
     m.def("normalize_coords(Tensor pix_a, Tensor pix_b, float fx, float fy, float cx, float cy) -> Tensor");

@@ -439,7 +439,7 @@ class RansacWorkspace:
         """fit + score + select (+ mask) for the sample table currently in ``self.S`` — or, with
         ``philox=(seed, h_begin, seed_stride)``, for Philox samples drawn inside the fit kernel (which also fills
         ``self.S``); ``seed`` may be an int64 device tensor (read at kernel run time)."""
-        if small_pass_eligible(self.batch, self.n, self.h) and (not with_mask or h_offset == 0):
+        if small_pass_eligible(self.batch, self.n, self.h):
             # workspace preparation rides in the fit launch, selection over 32 blocks (seed_stride only matters for batches)
             ransac_pass_small(corr, self.S, self.E, self.flags, self.cnt, self.s1, self.s2, self.result,
                               self.mask if with_mask else None, self.score_ws, thr, min_extra, aggregation, h_offset,

@@ -7,7 +7,6 @@ import gc
 import logging
 import os
 import random
-import warnings
 from itertools import starmap
 from operator import attrgetter
 from typing import Sequence
@@ -21,10 +20,11 @@ from ..common.feature import Feature
 
 _GET_X, _GET_Y = attrgetter("x"), attrgetter("y")
 
-# Above this many matches x iterations the default sampler switches from the exact random.shuffle replay to the
-# counter-based device sampler: the replay is inherently sequential (one Mersenne-Twister draw per element per
-# iteration, like the reference's own loop), ~3 ns per draw on the host against microseconds for the whole pass on
-# the GPU.  Every golden vector and the demo (600 matches x 2000 iterations = 1.2e6) stay far below it.
+# SFM_SAMPLER=auto: above this many matches x iterations (SFM_AUTO_PHILOX_WORK overrides) the sampler switches from the
+# exact random.shuffle replay to the counter-based device sampler: the replay is inherently sequential (one
+# Mersenne-Twister draw per element per iteration, like the reference's own loop), ~3 ns per draw on the host against
+# microseconds for the whole pass on the GPU.  The DEFAULT never switches: a drop-in call reproduces the reference's
+# samples, winner and inlier list for a given random.seed at every size, and pays the O(matches x iterations) replay.
 AUTO_PHILOX_WORK = 10_000_000
 
 
@@ -86,29 +86,20 @@ def copy_pairs(data, order) -> list:
         return [copy.deepcopy(p) for p in picked]
 
 
-_warned_auto_philox = False
-
-
 def sampler_name(n: int = 0, iterations: int = 0) -> str:
-    """``SFM_SAMPLER=pyshuffle|philox`` if set.  Otherwise ``pyshuffle`` — the exact replay of the reference's
-    cumulative ``random.shuffle``, so ``random.seed(k)`` reproduces the reference's samples — up to
-    ``AUTO_PHILOX_WORK`` matches x iterations, and ``philox`` (seeded from ``random.getrandbits(64)``, so the call is
-    still a deterministic function of ``random.seed``) beyond, with one warning per process."""
-    global _warned_auto_philox
-    name = os.environ.get("SFM_SAMPLER")
-    if name is None:
-        if n * iterations <= AUTO_PHILOX_WORK:
-            return "pyshuffle"
-        if not _warned_auto_philox:
-            _warned_auto_philox = True
-            warnings.warn(
-                f"structure_from_motion_amd: {n} matches x {iterations} iterations exceeds {AUTO_PHILOX_WORK}: sampling "
-                "hypotheses with the counter-based device sampler instead of replaying random.shuffle (set "
-                "SFM_SAMPLER=pyshuffle to force the exact replay, SFM_SAMPLER=philox to silence this)", stacklevel=3)
-        return "philox"
-    name = name.lower()
+    """``SFM_SAMPLER=pyshuffle|philox|auto``.  Default ``pyshuffle`` at EVERY size: the exact replay of the reference's
+    cumulative ``random.shuffle`` (ransac.py:59-64) from the global ``random`` state, which it advances exactly as the
+    reference's loop would — ``random.seed(k)`` reproduces the reference's samples, winner and ordered inlier list, and
+    later ``random``-dependent code of the caller sees the same stream.  ``philox``: the counter-based device sampler
+    (seed ``SFM_SEED`` or ``random.getrandbits(64)``; consumes 64 bits of the global stream instead of one shuffle per
+    iteration).  ``auto``: ``pyshuffle`` up to ``SFM_AUTO_PHILOX_WORK`` (default 10^7) matches x iterations, ``philox``
+    beyond — an explicit opt-in to trade the reference's sample stream for speed on large problems."""
+    name = os.environ.get("SFM_SAMPLER", "pyshuffle").lower()
+    if name == "auto":
+        limit = int(float(os.environ.get("SFM_AUTO_PHILOX_WORK", AUTO_PHILOX_WORK)))
+        return "pyshuffle" if n * iterations <= limit else "philox"
     if name not in ("pyshuffle", "philox"):
-        raise ValueError(f"SFM_SAMPLER must be 'pyshuffle' or 'philox', got {name!r}")
+        raise ValueError(f"SFM_SAMPLER must be 'pyshuffle', 'philox' or 'auto', got {name!r}")
     return name
 
 

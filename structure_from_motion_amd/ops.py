@@ -29,6 +29,13 @@ def load():
         if not os.path.exists(OPS_LIB_PATH):
             raise _native.NativeLibraryError(
                 f"{OPS_LIB_PATH} is missing: build it with `python -m structure_from_motion_amd.build`")
+        import ctypes
+
+        ops_abi = ctypes.CDLL(OPS_LIB_PATH).sfm_torch_ops_abi_version()   # the C-ABI version it was compiled against
+        if ops_abi != _native.ABI_VERSION:
+            raise _native.NativeLibraryError(
+                f"libsfm_torch_ops.so was built against C-ABI {ops_abi}, libsfm_hip.so is {_native.ABI_VERSION}; "
+                f"rebuild both with `python -m structure_from_motion_amd.build --force`")
         torch.ops.load_library(OPS_LIB_PATH)
         _loaded = True
     return torch.ops.sfm_hip

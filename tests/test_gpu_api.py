@@ -125,6 +125,42 @@ def test_estimate_essential_mat_with_ransac(golden):
     assert random.random() == after
 
 
+def test_default_sampler_is_the_reference_stream_above_the_old_switch(monkeypatch):
+    """2 000 matches x 6 000 iterations = 1.2e7 draws — above the size where rounds 1-2 silently switched the default to
+    the device sampler.  With the environment untouched the drop-in call must still draw the reference's samples
+    (cumulative random.shuffle from the global state, ransac.py:59-64): winner, E and the ORDERED inlier list equal the
+    oracle driven by CPython's own random.shuffle, and the global random state ends where 6 000 reference shuffles
+    leave it."""
+    monkeypatch.delenv("SFM_SAMPLER", raising=False)
+    monkeypatch.delenv("SFM_SEED", raising=False)
+    n, h, thr, min_extra = 2000, 6000, 1.5e-6, 10
+    pa, pb, K, *_ = orc.synthetic_two_view(n, seed=8)
+    matches = eight_point.create_trivial_matches(n)
+    random.seed(77)
+    e, pairs = epipolar_ransac.estimate_essential_mat_with_ransac(
+        K, feats(pa), feats(pb), matches, thr, min_num_extra_inliers=min_extra,
+        error_aggregation_method=ErrorAggregationMethod.RMS, max_iterations=h)
+    after = random.random()
+    random.seed(77)
+    perm = list(range(n))
+    S = np.empty((h, 8), dtype=np.int32)
+    corr = orc.pack_correspondences(orc.to_normalized_image_coords(pa, K), orc.to_normalized_image_coords(pb, K))
+    for it in range(h):
+        random.shuffle(perm)
+        S[it] = perm[:8]
+    assert random.random() == after          # the call advanced the global stream exactly like the reference's loop
+    ref = orc.ransac_essential(corr, S, thr, min_extra, orc.RMS)
+    assert ref["best"] >= 0 and rel(e, ref["E"]) <= 1e-6
+    # the reference's list order: the winning iteration's sample, then the survivors in that iteration's shuffled order
+    random.seed(77)
+    perm = list(range(n))
+    for it in range(ref["best"] + 1):
+        random.shuffle(perm)
+    order = orc.inlier_indices(corr, ref["E"], np.array(perm[:8]), thr, rest_order=perm[8:])
+    np.testing.assert_array_equal(np.array([[p[0].x, p[0].y] for p in pairs]), pa[order])
+    np.testing.assert_array_equal(np.array([[p[1].x, p[1].y] for p in pairs]), pb[order])
+
+
 def test_ransac_per_method_equals_reference(golden):
     d = golden("g3_per_hypothesis")
     features_1, features_2 = feats(d["pix_a"]), feats(d["pix_b"])
@@ -522,27 +558,25 @@ def test_rccl_accepts_the_record_all_gather():
 
 
 def test_bench_two_rank_rehearsal(tmp_path):
-    """`bench.py --gpus 2` end to end as the driver launches it (torch.distributed.run, one process per rank), both
+    """`python bench.py --gpus 2` end to end, typed without a launcher (bench.py starts one child process per rank through
+    torch.distributed.run, exactly the command the driver would type), both
     ranks sharing the one GPU of the box with the collective staged through gloo: the N > 1 path — shard_range
     partition, 40-byte all-gather, fold, winner re-derivation, max-over-ranks timing — produces one JSON line whose
     winner equals a single-rank run over the same global hypothesis range."""
     import json
     import os
-    import socket
     import subprocess
     import sys
 
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
     common = ["--steps", "3", "--warmup", "1", "--matches", "3000", "--no-cpu-baseline", "--no-extras"]
     env = dict(os.environ, SFM_DIST_BACKEND="gloo")
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(repo, "bench.py"),
-                          "--gpus", "2", "--hypotheses", "4000"] + common, env=env, capture_output=True, text=True,
-                         timeout=600, cwd=repo)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    # typed the plain way, with no launcher: bench.py starts its two ranks itself (child processes through
+    # torch.distributed.run) and relays rank 0's line
+    two = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--hypotheses", "4000"] + common,
+                         env=env, capture_output=True, text=True, timeout=600, cwd=repo)
     assert two.returncode == 0, two.stderr[-2000:]
     line2 = json.loads(two.stdout.strip().splitlines()[-1])
     one = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--hypotheses", "8000"] + common,

@@ -424,3 +424,47 @@ def test_bench_roofline_is_a_valu_issue_bound(monkeypatch, tmp_path):
     # another point set: the record does not apply
     other = bench.roofline(n + 1, h, 2.4, 2.5, "filtered")
     assert other["frac"] is None and other["counters_stale"] is None
+
+
+def test_sampler_default_is_the_exact_replay_at_every_size(monkeypatch):
+    """The drop-in call keeps the reference's sample stream (cumulative random.shuffle, ransac.py:59-64) by default at
+    every size — also at BASELINE configs[1] (5 000 x 10 000) and configs[2]; the size switch to the device sampler is
+    an explicit opt-in (SFM_SAMPLER=auto, threshold SFM_AUTO_PHILOX_WORK)."""
+    from structure_from_motion_amd.epipolar import _engine
+
+    monkeypatch.delenv("SFM_SAMPLER", raising=False)
+    monkeypatch.delenv("SFM_AUTO_PHILOX_WORK", raising=False)
+    assert _engine.sampler_name(300, 2000) == "pyshuffle"
+    assert _engine.sampler_name(5_000, 10_000) == "pyshuffle"
+    assert _engine.sampler_name(50_000, 100_000) == "pyshuffle"
+    monkeypatch.setenv("SFM_SAMPLER", "auto")
+    assert _engine.sampler_name(300, 2000) == "pyshuffle"
+    assert _engine.sampler_name(1000, 10_000) == "pyshuffle" and _engine.sampler_name(1001, 10_000) == "philox"
+    monkeypatch.setenv("SFM_AUTO_PHILOX_WORK", "1e6")
+    assert _engine.sampler_name(300, 2000) == "pyshuffle" and _engine.sampler_name(600, 2000) == "philox"
+    monkeypatch.setenv("SFM_SAMPLER", "philox")
+    assert _engine.sampler_name(8, 1) == "philox"
+    monkeypatch.setenv("SFM_SAMPLER", "fastest")
+    with pytest.raises(ValueError):
+        _engine.sampler_name(8, 1)
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` typed without a launcher starts its ranks as child processes (torch.distributed.run)
+    before anything touches a GPU and relays their exit code.  Without a GPU the ranks stop at the library's "needs a GPU"
+    error: what is checked here is the hand-over (two ranks started, their failure relayed, no WORLD_SIZE complaint)."""
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SFM_DIST_BACKEND"] = "gloo"
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("covered end to end by tests/test_gpu_api.py::test_bench_two_rank_rehearsal on a GPU box")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--matches", "64", "--hypotheses", "16", "--no-cpu-baseline", "--no-extras"],
+                         env=env, capture_output=True, text=True, timeout=300, cwd=REPO)
+    assert out.returncode != 0
+    assert "launch with torch.distributed.run" not in out.stderr          # the old refusal is gone
+    assert "bench.py FAILED" in out.stderr and "local_rank: 1" in out.stderr  # two child ranks were started and reaped
