@@ -121,3 +121,27 @@ def check(status: int, what: str) -> None:
     if status != SFM_OK:
         msg = load().sfm_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"{what} failed ({status}): {msg}")
+
+
+_hostfast = False   # not looked for yet
+
+
+def hostfast():
+    """The CPython helper module for the bulk conversions of the drop-in boundary (csrc/hostfast.c), or None when it has
+    not been built — callers then run the equivalent pure-Python code (same results, several times slower at 50 000
+    matches).  Host code only: nothing numeric depends on it."""
+    global _hostfast
+    if _hostfast is False:
+        import importlib.util
+
+        path = os.path.join(HERE, "csrc", "_sfm_hostfast.so")
+        _hostfast = None
+        if os.path.exists(path):
+            try:
+                spec = importlib.util.spec_from_file_location("_sfm_hostfast", path)
+                module = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(module)
+                _hostfast = module
+            except ImportError:
+                _hostfast = None
+    return _hostfast

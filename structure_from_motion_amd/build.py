@@ -140,9 +140,31 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+HOSTFAST_PATH = os.path.join(CSRC, "_sfm_hostfast.so")
+HOSTFAST_SOURCE = os.path.join(CSRC, "hostfast.c")
+
+
+def build_hostfast(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/hostfast.c — the CPython helper for the bulk Feature-list <-> array conversions of the drop-in
+    boundary (host code only, plain gcc) — into csrc/_sfm_hostfast.so."""
+    import sysconfig
+
+    def fresh() -> bool:
+        return os.path.exists(HOSTFAST_PATH) and os.path.getmtime(HOSTFAST_SOURCE) <= os.path.getmtime(HOSTFAST_PATH)
+
+    if not force and fresh():
+        return HOSTFAST_PATH
+    cmd = [os.environ.get("CC", "gcc"), "-O2", "-fPIC", "-shared", "-Wall", f"-I{sysconfig.get_paths()['include']}",
+           HOSTFAST_SOURCE, "-o", HOSTFAST_PATH]
+    with _build_lock():
+        if force or not fresh():
+            _compile(cmd, HOSTFAST_PATH, verbose)
+    return HOSTFAST_PATH
+
+
 def build_all(force: bool = False, verbose: bool = False):
-    """libsfm_hip.so (kernels + C ABI), then libsfm_torch_ops.so (torch custom ops above it)."""
-    return build(force, verbose), build_ops(force, verbose)
+    """libsfm_hip.so (kernels + C ABI), libsfm_torch_ops.so (torch custom ops above it), _sfm_hostfast.so (host helper)."""
+    return build(force, verbose), build_ops(force, verbose), build_hostfast(force, verbose)
 
 
 if __name__ == "__main__":

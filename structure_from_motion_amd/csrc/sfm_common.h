@@ -74,8 +74,6 @@ struct SmallPass {
 double small_pass_a_scale(double thr);   // factor the prepared a-side coordinates carry for this threshold
 // where the fit launch leaves the scoring order of the pass, or NULL when the pass is too small for an order to matter
 int32_t* small_pass_order(unsigned char* workspace, int64_t n, int64_t h_count);
-// the per-hypothesis arrival counters of a split scoring launch (the fit launch zeroes them), or NULL when the pass does not split
-int32_t* small_pass_arrivals(unsigned char* workspace, int64_t n, int64_t h_count);
 int launch_small_score(const SmallPass& pass);
 
 }  // namespace sfmhost

@@ -129,7 +129,6 @@ struct SmallPrep {
     double a_scale;
     int blocks;
     int32_t* order;   // scoring order of the pass that follows (see fit_eight_point_kernel), or NULL
-    int32_t* arrivals;   // per-hypothesis arrival counters of a split scoring launch (zeroed here), or NULL
 };
 
 template <bool TRACE>
@@ -203,7 +202,6 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     double fr[3][3];
     double ratio2 = 0.0;
     enforce_rank2(f, fr, &ratio2);
-    if (prep.arrivals != nullptr && active) prep.arrivals[h_raw] = 0;   // re-armed by every pass (kernel boundary orders it)
     if (prep.order != nullptr) {  // wave-uniform (small pass)
         // Scoring order for the launch that follows, for free: a sample of eight inliers gives an estimate that is
         // almost rank 2 already, so (sigma_3 / sigma_1)^2 of the unconstrained F predicts which hypotheses will fit the
@@ -861,7 +859,7 @@ int sfm_fit_eight_point(const double* corr, int64_t n, const int32_t* S, int64_t
     SFM_REQUIRE_GRID("sfm_fit_eight_point", h_count, kWave, kWave, batch);
     hipLaunchKernelGGL(fit_eight_point_kernel<false>, dim3(grid_for(h_count, kWave), (unsigned)batch),
                        dim3(kWave), 0, (hipStream_t)stream, (const Corr*)corr, n, const_cast<int32_t*>(S), h_count, E,
-                       flags, lambda2, (double*)nullptr, PhiloxSource{nullptr, 0, 0, 0, 0}, SmallPrep{nullptr, 0.0, 0, nullptr, nullptr});
+                       flags, lambda2, (double*)nullptr, PhiloxSource{nullptr, 0, 0, 0, 0}, SmallPrep{nullptr, 0.0, 0, nullptr});
     return check_launch("fit_eight_point_kernel");
 }
 
@@ -876,7 +874,7 @@ int sfm_sample_fit_philox(uint64_t seed, const uint64_t* seed_dev, uint64_t seed
     hipLaunchKernelGGL(fit_eight_point_kernel<false>, dim3(grid_for(h_count, kWave), (unsigned)batch),
                        dim3(kWave), 0, (hipStream_t)stream, (const Corr*)corr, n, S, h_count, E, flags,
                        (double*)nullptr, (double*)nullptr, PhiloxSource{seed_dev, seed, seed_stride, h_begin, 1},
-                       SmallPrep{nullptr, 0.0, 0, nullptr, nullptr});
+                       SmallPrep{nullptr, 0.0, 0, nullptr});
     return check_launch("fit_eight_point_kernel (philox)");
 }
 
@@ -906,8 +904,7 @@ int sfm_ransac_pass_small(uint64_t seed, const uint64_t* seed_dev, int use_philo
                        (const Corr*)corr, n, S, h_count, E, flags, (double*)nullptr, (double*)nullptr,
                        PhiloxSource{seed_dev, seed, 0, h_begin, use_philox ? 1 : 0},
                        SmallPrep{static_cast<unsigned char*>(workspace), sfmhost::small_pass_a_scale(thr), prep_blocks,
-                                 sfmhost::small_pass_order(static_cast<unsigned char*>(workspace), n, h_count),
-                                 sfmhost::small_pass_arrivals(static_cast<unsigned char*>(workspace), n, h_count)});
+                                 sfmhost::small_pass_order(static_cast<unsigned char*>(workspace), n, h_count)});
     const int rc = check_launch("fit_eight_point_kernel (fused small pass)");
     if (rc != SFM_OK) return rc;
     // launch 2: SED scoring
@@ -945,7 +942,7 @@ int sfm_fit_eight_point_traced(const double* corr, int64_t n, const int32_t* S, 
     SFM_REQUIRE_GRID("sfm_fit_eight_point_traced", h_count, kWave, kWave, batch);
     hipLaunchKernelGGL(fit_eight_point_kernel<true>, dim3(grid_for(h_count, kWave), (unsigned)batch),
                        dim3(kWave), 0, (hipStream_t)stream, (const Corr*)corr, n, const_cast<int32_t*>(S), h_count, E,
-                       flags, (double*)nullptr, trace, PhiloxSource{nullptr, 0, 0, 0, 0}, SmallPrep{nullptr, 0.0, 0, nullptr, nullptr});
+                       flags, (double*)nullptr, trace, PhiloxSource{nullptr, 0, 0, 0, 0}, SmallPrep{nullptr, 0.0, 0, nullptr});
     return check_launch("fit_eight_point_kernel<trace>");
 }
 

@@ -41,8 +41,6 @@
 #include <stdint.h>
 #include <stdlib.h>
 
-#include <algorithm>
-
 #include "sfm_common.h"
 #include "sfm_math.h"
 #include "sfm_score_ws.h"
@@ -56,11 +54,14 @@ using sfmhost::grid_for;
 using sfmhost::grid_stride;
 
 constexpr int kHypPerWave = 4;
+#ifndef SFM_SCORE_PACKED
+#define SFM_SCORE_PACKED 0   // tier 1 of two hypotheses per instruction in packed fp32 (experiment: profiles/r03/README.md)
+#endif
 #ifndef SFM_WAVE_STAMPS
 #define SFM_WAVE_STAMPS 0   // diagnostic build (tools/wave_timeline.py): per-wave start / end stamps of the filtered kernel
 #endif
 #if SFM_WAVE_STAMPS
-__device__ unsigned long long g_wave_stamps[4 * 65536];  // (the LDS kernel: 32 words x up to 8192 waves)  // begin, end, first hypothesis, exact-tier batches; read by nothing but sfm_debug_read_wave_stamps
+__device__ unsigned long long g_wave_stamps[4 * 65536];  // begin, end, first hypothesis, exact-tier batches; read by nothing but sfm_debug_read_wave_stamps
 #endif
 constexpr int kStack = 256;  // entries per (wave, hypothesis) survivor stack; <= 63 left + 128 pushed per step; popped in groups of 64
 
@@ -297,6 +298,77 @@ SFM_DEVICE unsigned long long reject_mask_one_sided(const FilterConsts& f, float
     return __builtin_amdgcn_ballot_w64(r * r > dB);
 }
 
+// The same test for TWO hypotheses at once in packed fp32 (v_pk_fma_f32: both halves of a 64-bit register pair per
+// instruction): the halves carry hypothesis A and hypothesis B, the point's coordinates are broadcast to both (op_sel
+// picks the dword of the (xa', ya') / (xb, yb) register pair) and the multipliers / addends are packed (A, B) pairs — the
+// four multipliers in SGPR pairs as before.  10 v_pk_fma_f32 + 1 v_pk_mul_f32 + 2 compares per point for two hypotheses
+// instead of 24 instructions; every half is the IEEE fma of the plain form, so the masks are bit for bit the same.
+typedef float float2v __attribute__((ext_vector_type(2)));
+struct PackedConsts {
+    float2v e0, e1, e3, e4;          // multipliers (SGPR pairs)
+    float2v e2, e5, e6, e7, e8, cb;  // the other multipliers and the addends (wave-uniform VGPR pairs)
+};
+SFM_DEVICE float2v sgpr_pair(float a, float b) { return float2v{uniform(a), uniform(b)}; }
+SFM_DEVICE PackedConsts pack_consts(const FilterConsts& a, const FilterConsts& b) {
+    PackedConsts p;
+    p.e0 = sgpr_pair(a.e[0], b.e[0]);
+    p.e1 = sgpr_pair(a.e[1], b.e[1]);
+    p.e3 = sgpr_pair(a.e[3], b.e[3]);
+    p.e4 = sgpr_pair(a.e[4], b.e[4]);
+    p.e2 = float2v{a.e[2], b.e[2]};
+    p.e5 = float2v{a.e[5], b.e[5]};
+    p.e6 = float2v{a.e[6], b.e[6]};
+    p.e7 = float2v{a.e[7], b.e[7]};
+    p.e8 = float2v{a.e[8], b.e[8]};
+    p.cb = float2v{a.cb, b.cb};
+    return p;
+}
+// d = broadcast(coord[SEL]) * mult + add, mult in an SGPR pair / in a VGPR pair
+template <int SEL>
+SFM_DEVICE float2v pk_fma_coord_s(float2v coord, float2v mult, float2v add) {
+    float2v d;
+    if (SEL == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(d) : "v"(coord), "s"(mult), "v"(add));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(coord), "s"(mult), "v"(add));
+    return d;
+}
+template <int SEL>
+SFM_DEVICE float2v pk_fma_coord_v(float2v coord, float2v mult, float2v add) {
+    float2v d;
+    if (SEL == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(d) : "v"(coord), "v"(mult), "v"(add));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(coord), "v"(mult), "v"(add));
+    return d;
+}
+// d = value * broadcast(coord[SEL]) + add
+template <int SEL>
+SFM_DEVICE float2v pk_fma_by_coord(float2v value, float2v coord, float2v add) {
+    float2v d;
+    if (SEL == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(value), "v"(coord), "v"(add));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(value), "v"(coord), "v"(add));
+    return d;
+}
+SFM_DEVICE float2v pk_fma(float2v a, float2v b, float2v c) {
+    float2v d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+SFM_DEVICE float2v pk_mul(float2v a, float2v b) {
+    float2v d;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// lane masks of the pairs hypothesis A / hypothesis B reject; a_xy = (xa', ya'), b_xy = (xb, yb) of the lane's point
+SFM_DEVICE void reject_masks_packed(const PackedConsts& f, float2v a_xy, float2v b_xy, unsigned long long& reject_a,
+                                    unsigned long long& reject_b) {
+    const float2v lb0 = pk_fma_coord_s<0>(b_xy, f.e0, pk_fma_coord_s<1>(b_xy, f.e3, f.e6));
+    const float2v lb1 = pk_fma_coord_s<0>(b_xy, f.e1, pk_fma_coord_s<1>(b_xy, f.e4, f.e7));
+    const float2v lb2 = pk_fma_coord_v<0>(b_xy, f.e2, pk_fma_coord_v<1>(b_xy, f.e5, f.e8));
+    const float2v r = pk_fma_by_coord<0>(lb0, a_xy, pk_fma_by_coord<1>(lb1, a_xy, lb2));
+    const float2v dB = pk_fma(lb0, lb0, pk_fma(lb1, lb1, f.cb));
+    const float2v rr = pk_mul(r, r);
+    reject_a = __builtin_amdgcn_ballot_w64(rr.x > dB.x);
+    reject_b = __builtin_amdgcn_ballot_w64(rr.y > dB.y);
+}
+
 // Turn the constants of the two-sided test into those of reject_mask_one_sided: fold delta into cb (see there), and
 // switch the filter off for this hypothesis (cb = +inf: nothing exceeds dB) when cb is too small to keep dB out of
 // the denormal range, or NaN.
@@ -455,8 +527,7 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
     const Corr* __restrict__ corr, const unsigned char* __restrict__ ws, int n,
     const double* __restrict__ E, const int32_t* __restrict__ S, int h_count, double thr, double a_scale,
     const int32_t* __restrict__ order, int32_t* __restrict__ cnt, double* __restrict__ s1,
-    double* __restrict__ s2, int batch, int blocks_per_pair, int prep_blocks, int units = 1, int chunks_per_unit = 0,
-    unsigned char* __restrict__ split = nullptr) {
+    double* __restrict__ s2, int batch, int blocks_per_pair, int prep_blocks) {
     // survivors' indices, one stack per (wave, hypothesis): pushes append at the top, the exact tier pops the top 64 —
     // which 64 of the queued points a batch takes does not matter (only the summation order depends on it, and that is
     // fixed), and a stack needs neither a wrap-around nor a second cursor
@@ -476,15 +547,6 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
     } else {  // one pair, or a grid too large to flatten: plain (block, pair) grid
         pair = blockIdx.y;
         block_of_pair = blockIdx.x;
-    }
-    // Split small pass (FUSED, units > 1): the points of the wave's hypotheses are cut into `units` ranges of
-    // chunks_per_unit 64-point chunks, one wave each — `units` consecutive blocks share their hypotheses, so the ranges of
-    // a hypothesis run side by side (what a launch this small lacks is parallel work per hypothesis: a hypothesis that
-    // fits the scene is ~50 dependent exact-tier batches, and the launch lasts as long as its slowest wave).
-    int unit = 0;
-    if (FUSED && units > 1) {
-        unit = block_of_pair % units;
-        block_of_pair /= units;
     }
     const int wave = block_of_pair * (256 / kWave) + wave_in_block;
     const int h0 = wave * HPW;  // first of this wave's HPW slots in the processing order
@@ -559,6 +621,11 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
         f[k].e[3] = uniform(f[k].e[3]);
         f[k].e[4] = uniform(f[k].e[4]);
     }
+#if SFM_SCORE_PACKED
+    PackedConsts fp[(HPW + 1) / 2];   // the steady-state loop tests hypotheses two at a time (reject_masks_packed)
+#pragma unroll
+    for (int k = 0; k + 1 < HPW; k += 2) fp[k / 2] = pack_consts(f[k], f[k + 1]);
+#endif
 
     int c[HPW];
     double a1[HPW], a2[HPW];
@@ -628,9 +695,31 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
     // Steady state: two full 64-point chunks per step (no validity masks), so the scalar bookkeeping and
     // the drain test are paid once per 128 evaluations of a hypothesis.
     auto process_pair = [&](const float4 p0, const float4 p1, int i0, int i1) __attribute__((always_inline)) {
+#if SFM_SCORE_PACKED
+        unsigned long long packed_m0[HPW], packed_m1[HPW];
+        if (ONE_SIDED && HPW % 2 == 0) {
+            const float2v a0 = {p0.x, p0.y}, b0 = {p0.z, p0.w}, a1 = {p1.x, p1.y}, b1 = {p1.z, p1.w};
+#pragma unroll
+            for (int k = 0; k + 1 < HPW; k += 2) {
+                unsigned long long ra, rb;
+                reject_masks_packed(fp[k / 2], a0, b0, ra, rb);
+                packed_m0[k] = ~ra;
+                packed_m0[k + 1] = ~rb;
+                reject_masks_packed(fp[k / 2], a1, b1, ra, rb);
+                packed_m1[k] = ~ra;
+                packed_m1[k + 1] = ~rb;
+            }
+        }
+#endif
 #pragma unroll
         for (int k = 0; k < HPW; ++k) {
             unsigned long long m0, m1;  // survivors of the two chunks
+#if SFM_SCORE_PACKED
+            if (ONE_SIDED && HPW % 2 == 0) {
+                m0 = packed_m0[k];
+                m1 = packed_m1[k];
+            } else
+#endif
             if (ONE_SIDED) {
                 m0 = ~reject_mask_one_sided(f[k], p0.x, p0.y, p0.z, p0.w);
                 m1 = ~reject_mask_one_sided(f[k], p1.x, p1.y, p1.z, p1.w);
@@ -663,11 +752,7 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
     };
 
     const int full_chunks = n / kWave;
-    const int chunks_total = (n + kWave - 1) / kWave;
-    // this wave's chunks: [chunk_begin, chunk_end) — everything unless the pass is split
-    const int chunk_begin = (FUSED && units > 1) ? unit * chunks_per_unit : 0;
-    const int chunk_end = (FUSED && units > 1) ? min(chunk_begin + chunks_per_unit, chunks_total) : chunks_total;
-    const int pairs = max(0, (min(chunk_end, full_chunks) - chunk_begin) / 2);
+    const int pairs = full_chunks / 2;
     // The point loads run kDepth steps ahead of the step being processed, in kDepth + 1 register stages that rotate by
     // unrolling, not by register moves (the plain "p = q" loop spent four 64-bit moves per step on that).  One
     // hypothesis per wave is the kernel of small launches (at most two generations of waves): whenever a SIMD holds few of
@@ -680,7 +765,7 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
         // a prefetch reads up to kDepth steps past a pair's last full step: inside the workspace (the next pair's
         // points, or the kPointsPad bytes behind the last pair's) and never used
         static_assert(2048 * kDepth <= kPointsPad, "the prefetch runs this far past a pair's last full step");
-        const float4* __restrict__ next = pts32 + chunk_begin * kWave + lane;  // per-lane cursor: one 64-bit add per step, no index clamping
+        const float4* __restrict__ next = pts32 + lane;  // per-lane cursor: one 64-bit add per step, no index clamping
         float4 stage[kStages][2];
 #pragma unroll
         for (int d = 0; d < kDepth; ++d) {  // reads inside the workspace even when pairs < kDepth (points, then the pad)
@@ -688,7 +773,7 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
             stage[d][1] = next[kWave];
             next += 2 * kWave;
         }
-        int i0 = chunk_begin * kWave + lane, i1 = i0 + kWave;  // both chunks' point indices are carried: one add each per step, not one per hypothesis
+        int i0 = lane, i1 = lane + kWave;  // both chunks' point indices are carried: one add each per step, not one per hypothesis
         int pr = 0;
         for (; pr + kStages <= pairs; pr += kStages) {
 #pragma unroll
@@ -710,7 +795,7 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
             }
         }
     }
-    for (int chunk = chunk_begin + pairs * 2; chunk < chunk_end; ++chunk) {  // at most two iterations
+    for (int chunk = pairs * 2; chunk * kWave < n; ++chunk) {  // at most two iterations
         const int i = chunk * kWave + lane;
         process_tail(pts32[min(i, n - 1)], i, i < n);
     }
@@ -718,10 +803,6 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
     // (finish_hypothesis: the scan treated them like any other point) are one evaluation when they fit one wave — lanes
     // [0, left) take the queued points, lanes [left, left + 8) the sample — instead of two gathers and two passes
     // through the fp64 routine, each with a fraction of the lanes (same-box A/B: 0.3 % of the large launch, 0.4 % of C2).
-    // In a split pass only the wave of a hypothesis' first range fixes up the sample.
-    const bool with_sample = !(FUSED && units > 1) || unit == 0;   // wave-uniform
-    int mine_c = 0;               // split pass: lane k keeps the totals of hypothesis k of this wave
-    double mine_a1 = 0.0, mine_a2 = 0.0;
 #pragma unroll
     for (int k = 0; k < HPW; ++k) {
         const int h = hyp[k];
@@ -729,7 +810,8 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
         double e[9];
 #pragma unroll
         for (int j = 0; j < 9; ++j) e[j] = Eb[(int64_t)h * 9 + j];
-        if (with_sample && left <= kWave - 8) {
+        const int64_t o = b * (int64_t)h_count + h;
+        if (left <= kWave - 8) {
             const bool queued = lane < left;
             const bool sample = !queued && lane < left + 8;
             int idx = 0;
@@ -750,74 +832,20 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
 #if SFM_WAVE_STAMPS
             if (k == 0 && left > 0) ++stamp_batches;
 #endif
+            if (slot_valid[k]) {  // wave-uniform: this slot exists
+                const int ck = sfm::wave_sum(c[k]);
+                const double s1k = sfm::wave_sum(a1[k]);
+                const double s2k = sfm::wave_sum(a2[k]);
+                if (lane == 0) {
+                    cnt[o] = ck;
+                    s1[o] = s1k;
+                    s2[o] = s2k;
+                }
+            }
         } else {
-            if (left > 0) drain(k, left);
-            if (with_sample && lane < 8) {   // the sample fix-up of finish_hypothesis, into the per-lane partials
-                const Corr p = pts[Sb[(int64_t)h * 8 + lane]];
-                const double sed = sfm::sed_value(e, p.xa, p.ya, p.xb, p.yb);
-                const bool counted = sed <= thr;  // already in (c, a1, a2)
-                c[k] += counted ? -1 : 0;
-                const double extra = counted ? 0.0 : sed;
-                a1[k] += extra;
-                a2[k] += extra * extra;
-            }
-        }
-        if (slot_valid[k]) {  // wave-uniform: this slot exists
-            const int ck = sfm::wave_sum(c[k]);
-            const double s1k = sfm::wave_sum(a1[k]);
-            const double s2k = sfm::wave_sum(a2[k]);
-            if (FUSED && units > 1) {
-                if (lane == k) {
-                    mine_c = ck;
-                    mine_a1 = s1k;
-                    mine_a2 = s2k;
-                }
-            } else if (lane == 0) {
-                const int64_t o = b * (int64_t)h_count + h;
-                cnt[o] = ck;
-                s1[o] = s1k;
-                s2[o] = s2k;
-            }
-        }
-    }
-    if (FUSED && units > 1) {
-        // Split pass: lane k publishes this range's partial of hypothesis k and counts itself in; the range that arrives
-        // last adds the partials in range order — a fixed order, so the sums are the same from run to run — and writes
-        // the hypothesis' totals.  Hand-off between waves of different CUs without L1 invalidates: write-through
-        // (sc1) stores, drained, then the agent-scope counter; the reader's loads bypass L1 the same way
-        // (MI355X_MICROARCH.md, inter-workgroup visibility, "valid forms").  The fit launch zeroed the counters.
-        bool owner = false;
-#pragma unroll
-        for (int k = 0; k < HPW; ++k) owner |= (lane == k) && slot_valid[k];
-        int my_h = 0;
-#pragma unroll
-        for (int k = 0; k < HPW; ++k) my_h = (lane == k) ? hyp[k] : my_h;
-        if (owner) {
-            const int64_t hp = split_padded(h_count);
-            int32_t* arrivals = reinterpret_cast<int32_t*>(split);
-            int32_t* part_c = arrivals + hp;
-            double* part_a1 = reinterpret_cast<double*>(part_c + kSplitMaxUnits * hp);
-            double* part_a2 = part_a1 + kSplitMaxUnits * hp;
-            __hip_atomic_store(part_c + unit * hp + my_h, mine_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(part_a1 + unit * hp + my_h, mine_a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(part_a2 + unit * hp + my_h, mine_a2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const int arrived = __hip_atomic_fetch_add(arrivals + my_h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (arrived == units - 1) {
-                int ck = 0;
-                double s1k = 0.0, s2k = 0.0;
-                for (int uu = 0; uu < units; ++uu) {
-                    const int pc = __hip_atomic_load(part_c + uu * hp + my_h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const double p1 = __hip_atomic_load(part_a1 + uu * hp + my_h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const double p2 = __hip_atomic_load(part_a2 + uu * hp + my_h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ck += pc;
-                    s1k = (uu == 0) ? p1 : s1k + p1;
-                    s2k = (uu == 0) ? p2 : s2k + p2;
-                }
-                cnt[my_h] = ck;
-                s1[my_h] = s1k;
-                s2[my_h] = s2k;
-            }
+            drain(k, left);
+            if (slot_valid[k])
+                finish_hypothesis(pts, Sb + (int64_t)h * 8, e, thr, lane, c[k], a1[k], a2[k], cnt + o, s1 + o, s2 + o);
         }
     }
 #if SFM_WAVE_STAMPS
@@ -826,357 +854,6 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
         g_wave_stamps[4 * wave + 1] = __builtin_amdgcn_s_memrealtime();
         g_wave_stamps[4 * wave + 2] = (unsigned long long)hyp[0];
         g_wave_stamps[4 * wave + 3] = (unsigned long long)stamp_batches;
-    }
-#endif
-}
-
-// ------------------------------------------------------------------------------------------------
-// Small passes (one pair, n <= 8192, more than 4096 hypotheses): the whole fp32 point set lives in LDS.
-//
-// What bounds the streaming kernel above on a small launch (profiles/r03/README.md): with one hypothesis per wave every
-// wave pulls all n x 16 B of fp32 points through the CU's vector L1 itself — 10 000 waves x 80 KB = 800 MB per C2
-// launch, none of it an L1 hit (TCP_TCC_READ_REQ x 128 B = all of it): 17 TB/s of L2 traffic for the whole 46 us.
-// More hypotheses per wave cut the bytes but leave one generation of waves whose slowest member — two or four
-// hypotheses, one of which fits the scene and keeps half the points in the exact tier — sets the launch's length.
-// Here one 1024-thread block per CU copies the n x 16 B once into LDS (80 KB at C2, 128 KB at the 8192-point limit)
-// and its 16 waves stream the points from there (ds_read_b128; E stays in scalar registers): no vector memory in
-// the steady-state loop.  Work items are (HPW hypotheses, range of point chunks), handed out through an LDS ticket in
-// the (heaviest-first) order the fit launch left, so the block's waves stay busy until its list is empty.  With only
-// 4 waves per SIMD a wave's own latencies show — an item's prologue (order entry -> E -> filter constants) and epilogue
-// (last partial batch: gather + fp64 routine, three wave sums) are ~1.9 us of mostly waiting (lds_timeline.py) — so
-// a wave runs HPW = 2 hypotheses side by side: their prologues, exact-tier batches and epilogues overlap.
-// Every item leaves its partial (count, sum, sum of squares) per hypothesis in LDS; after a block barrier the partials
-// of a hypothesis are added in range order — a fixed order, so results are run-to-run identical — and written at the
-// hypothesis' own index.  Tier 2 is the same fp64 routine on gathered fp64 records: counts and decisions are those of
-// the exact kernel bit for bit.
-// ------------------------------------------------------------------------------------------------
-constexpr int kLdsWaves = 16;           // waves per block: 4 per SIMD, one block per CU (the point set fills most of its LDS)
-constexpr int kLdsMaxBytes = 160 * 1024;
-constexpr int kLdsControlBytes = 64;    // the item ticket
-constexpr int kLdsStack = 192;          // entries per (wave, hypothesis) survivor stack: <= 63 left + 128 pushed per step
-struct LdsPartial {
-    double a1, a2;
-    int32_t c, pad;
-};
-__host__ __device__ inline int lds_padded_points(int n) { return ((n + 127) & ~127) + 128; }  // whole chunk pairs + one pair of over-read
-__host__ __device__ inline size_t lds_bytes_for(int n, int hpw, int partials) {
-    return kLdsControlBytes + 16 * (size_t)lds_padded_points(n) + 4 * (size_t)kLdsWaves * hpw * kLdsStack +
-           sizeof(LdsPartial) * (size_t)partials;
-}
-
-// Take a ticket from an LDS counter: ONE lane's atomic, broadcast to the wave.  Written as straight-line code with the
-// exec mask set by hand: spelled `if (lane == 0) q = atomicAdd(...); q = readfirstlane(q);` inside the work loop, the
-// compiler threaded the other 63 lanes around the atomic and straight into the next iteration, where readfirstlane then
-// read THEIR q (the first active lane of a partial exec mask) — a wild item index and a GPU memory fault.
-SFM_DEVICE int lds_ticket(unsigned counter_address) {
-    unsigned old;
-    const unsigned one = 1u;
-    unsigned long long saved;
-    asm volatile(
-        "s_mov_b64 %[saved], exec\n\t"
-        "s_mov_b64 exec, 1\n\t"
-        "ds_add_rtn_u32 %[q], %[address], %[one]\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "s_mov_b64 exec, %[saved]"
-        : [q] "=&v"(old), [saved] "=&s"(saved)
-        : [address] "v"(counter_address), [one] "v"(one)
-        : "memory");
-    return (int)__builtin_amdgcn_readfirstlane(old);
-}
-
-template <int HPW>
-__global__ __launch_bounds__(kLdsWaves * kWave, 4) void score_sed_lds_kernel(
-    const Corr* __restrict__ pts, const unsigned char* __restrict__ ws, int n, const double* __restrict__ Eb,
-    const int32_t* __restrict__ Sb, int h_count, double thr, double a_scale, const int32_t* __restrict__ order,
-    int32_t* __restrict__ cnt, double* __restrict__ s1, double* __restrict__ s2, int prep_blocks, int units,
-    int chunks_per_unit) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    int* control = reinterpret_cast<int*>(lds);   // [0] next item
-    float4* P = reinterpret_cast<float4*>(lds + kLdsControlBytes);
-    const int padded = lds_padded_points(n);
-    int32_t* stacks = reinterpret_cast<int32_t*>(lds + kLdsControlBytes + 16 * (size_t)padded);
-    LdsPartial* partial = reinterpret_cast<LdsPartial*>(stacks + kLdsWaves * HPW * kLdsStack);   // [groups][units][HPW]
-
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
-#if SFM_WAVE_STAMPS
-    if (lane == 0 && (int)blockIdx.x * kLdsWaves + wave_in_block < 8192)
-        g_wave_stamps[32 * (size_t)((int)blockIdx.x * kLdsWaves + wave_in_block)] = __builtin_amdgcn_s_memrealtime();
-#endif
-    // this block's hypotheses: slots blockIdx.x, + gridDim.x, ... of the processing order (heaviest first), HPW at a time
-    const int mine = ((int)blockIdx.x < h_count) ? (h_count - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
-    const int groups = (mine + HPW - 1) / HPW;
-    const int items = groups * units;
-
-    {   // the block's copy of the fp32 points (prepared by spare blocks of the fit launch: sfm_score_ws.h); every load of
-        // a thread is in flight before its first LDS store (n <= 8192: at most 9 per thread)
-        const float4* __restrict__ src = reinterpret_cast<const float4*>(ws + ws_points_offset(1));
-        constexpr int kCopies = (kSmallMaxPoints + 256 + kLdsWaves * kWave - 1) / (kLdsWaves * kWave);
-        float4 staged[kCopies];   // (loads beyond the copy re-read the last point: unconditional, so the array stays in registers)
-#pragma unroll
-        for (int r = 0; r < kCopies; ++r) staged[r] = src[min((int)threadIdx.x + r * kLdsWaves * kWave, n - 1)];
-#pragma unroll
-        for (int r = 0; r < kCopies; ++r) {
-            const int i = threadIdx.x + r * kLdsWaves * kWave;
-            if (i < padded) P[i] = staged[r];
-        }
-        if (threadIdx.x == 0) control[0] = 0;
-    }
-    // data-set coordinate maxima from the per-block partial maxima of the preparation (as the FUSED kernel above)
-    float Xa, Ya, Xb, Yb;
-    {
-        const uint32_t* part = reinterpret_cast<const uint32_t*>(ws + ws_buckets_offset(n, 1));
-        uint4 m = make_uint4(0u, 0u, 0u, 0u);
-        if (lane < prep_blocks) m = reinterpret_cast<const uint4*>(part)[lane];
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) {  // prep_blocks <= 16: lanes 0..15
-            m.x = max(m.x, (uint32_t)__shfl_xor((int)m.x, off, 64));
-            m.y = max(m.y, (uint32_t)__shfl_xor((int)m.y, off, 64));
-            m.z = max(m.z, (uint32_t)__shfl_xor((int)m.z, off, 64));
-            m.w = max(m.w, (uint32_t)__shfl_xor((int)m.w, off, 64));
-        }
-        Xa = __uint_as_float(__builtin_amdgcn_readfirstlane(m.x)) * (1.0f + 1e-6f);
-        Ya = __uint_as_float(__builtin_amdgcn_readfirstlane(m.y)) * (1.0f + 1e-6f);
-        Xb = __uint_as_float(__builtin_amdgcn_readfirstlane(m.z)) * (1.0f + 1e-6f);
-        Yb = __uint_as_float(__builtin_amdgcn_readfirstlane(m.w)) * (1.0f + 1e-6f);
-    }
-    __syncthreads();
-
-    unsigned stack_base[HPW];   // LDS byte address of each hypothesis' stack (wave-uniform)
-    const int32_t* stack[HPW];
-#pragma unroll
-    for (int k = 0; k < HPW; ++k) {
-        stack[k] = stacks + (wave_in_block * HPW + k) * kLdsStack;
-        stack_base[k] = __builtin_amdgcn_readfirstlane(
-            (unsigned)(size_t)(__attribute__((address_space(3))) int32_t*)const_cast<int32_t*>(stack[k]));
-    }
-    const unsigned control_address =
-        __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) int*)control);
-    const int chunks_total = (n + kWave - 1) / kWave;
-    const int full_chunks = n / kWave;
-#if SFM_WAVE_STAMPS
-    // diagnostic build (tools/lds_timeline.py): 32 words per wave — begin, start of the items, end of the items, (unused),
-    // end, items, batches, (unused), then (item | batches << 32, begin, end) of the wave's first eight items
-    unsigned long long* stamps = g_wave_stamps + 32 * (size_t)((int)blockIdx.x * kLdsWaves + wave_in_block);
-    const bool stamping = (int)blockIdx.x * kLdsWaves + wave_in_block < 8192 && lane == 0;
-    int stamp_items = 0, stamp_batches = 0;
-    if (stamping) stamps[1] = __builtin_amdgcn_s_memrealtime();
-#endif
-
-    for (;;) {
-        const int q = lds_ticket(control_address);
-        if (q >= items) break;
-#if SFM_WAVE_STAMPS
-        const unsigned long long item_begin = __builtin_amdgcn_s_memrealtime();
-        int batches = 0;
-#endif
-        const int g = q / units, u = q - g * units;
-        int hyp[HPW];
-        bool slot_valid[HPW];
-#pragma unroll
-        for (int k = 0; k < HPW; ++k) {
-            const int j = g * HPW + k;
-            slot_valid[k] = j < mine;
-            const int slot = (int)blockIdx.x + (int)gridDim.x * min(j, mine - 1);
-            hyp[k] = order != nullptr ? __builtin_amdgcn_readfirstlane(order[slot]) : slot;
-        }
-        FilterConsts f[HPW];
-#pragma unroll
-        for (int k = 0; k < HPW; ++k) {
-            double e[9];
-#pragma unroll
-            for (int j = 0; j < 9; ++j) e[j] = Eb[(int64_t)hyp[k] * 9 + j];
-            f[k] = make_filter_consts(e, Xa, Ya, Xb, Yb, a_scale);
-            arm_one_sided(f[k]);
-            f[k].e[0] = uniform(f[k].e[0]);
-            f[k].e[1] = uniform(f[k].e[1]);
-            f[k].e[3] = uniform(f[k].e[3]);
-            f[k].e[4] = uniform(f[k].e[4]);
-        }
-        int c[HPW], top[HPW];
-        double a1[HPW], a2[HPW];
-#pragma unroll
-        for (int k = 0; k < HPW; ++k) {
-            c[k] = 0;
-            top[k] = 0;
-            a1[k] = 0.0;
-            a2[k] = 0.0;
-        }
-        // tier 2: exact fp64 evaluation of `count` (<= 64) queued points of hypothesis k
-        auto drain = [&](int k, int count) __attribute__((always_inline)) {
-            double e[9];
-#pragma unroll
-            for (int j = 0; j < 9; ++j) e[j] = Eb[(int64_t)hyp[k] * 9 + j];
-            const bool active = lane < count;
-            const int idx = active ? stack[k][top[k] - count + lane] : 0;
-            const Corr p = pts[idx];
-            const double sed = sfm::sed_value(e, p.xa, p.ya, p.xb, p.yb);
-            const bool ok = active && (sed <= thr);
-            c[k] += ok ? 1 : 0;
-            const double kept = ok ? sed : 0.0;
-            a1[k] += kept;
-            a2[k] += kept * kept;
-            top[k] -= count;
-#if SFM_WAVE_STAMPS
-            ++batches;
-#endif
-        };
-        auto push = [&](int k, unsigned long long mask, int i) __attribute__((always_inline)) {  // see the streaming kernel's push
-            const unsigned lo = (unsigned)mask, hi = (unsigned)(mask >> 32);
-            const unsigned top_address = stack_base[k] + ((unsigned)top[k] << 2);
-            unsigned scratch;
-            unsigned long long saved;
-            asm volatile(
-                "s_mov_b64 %[saved], exec\n\t"
-                "s_mov_b64 exec, %[mask]\n\t"
-                "v_mbcnt_lo_u32_b32 %[t], %[lo], 0\n\t"
-                "v_mbcnt_hi_u32_b32 %[t], %[hi], %[t]\n\t"
-                "v_lshl_add_u32 %[t], %[t], 2, %[top_address]\n\t"
-                "ds_write_b32 %[t], %[index]\n\t"
-                "s_mov_b64 exec, %[saved]"
-                : [t] "=&v"(scratch), [saved] "=&s"(saved)
-                : [mask] "s"(mask), [lo] "s"(lo), [hi] "s"(hi), [top_address] "s"(top_address), [index] "v"(i)
-                : "memory");
-            top[k] += (int)__popcll(mask);
-        };
-        static_assert(kLdsStack >= (kWave - 1) + 2 * kWave, "a step pushes up to 128 survivors on top of at most 63 left over");
-        auto process_pair = [&](const float4 p0, const float4 p1, int i0, int i1) __attribute__((always_inline)) {
-#pragma unroll
-            for (int k = 0; k < HPW; ++k) {
-                const unsigned long long m0 = ~reject_mask_one_sided(f[k], p0.x, p0.y, p0.z, p0.w);
-                const unsigned long long m1 = ~reject_mask_one_sided(f[k], p1.x, p1.y, p1.z, p1.w);
-                if ((m0 | m1) != 0ull) {  // wave-uniform
-                    push(k, m0, i0);
-                    push(k, m1, i1);
-                    __builtin_amdgcn_wave_barrier();
-                    while (top[k] >= kWave) drain(k, kWave);  // at most twice
-                }
-            }
-        };
-
-        // this item's chunks: [c0, c1); full chunk pairs in the staged loop, at most two chunks with a validity mask behind it
-        const int c0 = u * chunks_per_unit;
-        const int c1 = min(c0 + chunks_per_unit, chunks_total);
-        const int pairs = max(0, (min(c1, full_chunks) - c0) / 2);
-        {
-            const float4* __restrict__ src = P + c0 * kWave + lane;
-            int i0 = c0 * kWave + lane, i1 = i0 + kWave;
-            float4 A0 = src[0], A1 = src[kWave];   // reads run at most one pair past the item's last: inside the padded copy
-            int pr = 0;
-            for (; pr + 2 <= pairs; pr += 2) {
-                const float4 B0 = src[2 * kWave], B1 = src[3 * kWave];
-                process_pair(A0, A1, i0, i1);
-                A0 = src[4 * kWave];
-                A1 = src[5 * kWave];
-                process_pair(B0, B1, i0 + 2 * kWave, i1 + 2 * kWave);
-                src += 4 * kWave;
-                i0 += 4 * kWave;
-                i1 += 4 * kWave;
-            }
-            if (pr < pairs) process_pair(A0, A1, i0, i1);
-        }
-        for (int chunk = c0 + 2 * pairs; chunk < c1; ++chunk) {  // at most two iterations
-            const int i = chunk * kWave + lane;
-            const float4 p = P[i];
-            const unsigned long long valid = __builtin_amdgcn_ballot_w64(i < n);
-#pragma unroll
-            for (int k = 0; k < HPW; ++k) {
-                const unsigned long long mask = ~reject_mask_one_sided(f[k], p.x, p.y, p.z, p.w) & valid;
-                if (mask != 0ull) {
-                    push(k, mask, i);
-                    __builtin_amdgcn_wave_barrier();
-                    if (top[k] >= kWave) drain(k, kWave);
-                }
-            }
-        }
-        // epilogue: the last partial batch; the item of a hypothesis' first range also fixes up the eight sample points
-        // (ransac.py:70-79: never counted, always summed — the scan treated them like any other point, wherever they lie)
-#pragma unroll
-        for (int k = 0; k < HPW; ++k) {
-            const int h = hyp[k];
-            const int left = top[k];  // 0..63
-            double e[9];
-#pragma unroll
-            for (int j = 0; j < 9; ++j) e[j] = Eb[(int64_t)h * 9 + j];
-            if (u == 0 && left <= kWave - 8) {
-                const bool queued = lane < left;
-                const bool sample = !queued && lane < left + 8;
-                int idx = 0;
-                if (queued) idx = stack[k][lane];
-                if (sample) idx = Sb[(int64_t)h * 8 + (lane - left)];
-                const Corr p = pts[idx];
-                const double sed = sfm::sed_value(e, p.xa, p.ya, p.xb, p.yb);
-                const bool in = sed <= thr;
-                const bool add = queued ? in : (sample && !in);
-                c[k] += queued ? (in ? 1 : 0) : ((sample && in) ? -1 : 0);
-                const double kept = add ? sed : 0.0;
-                a1[k] += kept;
-                a2[k] += kept * kept;
-                top[k] = 0;
-#if SFM_WAVE_STAMPS
-                ++batches;
-#endif
-            } else {
-                if (left > 0) drain(k, left);
-                if (u == 0 && lane < 8) {
-                    const Corr p = pts[Sb[(int64_t)h * 8 + lane]];
-                    const double sed = sfm::sed_value(e, p.xa, p.ya, p.xb, p.yb);
-                    const bool counted = sed <= thr;
-                    c[k] += counted ? -1 : 0;
-                    const double extra = counted ? 0.0 : sed;
-                    a1[k] += extra;
-                    a2[k] += extra * extra;
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < HPW; ++k) {
-            const int ck = sfm::wave_sum(c[k]);
-            const double s1k = sfm::wave_sum(a1[k]);
-            const double s2k = sfm::wave_sum(a2[k]);
-            if (lane == 0) {
-                LdsPartial* out = partial + (q * HPW + k);
-                out->c = ck;
-                out->a1 = s1k;
-                out->a2 = s2k;
-            }
-        }
-#if SFM_WAVE_STAMPS
-        if (stamping && stamp_items < 8) {
-            stamps[8 + 3 * stamp_items] = (unsigned long long)q | ((unsigned long long)batches << 32);
-            stamps[9 + 3 * stamp_items] = item_begin;
-            stamps[10 + 3 * stamp_items] = __builtin_amdgcn_s_memrealtime();
-        }
-        ++stamp_items;
-        stamp_batches += batches;
-#endif
-    }
-#if SFM_WAVE_STAMPS
-    if (stamping) stamps[2] = __builtin_amdgcn_s_memrealtime();
-#endif
-    __syncthreads();
-    // a hypothesis' partials added in range order (fixed), written at the hypothesis' own index
-    for (int j = threadIdx.x; j < mine; j += kLdsWaves * kWave) {
-        const int slot = (int)blockIdx.x + (int)gridDim.x * j;
-        const int h = order != nullptr ? order[slot] : slot;
-        const int g = j / HPW, k = j - g * HPW;
-        int ck = 0;
-        double s1k = 0.0, s2k = 0.0;
-        for (int u = 0; u < units; ++u) {
-            const LdsPartial part = partial[(g * units + u) * HPW + k];
-            ck += part.c;
-            s1k = (u == 0) ? part.a1 : s1k + part.a1;
-            s2k = (u == 0) ? part.a2 : s2k + part.a2;
-        }
-        cnt[h] = ck;
-        s1[h] = s1k;
-        s2[h] = s2k;
-    }
-#if SFM_WAVE_STAMPS
-    if (stamping) {
-        stamps[4] = __builtin_amdgcn_s_memrealtime();
-        stamps[5] = (unsigned long long)stamp_items;
-        stamps[6] = (unsigned long long)stamp_batches;
     }
 #endif
 }
@@ -1257,133 +934,23 @@ int32_t* small_pass_order(unsigned char* workspace, int64_t n, int64_t h_count) 
     return reinterpret_cast<int32_t*>(workspace + ws_order_offset(n, 1));
 }
 
-// Ranges of point chunks per group of `hpw` hypotheses for the LDS kernel: the split that minimises (items per wave,
-// rounded up) x (cost of an item) for a block of 16 waves — an item costs its chunks (~46 issue cycles each per
-// hypothesis and wave at four waves per SIMD) plus a fixed ~2 000 cycles of latencies (order entry -> E -> filter
-// constants; last partial batch; wave sums: lds_timeline.py), which hypotheses of one wave overlap.
-static void lds_partition(int n, int hyps_per_block, int hpw, int* units, int* chunks_per_unit) {
-    const int chunks = (n + kWave - 1) / kWave;
-    const int groups = (hyps_per_block + hpw - 1) / hpw;
-    long best_cost = -1;
-    for (int want = 1; want <= 8; ++want) {
-        int cpu = (chunks + want - 1) / want;
-        cpu += cpu & 1;                      // whole chunk pairs
-        const int u = (chunks + cpu - 1) / cpu;
-        const long rounds = ((long)groups * u + kLdsWaves - 1) / kLdsWaves;
-        const long cost = rounds * (185L * hpw * cpu + 4000L);
-        if (best_cost < 0 || cost < best_cost) {
-            best_cost = cost;
-            *units = u;
-            *chunks_per_unit = cpu;
-        }
-    }
-}
-
-// How the scoring launch of a small pass is laid out: hypotheses per wave, and the number of point ranges (`units`, of
-// chunks_per_unit 64-point chunks each) a hypothesis is cut into.  One launch of one to two generations of waves lasts
-// as long as its slowest wave, and a hypothesis that fits the scene costs several times the average: from 4097
-// hypotheses on (below, every wave is resident from the start and one hypothesis per wave is the fastest form) a wave takes
-// FOUR hypotheses (12 VALU instructions per evaluation with the point loads amortised, a quarter of the L2 traffic of
-// one per wave) over a RANGE of the points, so that about two generations of waves (2 x 5120) share the work evenly.
-// SFM_SPLIT_UNITS=0 switches the split off, =k forces k ranges; SFM_SCORE_HPW forces the hypotheses per wave.
-struct SmallPlan {
-    int hpw, units, chunks_per_unit;
-};
-static SmallPlan small_plan(int64_t n, int64_t h_count) {
-    static const int hpw_env = getenv("SFM_SCORE_HPW") ? atoi(getenv("SFM_SCORE_HPW")) : 0;
-    static const int units_env = getenv("SFM_SPLIT_UNITS") ? atoi(getenv("SFM_SPLIT_UNITS")) : -1;
-    const bool forced_hpw = hpw_env == 1 || hpw_env == 2 || hpw_env == 4;
-    SmallPlan plan{(h_count + 1) / 2 >= 5120 ? 2 : 1, 1, 0};
-    if (forced_hpw) plan.hpw = hpw_env;
-    if (h_count <= 4096 || units_env == 0) return plan;
-    const int hpw = forced_hpw ? hpw_env : 4;
-    const int64_t groups = (h_count + hpw - 1) / hpw;
-    int64_t want = units_env > 0 ? units_env : (2 * 5120 + groups / 2) / groups;
-    want = std::max<int64_t>(1, std::min<int64_t>(want, kSplitMaxUnits));
-    const int chunks = (int)((n + kWave - 1) / kWave);
-    int cpu = (int)((chunks + want - 1) / want);
-    cpu += cpu & 1;                                  // whole chunk pairs
-    if (units_env <= 0) cpu = std::max(cpu, 8);      // a range shorter than 512 points is all prologue and epilogue
-    const int units = (chunks + cpu - 1) / cpu;
-    if (units <= 1) return plan;
-    return SmallPlan{hpw, units, cpu};
-}
-
-int32_t* small_pass_arrivals(unsigned char* workspace, int64_t n, int64_t h_count) {
-    if (small_plan(n, h_count).units <= 1) return nullptr;
-    return reinterpret_cast<int32_t*>(workspace + ws_split_offset(n, h_count));
-}
-
 int launch_small_score(const SmallPass& p) {
-    // SFM_SMALL_SCORE=lds picks the LDS-resident kernel (experiments; profiles/r03/README.md)
-    static const char* mode_env = getenv("SFM_SMALL_SCORE");
-    const bool use_lds = mode_env && mode_env[0] == 'l';
-    const int prep_blocks = (int)((p.n + kPrepPoints - 1) / kPrepPoints);
-    if (use_lds) {
-        static const int cus = [] {
-            int dev = 0, count = 256;
-            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&count, hipDeviceAttributeMultiprocessorCount, dev);
-            return count > 0 ? count : 256;
-        }();
-        static const int lds_hpw_env = getenv("SFM_LDS_HPW") ? atoi(getenv("SFM_LDS_HPW")) : 0;
-        int hpw = (lds_hpw_env == 1 || lds_hpw_env == 2 || lds_hpw_env == 4) ? lds_hpw_env : 2;
-        const int grid = (int)std::min<int64_t>(cus, p.h_count);
-        const int per_block = (int)((p.h_count + grid - 1) / grid);
-        int units = 1, chunks_per_unit = 2;
-        lds_partition((int)p.n, per_block, hpw, &units, &chunks_per_unit);
-        static const int units_env = getenv("SFM_LDS_UNITS") ? atoi(getenv("SFM_LDS_UNITS")) : 0;   // experiments
-        if (units_env > 0) {
-            const int chunks = ((int)p.n + kWave - 1) / kWave;
-            chunks_per_unit = (chunks + units_env - 1) / units_env;
-            chunks_per_unit += chunks_per_unit & 1;
-            units = (chunks + chunks_per_unit - 1) / chunks_per_unit;
-        }
-        const int partials = ((per_block + hpw - 1) / hpw) * units * hpw;
-        const size_t bytes = lds_bytes_for((int)p.n, hpw, partials);
-        if (bytes > (size_t)kLdsMaxBytes) return fail(SFM_EINVAL, "sfm_ransac_pass_small: point set too large for the LDS kernel");
-        static bool attribute_set = false;   // LDS beyond 64 KB per block has to be asked for once
-        if (!attribute_set) {
-            const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(score_sed_lds_kernel<1>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxBytes);
-            const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(score_sed_lds_kernel<2>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxBytes);
-            const hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(score_sed_lds_kernel<4>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMaxBytes);
-            if (e1 != hipSuccess || e2 != hipSuccess || e4 != hipSuccess)
-                return check_launch("hipFuncSetAttribute(score_sed_lds_kernel)");
-            attribute_set = true;
-        }
-        if (g_event_before) (void)hipEventRecord(g_event_before, p.stream);
-#define SFM_LAUNCH_LDS(H)                                                                                              \
-    hipLaunchKernelGGL(score_sed_lds_kernel<H>, dim3((unsigned)grid), dim3(kLdsWaves * kWave), bytes, p.stream,        \
-                       (const Corr*)p.corr, p.workspace, (int)p.n, p.E, p.S, (int)p.h_count, p.thr,                    \
-                       one_sided_scale(p.thr), (const int32_t*)small_pass_order(p.workspace, p.n, p.h_count), p.cnt,   \
-                       p.s1, p.s2, prep_blocks, units, chunks_per_unit)
-        switch (hpw) {
-            case 1: SFM_LAUNCH_LDS(1); break;
-            case 2: SFM_LAUNCH_LDS(2); break;
-            default: SFM_LAUNCH_LDS(4); break;
-        }
-#undef SFM_LAUNCH_LDS
-        if (g_event_after) (void)hipEventRecord(g_event_after, p.stream);
-        return check_launch("score_sed_lds_kernel");
-    }
-    // hypotheses per wave without a split: at most 32768 hypotheses are a few generations of waves at best, where two per
-    // wave (7 waves per SIMD) beat four (5 per SIMD; measured at 20 000 and 30 000 hypotheses: 80 vs 85 and 186 vs 198 us
-    // per pass) and one per wave wins as long as two would leave the chip short of waves (profiles/r02/small_pass_hpw.log)
-    const SmallPlan plan = small_plan(p.n, p.h_count);
-    const int hpw = plan.hpw;
+    // hypotheses per wave: at most 32768 hypotheses are a few generations of waves at best, where two per wave (7
+    // waves per SIMD) beat four (5 per SIMD; measured at 20 000 and 30 000 hypotheses: 80 vs 85 and 186 vs 198 us per
+    // pass) and one per wave wins as long as two would leave the chip short of waves (profiles/r02/small_pass_hpw.log)
+    int hpw = (p.h_count + 1) / 2 >= 5120 ? 2 : 1;
+    const int hpw_env = getenv("SFM_SCORE_HPW") ? atoi(getenv("SFM_SCORE_HPW")) : 0;
+    if (hpw_env == 1 || hpw_env == 2 || hpw_env == 4) hpw = hpw_env;
     const int64_t waves = (p.h_count + hpw - 1) / hpw;
-    const int64_t blocks = (waves + 256 / kWave - 1) / (256 / kWave) * plan.units;
+    const int64_t blocks = (waves + 256 / kWave - 1) / (256 / kWave);
     SFM_REQUIRE_GRID("sfm_ransac_pass_small", blocks, 1, 256);
+    const int prep_blocks = (int)((p.n + kPrepPoints - 1) / kPrepPoints);
     const dim3 grid((unsigned)blocks);
-    unsigned char* split = plan.units > 1 ? p.workspace + ws_split_offset(p.n, p.h_count) : nullptr;
     if (g_event_before) (void)hipEventRecord(g_event_before, p.stream);
 #define SFM_LAUNCH_FUSED(H)                                                                                          \
     hipLaunchKernelGGL((score_sed_filtered_kernel<H, true, true>), grid, dim3(256), 0, p.stream, (const Corr*)p.corr, \
                        p.workspace, (int)p.n, p.E, p.S, (int)p.h_count, p.thr, one_sided_scale(p.thr),               \
-                       (const int32_t*)small_pass_order(p.workspace, p.n, p.h_count), p.cnt, p.s1, p.s2, 1, 0,       \
-                       prep_blocks, plan.units, plan.chunks_per_unit, split)
+                       (const int32_t*)small_pass_order(p.workspace, p.n, p.h_count), p.cnt, p.s1, p.s2, 1, 0, prep_blocks)
     switch (hpw) {
         case 1: SFM_LAUNCH_FUSED(1); break;
         case 2: SFM_LAUNCH_FUSED(2); break;

@@ -39,21 +39,7 @@ __host__ __device__ inline int64_t ws_buckets_offset(int64_t n, int64_t batch) {
 __host__ __device__ inline int64_t ws_order_offset(int64_t n, int64_t batch) {
     return ws_buckets_offset(n, batch) + ((4 * (int64_t)kBuckets * batch + 15) / 16) * 16;
 }
-// split small pass (sfm_score.hip): a hypothesis' points are scored in up to kSplitMaxUnits ranges by different waves;
-// behind the scoring order: one arrival counter per hypothesis, then the ranges' partial counts and sums
-//   [h_pad int32 counters][kSplitMaxUnits x h_pad int32][kSplitMaxUnits x h_pad f64][kSplitMaxUnits x h_pad f64]
-constexpr int kSplitMaxUnits = 8;
-constexpr int kSmallMaxHypotheses = 32 * 1024;
-__host__ __device__ inline int64_t split_padded(int64_t h_count) { return (h_count + 3) & ~(int64_t)3; }
-__host__ __device__ inline int64_t ws_split_offset(int64_t n, int64_t h_count) {
-    return ((ws_order_offset(n, 1) + 4 * h_count + 15) / 16) * 16;
-}
-__host__ __device__ inline int64_t split_bytes(int64_t h_count) {
-    return split_padded(h_count) * (4 + kSplitMaxUnits * (4 + 8 + 8));
-}
 __host__ __device__ inline int64_t workspace_bytes_for(int64_t n, int64_t h_count, int64_t batch) {
-    if (batch == 1 && n <= kSmallMaxPoints && h_count <= kSmallMaxHypotheses)   // sizes sfm_ransac_pass_small accepts
-        return ws_split_offset(n, h_count) + split_bytes(h_count);
     return ws_order_offset(n, batch) + 4 * h_count * batch;
 }
 

@@ -62,7 +62,7 @@ def estimate_essential_mat_with_ransac(
     a sampled eight-tuple is degenerate (reference behaviour; ``SFM_DEGENERATE=skip`` ignores such
     hypotheses instead)."""
     with _engine.gc_paused():  # bulk creation of pair tuples and inlier copies: see _engine.gc_paused
-        feature_pairs = [(features_a[m.a_index], features_b[m.b_index]) for m in matches]
+        feature_pairs = _engine.match_pairs(features_a, features_b, matches)
         e, inlier_feature_pairs = fit_with_ransac(
             feature_pairs,
             model_fit_data_count=8,

@@ -468,3 +468,63 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert out.returncode != 0
     assert "launch with torch.distributed.run" not in out.stderr          # the old refusal is gone
     assert "bench.py FAILED" in out.stderr and "local_rank: 1" in out.stderr  # two child ranks were started and reaped
+
+
+def test_hostfast_helper_equals_the_python_paths(native_lib):
+    """csrc/hostfast.c (CPython helper of the drop-in boundary) against the Python code it replaces: pair list from
+    matches (reference epipolar_ransac.py:55-57), coordinates as arrays, deep copies of the picked pairs (reference
+    ransac.py:59,76) — identical objects / values / types, and the shapes it declines fall through to the general path."""
+    import copy
+
+    from lib.common.feature import Feature
+    from lib.feature_matching.matching import Match
+    from structure_from_motion_amd import _native
+    from structure_from_motion_amd.epipolar import _engine
+
+    fast = _native.hostfast()
+    assert fast is not None, "build() compiles csrc/_sfm_hostfast.so"
+    rng = np.random.default_rng(4)
+    n = 3000
+    pa, pb = rng.random((n, 2)) * 600, rng.random((n, 2)) * 600
+    fa = [Feature(x=float(x), y=float(y)) for x, y in pa]
+    fb = [Feature(x=float(x), y=float(y)) for x, y in pb]
+    perm = rng.permutation(n)
+    matches = [Match(a_index=int(i), b_index=int(j)) for i, j in zip(perm, perm[::-1])]
+    pairs = _engine.match_pairs(fa, fb, matches)
+    want = [(fa[m.a_index], fb[m.b_index]) for m in matches]
+    assert len(pairs) == n and all(p[0] is w[0] and p[1] is w[1] for p, w in zip(pairs, want))
+    arr = _engine.pair_arrays(pairs)
+    np.testing.assert_array_equal(arr[0], pa[perm])
+    np.testing.assert_array_equal(arr[1], pb[perm[::-1]])
+    order = rng.permutation(n)[:1700]
+    copies = _engine.copy_pairs(pairs, order)
+    assert copies == [copy.deepcopy(pairs[i]) for i in order]
+    assert all(c[0] is not pairs[i][0] and c[1] is not pairs[i][1] and type(c) is tuple for c, i in zip(copies, order))
+    assert type(copies[0][0]) is Feature and copies[0][0].x is pairs[order[0]][0].x     # atomic values are shared, like deepcopy
+    copies[0][0].x = -1.0
+    assert pairs[order[0]][0].x != -1.0                                                  # ... the instances are not
+    with pytest.raises(IndexError):
+        _engine.copy_pairs(pairs, np.array([n]))
+    with pytest.raises(IndexError):
+        _engine.match_pairs(fa, fb, [Match(a_index=n, b_index=0)])
+    # shapes outside the helper's fast path: same results through the general code
+    fa[3].extra = "tag"             # an extra atomic attribute travels with the copy
+    fa[4].x = 7                     # an int coordinate stays an int
+    fb[5].y = np.float64(2.5)       # a non-atomic value: deep-copied
+    odd = _engine.match_pairs(fa, fb, [Match(a_index=3, b_index=3), Match(a_index=-1, b_index=4),
+                                       Match(a_index=np.int64(5), b_index=5), Match(a_index=4, b_index=0)])
+    assert odd[0][0] is fa[3] and odd[1][0] is fa[-1] and odd[2][1] is fb[5] and odd[3][0] is fa[4]
+    got = _engine.copy_pairs(odd, np.arange(4))
+    assert got == [copy.deepcopy(p) for p in odd]
+    assert got[0][0].extra == "tag" and isinstance(got[3][0].x, int) and isinstance(got[2][1].y, np.float64)
+    np.testing.assert_array_equal(_engine.pair_arrays(odd)[0][3], [7.0, fa[4].y])
+
+    class Point:                    # not a Feature at all
+        def __init__(self, x, y):
+            self.x, self.y = x, y
+
+    other = [(Point(1.0, 2.0), Point(3.0, 4.0)) for _ in range(3)]
+    np.testing.assert_array_equal(_engine.pair_arrays(other)[1], [[3.0, 4.0]] * 3)
+    one = _engine.copy_pairs(other, np.array([1]))
+    assert one[0][0] is not other[1][0] and one[0][0].x == 1.0
+    assert _engine.pair_arrays([]).shape == (2, 0, 2) and _engine.copy_pairs(pairs, np.array([], dtype=np.int64)) == []

@@ -1,4 +1,5 @@
-"""A/B of the small pass's scoring kernels (SFM_SMALL_SCORE=lds|stream, read once per process): runs passes at the
+"""A/B of small-pass variants selected by environment switches the library reads once per process (SFM_SCORE_HPW, experiment
+builds): runs passes at the
 sizes given as N:H pairs on the command line, prints the time per pass and writes cnt / s1 / s2 / record of the last
 pass of each size to OUT (npz) so that two runs can be compared with --compare A B."""
 import os
@@ -45,7 +46,7 @@ for spec in sys.argv[1:]:
         engine.step(1000 + s)
     torch.cuda.synchronize()
     us = (time.perf_counter() - t0) / steps * 1e6
-    print(f"n={n} h={h} mode={os.environ.get('SFM_SMALL_SCORE', 'default')}: {us:.1f} us/pass "
+    print(f"n={n} h={h} hpw={os.environ.get('SFM_SCORE_HPW', 'default')}: {us:.1f} us/pass "
           f"({n * h / us * 1e6:.3e} evals/s)", flush=True)
     ws = engine.ws
     out[f"cnt_{spec}"] = ws.cnt.cpu().numpy()
