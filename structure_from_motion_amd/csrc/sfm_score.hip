@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
     const Corr* __restrict__ corr, const unsigned char* __restrict__ ws, int n,
     const double* __restrict__ E, const int32_t* __restrict__ S, int h_count, double thr, double a_scale,
     const int32_t* __restrict__ order, int32_t* __restrict__ cnt, double* __restrict__ s1,
-    double* __restrict__ s2, int batch, int blocks_per_pair, int prep_blocks) {
+    double* __restrict__ s2, int batch, int blocks_per_pair, int prep_blocks, int sync_every = 0) {
     // survivors' indices, one stack per (wave, hypothesis): pushes append at the top, the exact tier pops the top 64 —
     // which 64 of the queued points a batch takes does not matter (only the summation order depends on it, and that is
     // fixed), and a stack needs neither a wrap-around nor a second cursor
@@ -775,7 +775,18 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
         }
         int i0 = lane, i1 = lane + kWave;  // both chunks' point indices are carried: one add each per step, not one per hypothesis
         int pr = 0;
+        int sync_countdown = 1;   // loop iterations (kStages steps each) until the next block barrier
         for (; pr + kStages <= pairs; pr += kStages) {
+            // Small launches, one hypothesis per wave: every wave streams the whole point set itself, and the waves of a CU
+            // drift apart until nothing hits in its 32 KB vector L1 (TCP_TCC_READ_REQ x 128 B = waves x set size: 797 MB,
+            // 17 TB/s of L2 traffic at C2; profiles/r03/README.md).  A block barrier every few steps keeps the four waves
+            // of a block within one L1's reach of each other, so some of them hit the lines the first one fetched
+            // (L1 -> L2 requests -41 %, kernel -4 %: the traffic was the smaller part of that launch's problem).  Every
+            // wave of a block runs the same number of steps (a function of n alone), and waves that ended are not waited for.
+            if (FUSED && HPW == 1 && sync_every > 0 && --sync_countdown <= 0) {   // wave-uniform
+                __builtin_amdgcn_s_barrier();
+                sync_countdown = sync_every;
+            }
 #pragma unroll
             for (int u = 0; u < kStages; ++u) {
                 stage[(u + kDepth) % kStages][0] = next[0];
@@ -946,11 +957,17 @@ int launch_small_score(const SmallPass& p) {
     SFM_REQUIRE_GRID("sfm_ransac_pass_small", blocks, 1, 256);
     const int prep_blocks = (int)((p.n + kPrepPoints - 1) / kPrepPoints);
     const dim3 grid((unsigned)blocks);
+    // block barrier every `sync_every` iterations (three 128-point steps each) of the one-hypothesis-per-wave loop (0 = never): see the kernel
+    // measured (profiles/r03/small_pass/block_barrier.log): every 1..4 iterations alike, -2 % at 5000 x 10000, -5 % at 7000..8000
+    // points (L1 -> L2 requests -41 %), nothing below ~4000 points; SFM_SCORE_SYNC overrides
+    static const int sync_env = getenv("SFM_SCORE_SYNC") ? atoi(getenv("SFM_SCORE_SYNC")) : -1;
+    const int sync_every = sync_env >= 0 ? sync_env : (hpw == 1 && p.n >= 4096 ? 2 : 0);
     if (g_event_before) (void)hipEventRecord(g_event_before, p.stream);
 #define SFM_LAUNCH_FUSED(H)                                                                                          \
     hipLaunchKernelGGL((score_sed_filtered_kernel<H, true, true>), grid, dim3(256), 0, p.stream, (const Corr*)p.corr, \
                        p.workspace, (int)p.n, p.E, p.S, (int)p.h_count, p.thr, one_sided_scale(p.thr),               \
-                       (const int32_t*)small_pass_order(p.workspace, p.n, p.h_count), p.cnt, p.s1, p.s2, 1, 0, prep_blocks)
+                       (const int32_t*)small_pass_order(p.workspace, p.n, p.h_count), p.cnt, p.s1, p.s2, 1, 0, prep_blocks, \
+                       sync_every)
     switch (hpw) {
         case 1: SFM_LAUNCH_FUSED(1); break;
         case 2: SFM_LAUNCH_FUSED(2); break;

@@ -2,7 +2,7 @@
 # rocprofv3 PMC evidence for the small pass's scoring kernel (run on the GPU box, from the repo root):
 #   tools/collect_small_pass_counters.sh gpurun_out/<dir> [N] [H]
 # One --kernel-trace --stats pass and separate --pmc passes (vector-L1 = TCP, L2 = TCC, SQ) over tools/time_small_pass.py
-# for each setting of SFM_SCORE_HPW (exported before the profiler starts: the program itself follows `--`).
+# for each setting of SFM_SCORE_HPW / SFM_SCORE_SYNC (exported before the profiler starts: the program itself follows `--`).
 set -e -o pipefail
 OUT=${1:?usage: tools/collect_small_pass_counters.sh gpurun_out/<dir> [N] [H]}
 export N=${2:-5000} H=${3:-10000} STEPS=${STEPS:-40}
@@ -16,10 +16,11 @@ run() {  # name, rocprofv3 options...
     rocprofv3 "$@" --output-format csv -d "$OUT/$name" -o p -- python3 "$REPO/tools/time_small_pass.py" > "$OUT/$name.log" 2>&1
 }
 for variant in ${VARIANTS:-hpw1 hpw2}; do
-    unset SFM_SCORE_HPW
+    unset SFM_SCORE_HPW SFM_SCORE_SYNC
     case $variant in
-        hpw1) export SFM_SCORE_HPW=1 ;;
+        hpw1) export SFM_SCORE_HPW=1 SFM_SCORE_SYNC=0 ;;
         hpw2) export SFM_SCORE_HPW=2 ;;
+        hpw1sync) export SFM_SCORE_HPW=1 SFM_SCORE_SYNC=2 ;;
     esac
     echo "== $variant (N=$N H=$H)"
     run ${variant}_trace --kernel-trace --stats
