@@ -21,6 +21,13 @@ constexpr int kN = 624, kM = 397;
 struct Mt19937 {
     uint32_t* mt;
     int index;
+    // output words of the current state block, tempered in one vectorisable sweep when the block is (re)generated: the
+    // draw loop below then spends one load per draw on them instead of the eight dependent ALU operations of the tempering
+    uint32_t tempered[kN];
+
+    Mt19937(uint32_t* state, int position) : mt(state), index(position) {
+        for (int k = position < 0 ? 0 : position; k < kN; ++k) tempered[k] = temper(mt[k]);
+    }
 
     // regenerate the 624 state words (Modules/_randommodule.c genrand_uint32, the `mti >= N` branch)
     void regenerate() {
@@ -36,6 +43,7 @@ struct Mt19937 {
         }
         const uint32_t y = (mt[kN - 1] & 0x80000000u) | (mt[0] & 0x7fffffffu);
         mt[kN - 1] = mt[kM - 1] ^ (y >> 1) ^ mag01[y & 1u];
+        for (int k = 0; k < kN; ++k) tempered[k] = temper(mt[k]);
         index = 0;
     }
 
@@ -60,11 +68,11 @@ struct Mt19937 {
             const int64_t lowest = ((int64_t)1 << (k - 1)) - 1 > 1 ? ((int64_t)1 << (k - 1)) - 1 : 1;  // same k down to here
             while (i >= lowest) {
                 if (index >= kN) regenerate();
-                const uint32_t* word = mt + index;
+                const uint32_t* word = tempered + index;
                 const int available = kN - index;
                 int used = 0;
                 while (used < available && i >= lowest) {
-                    const uint32_t r = temper(word[used++]) >> shift;
+                    const uint32_t r = word[used++] >> shift;
                     const bool accept = (int64_t)r <= i;          // r < i + 1
                     const int64_t j = accept ? (int64_t)r : i;    // rejected: swap perm[i] with itself
                     const int32_t tmp = perm[i];
@@ -86,7 +94,7 @@ extern "C" int sfm_pyshuffle_table(uint32_t* mt_state, int32_t* mt_index, int64_
     if (!mt_state || !mt_index || n < 0 || iterations < 0 || n > 0x7FFFFFFF) return SFM_EINVAL;
     if (*mt_index < 0 || *mt_index > kN) return SFM_EINVAL;
     if (iterations > 0 && !S_out) return SFM_EINVAL;
-    Mt19937 gen{mt_state, *mt_index};
+    Mt19937 gen(mt_state, *mt_index);
     std::vector<int32_t> local;
     int32_t* perm = perm_io;
     if (!perm) {

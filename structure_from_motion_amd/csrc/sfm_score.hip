@@ -522,6 +522,9 @@ __global__ __launch_bounds__(256) void score_class_scatter_kernel(const int32_t*
 #ifndef SFM_SCORE_PREFETCH_DEPTH
 #define SFM_SCORE_PREFETCH_DEPTH 2   // steps of point loads in flight in one-hypothesis waves (1 = the plain loop)
 #endif
+#ifndef SFM_SCORE_PREFETCH_DEPTH_MULTI
+#define SFM_SCORE_PREFETCH_DEPTH_MULTI 1   // ... in waves with two or four hypotheses
+#endif
 template <int HPW, bool ONE_SIDED, bool FUSED = false>
 __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
     const Corr* __restrict__ corr, const unsigned char* __restrict__ ws, int n,
@@ -759,7 +762,7 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
     // them — the waves that could not start with the first generation — a step costs one L2 round trip for the points
     // (~800 cycles against ~300 of work: profiles/r02/README.md, small_pass_timeline.log), so there two steps are in
     // flight; with more hypotheses per wave one step ahead is enough and the registers are needed elsewhere.
-    constexpr int kDepth = HPW == 1 ? SFM_SCORE_PREFETCH_DEPTH : 1;
+    constexpr int kDepth = HPW == 1 ? SFM_SCORE_PREFETCH_DEPTH : SFM_SCORE_PREFETCH_DEPTH_MULTI;
     {
         constexpr int kStages = kDepth + 1;
         // a prefetch reads up to kDepth steps past a pair's last full step: inside the workspace (the next pair's
