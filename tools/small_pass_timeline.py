@@ -24,6 +24,8 @@ for s in range(3):
 torch.cuda.synchronize()
 hpw = int(os.environ.get("SFM_SCORE_HPW", 2 if (h + 1) // 2 >= 5120 else 1))
 waves = (h + hpw - 1) // hpw
+if int(os.environ.get("SFM_SCORE_RESIDENT", "0")) > 0:
+    waves = int(os.environ["SFM_SCORE_RESIDENT"])
 st = np.zeros((waves, 4), dtype=np.uint64)
 assert lib.sfm_debug_read_wave_stamps(st.ctypes.data, waves) == 0
 t0 = st[:, 0].min()
