@@ -310,7 +310,14 @@ def self_launch(args) -> int:
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
     env.setdefault("OMP_NUM_THREADS", "1")
-    return subprocess.call(cmd, env=env)
+    # stdout carries exactly one JSON line: anything else the ranks' libraries write there (the gloo transport announces
+    # its connections on stdout) is passed on to stderr
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for text in child.stdout:
+        is_line = text.startswith('{"metric"')
+        (sys.stdout if is_line else sys.stderr).write(text)
+        (sys.stdout if is_line else sys.stderr).flush()
+    return child.wait()
 
 
 def main():

@@ -578,6 +578,7 @@ def test_bench_two_rank_rehearsal(tmp_path):
     two = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--hypotheses", "4000"] + common,
                          env=env, capture_output=True, text=True, timeout=600, cwd=repo)
     assert two.returncode == 0, two.stderr[-2000:]
+    assert len(two.stdout.strip().splitlines()) == 1, two.stdout[:600]   # ONE line on stdout (gloo's own chatter goes to stderr)
     line2 = json.loads(two.stdout.strip().splitlines()[-1])
     one = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--hypotheses", "8000"] + common,
                          capture_output=True, text=True, timeout=600, cwd=repo)
@@ -587,3 +588,6 @@ def test_bench_two_rank_rehearsal(tmp_path):
     assert line2["config"]["exchange"].startswith("one all_gather")
     assert line2["result"] == line1["result"]        # same winner, error, inlier count from either partition
     assert line2["value"] > 0 and line2["roofline"]["bound"] == "valu-issue"
+    # 3000 x 4000 per rank runs as the lean small pass: its scoring launch is bracketed by the events all the same,
+    # and there is no separate scoring call to time
+    assert line2["roofline"]["kernel_ms"] > 0 and line2["roofline"]["score_call_ms"] is None
