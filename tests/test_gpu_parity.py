@@ -805,7 +805,10 @@ def test_c4_virtual_shards_full_size(dev, c_oracle_lib):
                                         (1000, 64, False), (5000, 10000, True), (8192, 32768, True), (4099, 1300, False),
                                         (600, 4097, True), (2500, 5121, False),
                                         # two hypotheses per wave (>= 10240 hypotheses) with odd step counts and tail chunks
-                                        (1001, 11000, True), (450, 10241, False)])
+                                        (1001, 11000, True), (450, 10241, False),
+                                        # one-hypothesis waves with the block barrier in their loop (>= 4096 points) and a last
+                                        # block whose surplus waves have ended before the first barrier
+                                        (4100, 4099, True), (6000, 7001, False), (8191, 9, True)])
 def test_fused_small_pass_equals_separate_calls(dev, monkeypatch, n, h, philox):
     """sfm_ransac_pass_small (workspace preparation inside the fit launch, scoring from per-block partial maxima,
     selection spread over up to 32 blocks folded by the last arriver) against the five separate calls on the same
@@ -845,6 +848,32 @@ def test_fused_small_pass_equals_separate_calls(dev, monkeypatch, n, h, philox):
         np.testing.assert_array_equal(fused["cnt"][0], ref["cnt"])
         if ref["best"] >= 0:
             np.testing.assert_array_equal(np.nonzero(fused["mask"][0])[0], np.sort(ref["inliers"]))
+
+
+def test_fused_small_pass_random_sizes(dev, monkeypatch):
+    """The lean small pass against the separate calls on 40 random (points, hypotheses) sizes over its whole range — every
+    hypotheses-per-wave choice, loop remainder, partial last block, with and without the block barrier: counts, flags, masks
+    and the winner identical, sums to summation order."""
+    from structure_from_motion_amd._native import AGG_RMS
+
+    rng = np.random.default_rng(2024)
+    sizes = [(int(rng.integers(8, 8193)), int(rng.integers(1, 32769))) for _ in range(28)]
+    sizes += [(int(rng.integers(4096, 8193)), int(rng.integers(4097, 10239))) for _ in range(12)]   # barrier + one per wave
+    for n, h in sizes:
+        _, _, _, corr = scene(n, seed=n % 11)
+        corr_d = dev.to_device(corr).reshape(1, n, 4)
+        outs = []
+        for fused in ("1", "0"):
+            monkeypatch.setenv("SFM_SMALL_PASS", fused)
+            ws = dev.RansacWorkspace(1, n, h)
+            ws.run(corr_d, 1.5e-6, 10 if n >= 300 else 0, AGG_RMS, philox=(n + h, 0, 1))
+            outs.append({k: getattr(ws, k).cpu().numpy().copy() for k in ("flags", "cnt", "s1", "s2", "result", "mask")})
+        fused, plain = outs
+        for key in ("flags", "cnt", "mask"):
+            np.testing.assert_array_equal(fused[key], plain[key], err_msg=f"{key} at {n} x {h}")
+        np.testing.assert_allclose(fused["s1"], plain["s1"], rtol=1e-13, atol=0, equal_nan=True)
+        np.testing.assert_allclose(fused["s2"], plain["s2"], rtol=1e-13, atol=0, equal_nan=True)
+        assert fused["result"][0][1] == plain["result"][0][1], (n, h)
 
 
 def test_fused_small_pass_repeated_and_offsets(dev):
