@@ -586,13 +586,18 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
         const uint32_t* partial = reinterpret_cast<const uint32_t*>(ws + ws_buckets_offset(n, 1));
         uint4 m = make_uint4(0u, 0u, 0u, 0u);
         if (lane < prep_blocks) m = reinterpret_cast<const uint4*>(partial)[lane];
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) {  // prep_blocks <= 16: lanes 0..15
-            m.x = max(m.x, (uint32_t)__shfl_xor((int)m.x, off, 64));
-            m.y = max(m.y, (uint32_t)__shfl_xor((int)m.y, off, 64));
-            m.z = max(m.z, (uint32_t)__shfl_xor((int)m.z, off, 64));
-            m.w = max(m.w, (uint32_t)__shfl_xor((int)m.w, off, 64));
-        }
+        // prep_blocks <= 16: lanes 0..15 are one DPP row; four row rotations leave its maximum in every lane of the row
+        // (all VALU: a __shfl_xor butterfly is four dependent trips through the LDS crossbar in every wave's prologue)
+#define SFM_ROW_MAX(N)                                                        \
+        m.x = max(m.x, (uint32_t)sfm::dpp_row_ror<N>((int)m.x));              \
+        m.y = max(m.y, (uint32_t)sfm::dpp_row_ror<N>((int)m.y));              \
+        m.z = max(m.z, (uint32_t)sfm::dpp_row_ror<N>((int)m.z));              \
+        m.w = max(m.w, (uint32_t)sfm::dpp_row_ror<N>((int)m.w))
+        SFM_ROW_MAX(8);
+        SFM_ROW_MAX(4);
+        SFM_ROW_MAX(2);
+        SFM_ROW_MAX(1);
+#undef SFM_ROW_MAX
         Xa = __uint_as_float(__builtin_amdgcn_readfirstlane(m.x)) * (1.0f + 1e-6f);
         Ya = __uint_as_float(__builtin_amdgcn_readfirstlane(m.y)) * (1.0f + 1e-6f);
         Xb = __uint_as_float(__builtin_amdgcn_readfirstlane(m.z)) * (1.0f + 1e-6f);

@@ -29,6 +29,61 @@ SFM_DEVICE uint64_t hypothesis_key(const int32_t* cnt, const double* s1, const d
     return ok ? bits : kNoModelKey;
 }
 
+// Wave-level fold of (key, best index, first flagged index, flag count) with the rule of ransac.py:83-86 (lowest key,
+// then lowest index): four DPP row rotations leave every lane of a 16-lane row with the row's result, the four rows
+// are then read out with v_readlane and folded in row order.  All VALU: the __shfl_xor butterfly this replaces went
+// through the LDS crossbar (ds_bpermute) six times in a dependent chain with seven words each — most of what a
+// latency-bound selection block waited on.
+template <int N>
+SFM_DEVICE uint64_t dpp_ror_u64(uint64_t x) {
+    const uint32_t lo = (uint32_t)sfm::dpp_row_ror<N>((int)(uint32_t)x), hi = (uint32_t)sfm::dpp_row_ror<N>((int)(uint32_t)(x >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+SFM_DEVICE uint64_t read_lane_u64(uint64_t x, int lane) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, lane);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), lane);
+    return ((uint64_t)hi << 32) | lo;
+}
+SFM_DEVICE void wave_fold(uint64_t& key, int64_t& best, int64_t& first_flag, int& n_flag) {
+    auto combine = [&](uint64_t ok, int64_t ob, int64_t of, int on) {
+        if (ok < key || (ok == key && ob < best)) {
+            key = ok;
+            best = ob;
+        }
+        first_flag = of < first_flag ? of : first_flag;
+        n_flag += on;
+    };
+#define SFM_FOLD_STEP(N)                                                                                       \
+    combine(dpp_ror_u64<N>(key), (int64_t)dpp_ror_u64<N>((uint64_t)best), (int64_t)dpp_ror_u64<N>((uint64_t)first_flag), \
+            sfm::dpp_row_ror<N>(n_flag))
+    SFM_FOLD_STEP(8);
+    SFM_FOLD_STEP(4);
+    SFM_FOLD_STEP(2);
+    SFM_FOLD_STEP(1);
+#undef SFM_FOLD_STEP
+    // rows 1..3 into row 0's result (every lane ends up with the wave's result)
+    uint64_t k0 = read_lane_u64(key, 0);
+    int64_t b0 = (int64_t)read_lane_u64((uint64_t)best, 0), f0 = (int64_t)read_lane_u64((uint64_t)first_flag, 0);
+    int n0 = __builtin_amdgcn_readlane(n_flag, 0);
+#pragma unroll
+    for (int row = 1; row < 4; ++row) {
+        const uint64_t kr = read_lane_u64(key, 16 * row);
+        const int64_t br = (int64_t)read_lane_u64((uint64_t)best, 16 * row);
+        const int64_t fr = (int64_t)read_lane_u64((uint64_t)first_flag, 16 * row);
+        const int nr = __builtin_amdgcn_readlane(n_flag, 16 * row);
+        if (kr < k0 || (kr == k0 && br < b0)) {
+            k0 = kr;
+            b0 = br;
+        }
+        f0 = fr < f0 ? fr : f0;
+        n0 += nr;
+    }
+    key = k0;
+    best = b0;
+    first_flag = f0;
+    n_flag = n0;
+}
+
 // Shared-memory scratch of block_select for a block of THREADS threads.
 template <int THREADS>
 struct SelectScratch {
@@ -50,10 +105,7 @@ __device__ __forceinline__ void block_combine(uint64_t& key, int64_t& best, int6
         first_flag = of < first_flag ? of : first_flag;
         n_flag += on;
     };
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-        combine(__shfl_xor(key, off, 64), __shfl_xor(best, off, 64), __shfl_xor(first_flag, off, 64),
-                __shfl_xor(n_flag, off, 64));
+    wave_fold(key, best, first_flag, n_flag);
     const int wave = threadIdx.x / kWave;
     __syncthreads();  // the scratch may still be read from a previous fold
     if ((threadIdx.x & (kWave - 1)) == 0) {
@@ -107,10 +159,7 @@ __device__ __forceinline__ int64_t block_select(const int32_t* __restrict__ cnt,
         first_flag = of < first_flag ? of : first_flag;
         n_flag += on;
     };
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-        combine(__shfl_xor(key, off, 64), __shfl_xor(best, off, 64), __shfl_xor(first_flag, off, 64),
-                __shfl_xor(n_flag, off, 64));
+    wave_fold(key, best, first_flag, n_flag);
     const int wave = threadIdx.x / kWave;
     if ((threadIdx.x & (kWave - 1)) == 0) {
         sh.key[wave] = key; sh.best[wave] = best; sh.first[wave] = first_flag; sh.flags[wave] = n_flag;
