@@ -41,6 +41,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "sfm_common.h"
 #include "sfm_math.h"
 #include "sfm_score_ws.h"
@@ -162,6 +164,12 @@ __global__ __launch_bounds__(256) void score_reset_kernel(unsigned char* __restr
     static_assert(kBuckets == 256, "one thread per counter word");
     buckets[b * kBuckets + threadIdx.x] = 0;
     if (threadIdx.x < 4) reinterpret_cast<uint32_t*>(ws + 16 * b)[threadIdx.x] = 0u;
+}
+
+// arrival counters of a range-split launch (one per hypothesis): re-armed before every scoring launch
+__global__ __launch_bounds__(256) void score_split_reset_kernel(int32_t* __restrict__ arrivals, int64_t h_count) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < h_count; i += (int64_t)gridDim.x * blockDim.x)
+        arrivals[i] = 0;
 }
 
 __global__ void score_prepare_kernel(const Corr* __restrict__ corr, int64_t n, double a_scale,
@@ -530,7 +538,8 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
     const Corr* __restrict__ corr, const unsigned char* __restrict__ ws, int n,
     const double* __restrict__ E, const int32_t* __restrict__ S, int h_count, double thr, double a_scale,
     const int32_t* __restrict__ order, int32_t* __restrict__ cnt, double* __restrict__ s1,
-    double* __restrict__ s2, int batch, int blocks_per_pair, int prep_blocks, int sync_every = 0) {
+    double* __restrict__ s2, int batch, int blocks_per_pair, int prep_blocks, int sync_every = 0, int units = 1,
+    int chunks_per_unit = 0, unsigned char* __restrict__ split = nullptr) {
     // survivors' indices, one stack per (wave, hypothesis): pushes append at the top, the exact tier pops the top 64 —
     // which 64 of the queued points a batch takes does not matter (only the summation order depends on it, and that is
     // fixed), and a stack needs neither a wrap-around nor a second cursor
@@ -550,6 +559,15 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
     } else {  // one pair, or a grid too large to flatten: plain (block, pair) grid
         pair = blockIdx.y;
         block_of_pair = blockIdx.x;
+    }
+    // Range split (single pair, units > 1): the points are cut into `units` ranges of chunks_per_unit 64-point chunks and
+    // `units` consecutive blocks take the same hypotheses over one range each.  A launch of few generations ends with a
+    // generation that drains for a whole wave duration (435 us of a 2.6 ms launch at 50 000 x 100 000: wave_timeline.py);
+    // half as long waves halve that tail, for one more epilogue per hypothesis (< 2 % of a range's work).
+    int unit = 0;
+    if (units > 1) {
+        unit = block_of_pair % units;
+        block_of_pair /= units;
     }
     const int wave = block_of_pair * (256 / kWave) + wave_in_block;
     const int h0 = wave * HPW;  // first of this wave's HPW slots in the processing order
@@ -760,7 +778,11 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
     };
 
     const int full_chunks = n / kWave;
-    const int pairs = full_chunks / 2;
+    const int chunks_total = (n + kWave - 1) / kWave;
+    // this wave's chunks: [chunk_begin, chunk_end) — every chunk unless the launch is range-split
+    const int chunk_begin = units > 1 ? unit * chunks_per_unit : 0;
+    const int chunk_end = units > 1 ? min(chunk_begin + chunks_per_unit, chunks_total) : chunks_total;
+    const int pairs = max(0, (min(chunk_end, full_chunks) - chunk_begin) / 2);
     // The point loads run kDepth steps ahead of the step being processed, in kDepth + 1 register stages that rotate by
     // unrolling, not by register moves (the plain "p = q" loop spent four 64-bit moves per step on that).  One
     // hypothesis per wave is the kernel of small launches (at most two generations of waves): whenever a SIMD holds few of
@@ -773,7 +795,7 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
         // a prefetch reads up to kDepth steps past a pair's last full step: inside the workspace (the next pair's
         // points, or the kPointsPad bytes behind the last pair's) and never used
         static_assert(2048 * kDepth <= kPointsPad, "the prefetch runs this far past a pair's last full step");
-        const float4* __restrict__ next = pts32 + lane;  // per-lane cursor: one 64-bit add per step, no index clamping
+        const float4* __restrict__ next = pts32 + chunk_begin * kWave + lane;  // per-lane cursor: one 64-bit add per step, no index clamping
         float4 stage[kStages][2];
 #pragma unroll
         for (int d = 0; d < kDepth; ++d) {  // reads inside the workspace even when pairs < kDepth (points, then the pad)
@@ -781,7 +803,7 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
             stage[d][1] = next[kWave];
             next += 2 * kWave;
         }
-        int i0 = lane, i1 = lane + kWave;  // both chunks' point indices are carried: one add each per step, not one per hypothesis
+        int i0 = chunk_begin * kWave + lane, i1 = i0 + kWave;  // both chunks' point indices are carried: one add each per step, not one per hypothesis
         int pr = 0;
         int sync_countdown = 1;   // loop iterations (kStages steps each) until the next block barrier
         for (; pr + kStages <= pairs; pr += kStages) {
@@ -814,7 +836,7 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
             }
         }
     }
-    for (int chunk = pairs * 2; chunk * kWave < n; ++chunk) {  // at most two iterations
+    for (int chunk = chunk_begin + pairs * 2; chunk < chunk_end; ++chunk) {  // at most two iterations
         const int i = chunk * kWave + lane;
         process_tail(pts32[min(i, n - 1)], i, i < n);
     }
@@ -822,6 +844,10 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
     // (finish_hypothesis: the scan treated them like any other point) are one evaluation when they fit one wave — lanes
     // [0, left) take the queued points, lanes [left, left + 8) the sample — instead of two gathers and two passes
     // through the fp64 routine, each with a fraction of the lanes (same-box A/B: 0.3 % of the large launch, 0.4 % of C2).
+    // In a range-split launch only the wave of a hypothesis' first range fixes up the sample.
+    const bool with_sample = units <= 1 || unit == 0;   // wave-uniform
+    int mine_c = 0;               // range split: lane k keeps this range's totals of hypothesis k of the wave
+    double mine_a1 = 0.0, mine_a2 = 0.0;
 #pragma unroll
     for (int k = 0; k < HPW; ++k) {
         const int h = hyp[k];
@@ -829,8 +855,7 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
         double e[9];
 #pragma unroll
         for (int j = 0; j < 9; ++j) e[j] = Eb[(int64_t)h * 9 + j];
-        const int64_t o = b * (int64_t)h_count + h;
-        if (left <= kWave - 8) {
+        if (with_sample && left <= kWave - 8) {
             const bool queued = lane < left;
             const bool sample = !queued && lane < left + 8;
             int idx = 0;
@@ -851,20 +876,75 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
 #if SFM_WAVE_STAMPS
             if (k == 0 && left > 0) ++stamp_batches;
 #endif
-            if (slot_valid[k]) {  // wave-uniform: this slot exists
-                const int ck = sfm::wave_sum(c[k]);
-                const double s1k = sfm::wave_sum(a1[k]);
-                const double s2k = sfm::wave_sum(a2[k]);
-                if (lane == 0) {
-                    cnt[o] = ck;
-                    s1[o] = s1k;
-                    s2[o] = s2k;
-                }
-            }
         } else {
-            drain(k, left);
-            if (slot_valid[k])
-                finish_hypothesis(pts, Sb + (int64_t)h * 8, e, thr, lane, c[k], a1[k], a2[k], cnt + o, s1 + o, s2 + o);
+            if (left > 0) drain(k, left);
+            if (with_sample && lane < 8) {   // the sample fix-up of finish_hypothesis, into the per-lane partials
+                const Corr p = pts[Sb[(int64_t)h * 8 + lane]];
+                const double sed = sfm::sed_value(e, p.xa, p.ya, p.xb, p.yb);
+                const bool counted = sed <= thr;  // already in (c, a1, a2)
+                c[k] += counted ? -1 : 0;
+                const double extra = counted ? 0.0 : sed;   // NaN / inf propagate: such a model never wins
+                a1[k] += extra;
+                a2[k] += extra * extra;
+            }
+        }
+        if (slot_valid[k]) {  // wave-uniform: this slot exists
+            const int ck = sfm::wave_sum(c[k]);
+            const double s1k = sfm::wave_sum(a1[k]);
+            const double s2k = sfm::wave_sum(a2[k]);
+            if (units > 1) {
+                if (lane == k) {
+                    mine_c = ck;
+                    mine_a1 = s1k;
+                    mine_a2 = s2k;
+                }
+            } else if (lane == 0) {
+                const int64_t o = b * (int64_t)h_count + h;
+                cnt[o] = ck;
+                s1[o] = s1k;
+                s2[o] = s2k;
+            }
+        }
+    }
+    if (units > 1) {
+        // Range split: lane k publishes this range's partial of hypothesis k and counts itself in; the range that arrives
+        // last adds the partials in range order — a fixed order, so the sums are the same from run to run — and writes
+        // the hypothesis' totals.  Hand-off between waves of different CUs without L1 invalidates: write-through
+        // (sc1) stores, drained, then the agent-scope counter; the reader's loads bypass L1 the same way
+        // (MI355X_MICROARCH.md, inter-workgroup visibility, "valid forms").  score_split_reset_kernel zeroed the counters.
+        bool owner = false;
+        int my_h = 0;
+#pragma unroll
+        for (int k = 0; k < HPW; ++k) {
+            owner |= (lane == k) && slot_valid[k];
+            my_h = (lane == k) ? hyp[k] : my_h;
+        }
+        if (owner) {
+            const int64_t hp = split_padded(h_count);
+            int32_t* arrivals = reinterpret_cast<int32_t*>(split);
+            int32_t* part_c = arrivals + hp;
+            double* part_a1 = reinterpret_cast<double*>(part_c + kSplitMaxUnits * hp);
+            double* part_a2 = part_a1 + kSplitMaxUnits * hp;
+            __hip_atomic_store(part_c + unit * hp + my_h, mine_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(part_a1 + unit * hp + my_h, mine_a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(part_a2 + unit * hp + my_h, mine_a2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int arrived = __hip_atomic_fetch_add(arrivals + my_h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (arrived == units - 1) {
+                int ck = 0;
+                double s1k = 0.0, s2k = 0.0;
+                for (int uu = 0; uu < units; ++uu) {
+                    const int pc = __hip_atomic_load(part_c + uu * hp + my_h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const double p1 = __hip_atomic_load(part_a1 + uu * hp + my_h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const double p2 = __hip_atomic_load(part_a2 + uu * hp + my_h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ck += pc;
+                    s1k = (uu == 0) ? p1 : s1k + p1;
+                    s2k = (uu == 0) ? p2 : s2k + p2;
+                }
+                cnt[my_h] = ck;
+                s1[my_h] = s1k;
+                s2[my_h] = s2k;
+            }
         }
     }
 #if SFM_WAVE_STAMPS
@@ -900,6 +980,7 @@ struct FilteredLaunch {
     hipStream_t st;
     bool one_sided;
     double a_scale;
+    int units, chunks_per_unit;   // range split (single pair): 1, 0 = off
 };
 
 template <int HPW>
@@ -929,14 +1010,23 @@ int launch_filtered(const FilteredLaunch& a) {
     static const bool xcd_env = getenv("SFM_SCORE_XCD") ? atoi(getenv("SFM_SCORE_XCD")) != 0 : true;
     const bool remap = xcd_env && a.batch > 1 && flat_blocks <= 0x7FFFFFFF;  // see the kernel's block -> (pair, block) map
     const int blocks_per_pair = remap ? (int)grid.x : 0;
-    const dim3 flat = remap ? dim3((unsigned)flat_blocks) : grid;
+    dim3 flat = remap ? dim3((unsigned)flat_blocks) : grid;
+    unsigned char* split = nullptr;
+    if (a.units > 1) {   // single pair: `units` consecutive blocks per group of waves, arrival counters re-armed first
+        flat = dim3(grid.x * (unsigned)a.units);   // (sfm_score_sed checked that this grid fits one launch)
+        split = a.ws + ws_split_offset(a.n, a.h_count);
+        hipLaunchKernelGGL(score_split_reset_kernel, dim3(grid_stride(a.h_count, 256, 1024)), dim3(256), 0, a.st,
+                           reinterpret_cast<int32_t*>(split), (int64_t)a.h_count);
+    }
     if (g_event_before) (void)hipEventRecord(g_event_before, a.st);
     if (a.one_sided)
         hipLaunchKernelGGL((score_sed_filtered_kernel<HPW, true>), flat, dim3(256), 0, a.st, a.corr, a.ws, a.n, a.E, a.S,
-                           a.h_count, a.thr, a.a_scale, order_arg, a.cnt, a.s1, a.s2, (int)a.batch, blocks_per_pair, 0);
+                           a.h_count, a.thr, a.a_scale, order_arg, a.cnt, a.s1, a.s2, (int)a.batch, blocks_per_pair, 0, 0,
+                           a.units, a.chunks_per_unit, split);
     else
         hipLaunchKernelGGL((score_sed_filtered_kernel<HPW, false>), flat, dim3(256), 0, a.st, a.corr, a.ws, a.n, a.E, a.S,
-                           a.h_count, a.thr, a.a_scale, order_arg, a.cnt, a.s1, a.s2, (int)a.batch, blocks_per_pair, 0);
+                           a.h_count, a.thr, a.a_scale, order_arg, a.cnt, a.s1, a.s2, (int)a.batch, blocks_per_pair, 0, 0,
+                           a.units, a.chunks_per_unit, split);
     if (g_event_after) (void)hipEventRecord(g_event_after, a.st);
     return check_launch("score_sed_filtered_kernel");
 }
@@ -1064,8 +1154,30 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
                        (const Corr*)corr, n, a_scale, ws);
     int rc = check_launch("score_prepare_kernel");
     if (rc != SFM_OK) return rc;
+    // Range split: a single-pair launch of 3 to 8 generations of waves (5120 each) is cut into 2 ranges of the points, so
+    // that its last generation — a whole wave duration of draining chip — is half as long: 2.233-2.240 ms against
+    // 2.279-2.297 ms at 50 000 x 100 000 (4.9 generations), 2.803 vs 2.831 at 125 000 hypotheses (6.1).  Four ranges
+    // give the gain back (2.286 ms), launches of one or two generations lose (20 000 x 40 000: 0.480 vs 0.458 ms with
+    // four ranges), more generations have no tail to speak of (profiles/r03/README.md).  SFM_SCORE_SPLIT=0 switches it
+    // off, =k forces k ranges.
+    static const int split_env = getenv("SFM_SCORE_SPLIT") ? atoi(getenv("SFM_SCORE_SPLIT")) : -1;
+    int units = 1, chunks_per_unit = 0;
+    if (batch == 1 && split_env != 0) {
+        const int64_t launch_waves = (h_count + hpw - 1) / hpw;
+        int want = split_env > 0 ? split_env : (launch_waves >= 3 * 5120 && launch_waves < 8 * 5120 ? 2 : 1);
+        want = std::max(1, std::min(want, kSplitMaxUnits));
+        const int chunks = (int)((n + kWave - 1) / kWave);
+        chunks_per_unit = (chunks + want - 1) / want;
+        chunks_per_unit += chunks_per_unit & 1;   // whole chunk pairs
+        if (split_env <= 0) chunks_per_unit = std::max(chunks_per_unit, 64);   // ranges under 4096 points are mostly epilogue
+        units = (chunks + chunks_per_unit - 1) / chunks_per_unit;
+        if (units <= 1 || !sfmhost::grid_fits((int64_t)grid_for((h_count + hpw - 1) / hpw, 256 / kWave) * (int64_t)units, 1, 256)) {
+            units = 1;
+            chunks_per_unit = 0;
+        }
+    }
     const FilteredLaunch args{(const Corr*)corr, ws, (int)n, E, S, (int)h_count, thr, use_order, cnt, s1, s2,
-                              buckets, order, batch, st, one_sided, a_scale};
+                              buckets, order, batch, st, one_sided, a_scale, units, chunks_per_unit};
     switch (hpw) {
         case 1: return launch_filtered<1>(args);
         case 2: return launch_filtered<2>(args);

@@ -39,7 +39,19 @@ __host__ __device__ inline int64_t ws_buckets_offset(int64_t n, int64_t batch) {
 __host__ __device__ inline int64_t ws_order_offset(int64_t n, int64_t batch) {
     return ws_buckets_offset(n, batch) + ((4 * (int64_t)kBuckets * batch + 15) / 16) * 16;
 }
+// Range split of a single-pair launch (sfm_score.hip): a wave's hypotheses are scored over up to kSplitMaxUnits ranges of
+// the points by different waves.  Behind the scoring order: one arrival counter per hypothesis, then the ranges' partial
+// counts and sums —  [h_pad int32 arrivals][kSplitMaxUnits x h_pad int32][kSplitMaxUnits x h_pad f64][kSplitMaxUnits x h_pad f64]
+constexpr int kSplitMaxUnits = 4;
+__host__ __device__ inline int64_t split_padded(int64_t h_count) { return (h_count + 3) & ~(int64_t)3; }
+__host__ __device__ inline int64_t ws_split_offset(int64_t n, int64_t h_count) {   // batch == 1
+    return ((ws_order_offset(n, 1) + 4 * h_count + 15) / 16) * 16;
+}
+__host__ __device__ inline int64_t split_bytes(int64_t h_count) {
+    return split_padded(h_count) * (4 + kSplitMaxUnits * (4 + 8 + 8));
+}
 __host__ __device__ inline int64_t workspace_bytes_for(int64_t n, int64_t h_count, int64_t batch) {
+    if (batch == 1) return ws_split_offset(n, h_count) + split_bytes(h_count);
     return ws_order_offset(n, batch) + 4 * h_count * batch;
 }
 
