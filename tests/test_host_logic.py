@@ -528,3 +528,52 @@ def test_hostfast_helper_equals_the_python_paths(native_lib):
     one = _engine.copy_pairs(other, np.array([1]))
     assert one[0][0] is not other[1][0] and one[0][0].x == 1.0
     assert _engine.pair_arrays([]).shape == (2, 0, 2) and _engine.copy_pairs(pairs, np.array([], dtype=np.int64)) == []
+
+
+def test_gc_paused_restores_the_collector_and_leaves_no_permanent_generation():
+    """_engine.gc_paused: the collector's state is restored, bulk objects created inside do not trigger a young
+    collection right after (they are spliced into the oldest generation), nothing stays frozen, cyclic garbage is still
+    collected afterwards, and a process that keeps a permanent generation of its own is left alone."""
+    import gc
+    import weakref
+
+    from lib.common.feature import Feature
+    from structure_from_motion_amd.epipolar import _engine
+
+    assert gc.isenabled() and gc.get_freeze_count() == 0
+    with _engine.gc_paused():
+        assert not gc.isenabled()
+        with _engine.gc_paused():          # nested: the inner exit must not switch the collector back on
+            made = [(Feature(1.0, 2.0), Feature(3.0, 4.0)) for _ in range(15_000)]
+        assert not gc.isenabled()
+    assert gc.isenabled() and gc.get_freeze_count() == 0
+    assert gc.get_count()[0] < 5_000      # the 45 000 new objects are not waiting in the youngest generation
+    del made
+
+    class Node:
+        pass
+
+    a, b = Node(), Node()
+    a.other, b.other = b, a
+    probe = weakref.ref(a)
+    del a, b
+    gc.collect()
+    assert probe() is None
+
+    keep = [Node() for _ in range(10)]
+    gc.freeze()
+    try:
+        frozen = gc.get_freeze_count()
+        with _engine.gc_paused():
+            made = [(Feature(1.0, 2.0), Feature(3.0, 4.0)) for _ in range(15_000)]
+        assert gc.get_freeze_count() == frozen      # the caller's permanent generation was not released
+    finally:
+        gc.unfreeze()
+    gc.disable()
+    try:
+        with _engine.gc_paused():
+            pass
+        assert not gc.isenabled()                    # a collector the caller had off stays off
+    finally:
+        gc.enable()
+    del keep, made
