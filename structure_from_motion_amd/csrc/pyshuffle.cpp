@@ -69,10 +69,11 @@ struct Mt19937 {
             while (i >= lowest) {
                 if (index >= kN) regenerate();
                 const uint32_t* word = tempered + index;
-                const int available = kN - index;
-                int used = 0;
-                while (used < available && i >= lowest) {
-                    const uint32_t r = word[used++] >> shift;
+                // every draw lowers i by at most one, so the next `safe` draws need no test of the segment's lower end
+                const int64_t room = i - lowest + 1;
+                const int safe = (int)(room < (int64_t)(kN - index) ? room : (int64_t)(kN - index));
+                for (int used = 0; used < safe; ++used) {
+                    const uint32_t r = word[used] >> shift;
                     const bool accept = (int64_t)r <= i;          // r < i + 1
                     const int64_t j = accept ? (int64_t)r : i;    // rejected: swap perm[i] with itself
                     const int32_t tmp = perm[i];
@@ -80,7 +81,7 @@ struct Mt19937 {
                     perm[j] = tmp;
                     i -= accept ? 1 : 0;
                 }
-                index += used;
+                index += safe;
             }
         }
     }
