@@ -91,6 +91,30 @@ def test_pyshuffle_replay_matches_cpython(native_lib, n, iters, seed):
         assert (S[:, n:] == -1).all()
 
 
+@pytest.mark.parametrize("wide", ["1", "0"])
+@pytest.mark.parametrize("n,iters,seed", [(5000, 40, 1), (70000, 3, 2), (1023, 20, 3), (1024, 20, 4), (526, 50, 5), (527, 50, 6),
+                                          (4111, 10, 7), (8191, 6, 8), (8192, 6, 9), (300, 200, 10), (65536 + 15, 2, 11)])
+def test_pyshuffle_replay_wide_and_plain_paths(native_lib, monkeypatch, n, iters, seed, wide):
+    """The sixteen-at-a-time draw classification (AVX-512, segments from i = 511 up) and the one-at-a-time form give
+    CPython's permutation and leave CPython's generator state, at sizes around every place the two hand over: segment
+    ends (2^k - 1), the first block of a segment, the last words of a 624-word state block."""
+    from structure_from_motion_amd import device
+
+    monkeypatch.setenv("SFM_PYSHUFFLE_WIDE", wide)
+    rng = random.Random(seed)
+    for _ in range(seed):
+        rng.random()  # a different position inside the state block per case
+    twin = random.Random()
+    twin.setstate(rng.getstate())
+    S, snap = device.pyshuffle_table(n, iters, rng, snapshot_iteration=iters - 1)
+    perm = list(range(n))
+    for it in range(iters):
+        twin.shuffle(perm)
+        np.testing.assert_array_equal(S[it], perm[:8])
+    np.testing.assert_array_equal(snap, perm)
+    assert rng.getstate() == twin.getstate()
+
+
 def test_pyshuffle_replay_uses_global_random(native_lib):
     from structure_from_motion_amd import device
 
