@@ -11,3 +11,4 @@ done
 MFMA_FORM="-mllvm -amdgpu-mfma-vgpr-form=1"
 [ -n "$MFMA_AGPR" ] && MFMA_FORM=""
 /opt/rocm/bin/hipcc $FLAGS $MFMA_FORM -fPIC -shared -fvisibility=hidden mfma_filter.hip -o bin/libmfma_filter.so
+/opt/rocm/bin/hipcc $FLAGS $MFMA_FORM -fPIC -shared -fvisibility=hidden mfma_bf16_filter.hip -o bin/libmfma_bf16_filter.so
