@@ -46,6 +46,7 @@
 #include "sfm_common.h"
 #include "sfm_math.h"
 #include "sfm_score_ws.h"
+#include "sfm_score_matrix.h"
 
 namespace {
 
@@ -161,8 +162,9 @@ __global__ __launch_bounds__(256) void score_sed_exact_kernel(
 // the graph while a second captured graph was alive faulted on ROCm 7.2 — profiles/r01/README.md).
 __global__ __launch_bounds__(256) void score_reset_kernel(unsigned char* __restrict__ ws, int32_t* __restrict__ buckets) {
     const int64_t b = blockIdx.x;
-    static_assert(kBuckets == 256, "one thread per counter word");
-    buckets[b * kBuckets + threadIdx.x] = 0;
+    static_assert(kBuckets % 256 == 0, "256 threads clear the counter words");
+#pragma unroll
+    for (int k = 0; k < kBuckets / 256; ++k) buckets[b * kBuckets + k * 256 + threadIdx.x] = 0;
     if (threadIdx.x < 4) reinterpret_cast<uint32_t*>(ws + 16 * b)[threadIdx.x] = 0u;
 }
 
@@ -451,9 +453,15 @@ __global__ __launch_bounds__(256) void score_estimate_kernel(const unsigned char
     }
 }
 
-SFM_DEVICE int cost_class(int survivors) {  // 0 = heaviest ... kClasses-1 = no survivors at all
-    return survivors <= 0 ? kClasses - 1 : max(0, 10 - (31 - __builtin_clz((unsigned)survivors)));
+// 0 = heaviest ... kClasses-1 = no survivors at all.  Quarter octaves: the matrix-pipe kernel (sfm_score_matrix.h) runs the 32
+// hypotheses of a wave in lock step through its exact tier, so a wave's hypotheses should differ by tens of per cent, not by 2 x.
+SFM_DEVICE int cost_class(int survivors) {
+    if (survivors <= 0) return kClasses - 1;
+    const int lg = 31 - __builtin_clz((unsigned)survivors);                           // 0..10 (kEstimatePoints = 1024)
+    const int quarter = lg >= 2 ? (int)(((unsigned)survivors >> (lg - 2)) & 3u) : 0;   // the two bits below the leading one
+    return max(0, 4 * (10 - lg) + (3 - quarter));
 }
+static_assert(kEstimatePoints == 1024 && kClasses == 45, "cost_class covers survivor counts up to 2^10 in 44 classes + one for zero");
 
 // Histogram of the cost classes: waves combine through LDS, one global atomic per block and class, and every
 // class counter sits on its own cache line (atomics on one line serialise at ~10 ns each).
@@ -1031,6 +1039,48 @@ int launch_filtered(const FilteredLaunch& a) {
     return check_launch("score_sed_filtered_kernel");
 }
 
+// The ordering pre-pass (cost estimate per hypothesis with the VALU filter, counting sort by class): `cnt` doubles as the
+// estimate buffer, it is rewritten by the scoring kernel afterwards.
+int launch_order(const FilteredLaunch& a) {
+    constexpr int HPW = 4;
+    const int64_t waves = (a.h_count + HPW - 1) / HPW;
+    const dim3 grid(grid_for(waves, 256 / kWave), (unsigned)a.batch);
+    hipLaunchKernelGGL((score_estimate_kernel<HPW, true>), grid, dim3(256), 0, a.st, a.ws, a.n, a.E, a.h_count, a.thr, a.a_scale,
+                       a.cnt);
+    const dim3 per_hyp(grid_for(a.h_count, 256), (unsigned)a.batch);
+    hipLaunchKernelGGL(score_class_count_kernel, per_hyp, dim3(256), 0, a.st, a.cnt, a.h_count, a.buckets);
+    hipLaunchKernelGGL(score_class_scan_kernel, dim3(grid_for(a.batch, 64)), dim3(64), 0, a.st, a.buckets, a.batch);
+    hipLaunchKernelGGL(score_class_scatter_kernel, per_hyp, dim3(256), 0, a.st, a.cnt, a.h_count, a.buckets, a.order);
+    return check_launch("score order kernels");
+}
+
+// Scoring launch with tier 1 on the matrix pipe (sfm_score_matrix.h): one pair, workspace prepared with that kernel's scale.
+int launch_matrix(const FilteredLaunch& a) {
+    using namespace matrixscore;
+    const uint4* table = reinterpret_cast<const uint4*>(a.ws + ws_matrix_offset(a.n, a.h_count));
+    hipLaunchKernelGGL(matrix_prepare_kernel, dim3((unsigned)steps_of(a.n)), dim3(64), 0, a.st, a.corr, a.n, a.a_scale, a.ws,
+                       const_cast<uint4*>(table));
+    const int32_t* order_arg = nullptr;
+    if (a.use_order) {
+        const int rc = launch_order(a);
+        if (rc != SFM_OK) return rc;
+        order_arg = a.order;
+    }
+    const int64_t waves = (a.h_count + kHyps - 1) / kHyps;
+    const unsigned blocks = grid_for(waves, 256 / kWave);
+    unsigned char* split = nullptr;
+    if (a.units > 1) {
+        split = a.ws + ws_split_offset(a.n, a.h_count);
+        hipLaunchKernelGGL(score_split_reset_kernel, dim3(grid_stride(a.h_count, 256, 1024)), dim3(256), 0, a.st,
+                           reinterpret_cast<int32_t*>(split), (int64_t)a.h_count);
+    }
+    if (g_event_before) (void)hipEventRecord(g_event_before, a.st);
+    hipLaunchKernelGGL(score_sed_matrix_kernel, dim3(blocks * (unsigned)a.units), dim3(256), 0, a.st, a.corr, a.ws, table, a.n, a.E,
+                       a.S, a.h_count, a.thr, a.a_scale, order_arg, a.cnt, a.s1, a.s2, a.units, a.chunks_per_unit, split);
+    if (g_event_after) (void)hipEventRecord(g_event_after, a.st);
+    return check_launch("score_sed_matrix_kernel");
+}
+
 }  // namespace
 
 namespace sfmhost {
@@ -1077,6 +1127,15 @@ int launch_small_score(const SmallPass& p) {
 }
 
 }  // namespace sfmhost
+
+#if SFM_MATRIX_STATS
+extern "C" int sfm_debug_matrix_stats(unsigned long long* out, int reset) {   // rounds, points popped, push iterations (per wave)
+    unsigned long long zero[4] = {0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(matrixscore::g_matrix_stats), 32) != hipSuccess) return -2;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(matrixscore::g_matrix_stats), zero, 32) != hipSuccess) return -2;
+    return 0;
+}
+#endif
 
 #if SFM_WAVE_STAMPS
 extern "C" int sfm_debug_read_wave_stamps(unsigned long long* out, int64_t waves) {
@@ -1142,14 +1201,19 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
     const int order_env = getenv("SFM_SCORE_ORDER") ? atoi(getenv("SFM_SCORE_ORDER")) : -1;
     // ... and its fixed cost (~25 us) needs enough points per hypothesis to be won back (measured break-even ~8k).
     const bool use_order = order_env >= 0 ? order_env != 0 : (waves * batch <= 12 * 5120 && n >= 8192);
+    // tier 1 on the matrix pipe (sfm_score_matrix.h): SFM_SCORE_MATRIX=1 / 0 forces it on (where it applies) / off
+    const char* matrix_choice = getenv("SFM_SCORE_MATRIX");   // (read per call: the tests switch it)
+    const int matrix_env = matrix_choice ? atoi(matrix_choice) : -1;
+    const bool matrix = batch == 1 && n <= matrixscore::kMaxPoints && n >= 64 && h_count >= matrixscore::kHyps &&
+                        (matrix_env > 0 || (matrix_env < 0 && false));
     // Small point sets are prepared by one block per pair, which stores the maxima itself; the zeroing kernel is then
     // only needed for the class counters of the ordering pre-pass (a small pass is a chain of ~4 us launches).
     const unsigned prepare_blocks = n <= 8192 ? 1u : grid_stride(n, 256, 64);
-    if (use_order || prepare_blocks > 1)
+    if (use_order || matrix || prepare_blocks > 1)
         hipLaunchKernelGGL(score_reset_kernel, dim3((unsigned)batch), dim3(256), 0, st, ws, buckets);
     // SFM_SCORE_ONE_SIDED=0 switches tier 1 back to the two-sided test (ablation)
     static const bool one_sided = getenv("SFM_SCORE_ONE_SIDED") ? atoi(getenv("SFM_SCORE_ONE_SIDED")) != 0 : true;
-    const double a_scale = one_sided ? one_sided_scale(thr) : 1.0;
+    const double a_scale = matrix ? matrixscore::scale_for(thr) : (one_sided ? one_sided_scale(thr) : 1.0);
     hipLaunchKernelGGL(score_prepare_kernel, dim3(prepare_blocks, (unsigned)batch), dim3(256), 0, st,
                        (const Corr*)corr, n, a_scale, ws);
     int rc = check_launch("score_prepare_kernel");
@@ -1175,6 +1239,25 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
             units = 1;
             chunks_per_unit = 0;
         }
+    }
+    if (matrix) {
+        // waves of 32 hypotheses: ranges of the points so that the launch has about four generations (3072 resident waves)
+        static const int split_env2 = getenv("SFM_SCORE_SPLIT") ? atoi(getenv("SFM_SCORE_SPLIT")) : -1;
+        const int64_t waves32 = (h_count + matrixscore::kHyps - 1) / matrixscore::kHyps;
+        int want = split_env2 > 0 ? split_env2 : (int)std::min<int64_t>(kSplitMaxUnits, std::max<int64_t>(1, (4 * 3072 + waves32 - 1) / waves32));
+        want = std::max(1, std::min(want, kSplitMaxUnits));
+        const int steps = (int)matrixscore::steps_of(n);
+        int steps_per_unit = (steps + want - 1) / want;
+        if (split_env2 <= 0) steps_per_unit = std::max(steps_per_unit, 128);   // ranges under 4096 points are mostly epilogue
+        int m_units = (steps + steps_per_unit - 1) / steps_per_unit;
+        if (m_units <= 1 || split_env2 == 0 ||
+            !sfmhost::grid_fits((int64_t)grid_for(waves32, 256 / kWave) * (int64_t)m_units, 1, 256)) {
+            m_units = 1;
+            steps_per_unit = steps;
+        }
+        const FilteredLaunch margs{(const Corr*)corr, ws, (int)n, E, S, (int)h_count, thr, order_env != 0 && h_count >= 2048, cnt, s1, s2,
+                                   buckets, order, batch, st, true, a_scale, m_units, steps_per_unit};
+        return launch_matrix(margs);
     }
     const FilteredLaunch args{(const Corr*)corr, ws, (int)n, E, S, (int)h_count, thr, use_order, cnt, s1, s2,
                               buckets, order, batch, st, one_sided, a_scale, units, chunks_per_unit};

@@ -1,0 +1,422 @@
+// Scoring kernel with tier 1 on the matrix pipe (included by sfm_score.hip; same results as its two other kernels).
+//
+// Tier 1 of score_sed_filtered_kernel is two small contractions per (point, hypothesis):
+//   r'[i,h] = sum_t m_t(i) E_t(h),  m = (xb xa', xb ya', xb c, yb xa', yb ya', yb c, xa', ya', c)          (9 terms)
+//   dB[i,h] = sum_k q_k(i) g_k(h),  q = (xb^2, xb yb, yb^2, xb, yb, 1),  g = the quadratic form of lb0^2 + lb1^2 in E
+// On v_mfma_f32_32x32x2_f32 they cost more than the 12 VALU instructions they replace (round 2: fp32 MFMA runs at the VALU
+// rate).  The 16-bit MFMAs run at 16 x that rate, and a value is the sum of two fp16 values to 2^-22:
+//   r'  ~ sum_t  m_hi E_hi + m_hi E_mid + m_mid E_hi                                   27 products, K = 32: 2 x v_mfma_f32_32x32x16_f16
+//   dB <= sum_k bf(q_k) bf(g_k) + sum_k up(|q_k|) up(eps |g_k|) + slack(h)             13 products, K = 16: 1 x v_mfma_f32_32x32x16_bf16
+// per 32 points x 32 hypotheses: 96 matrix cycles and 3 VALU instructions per accumulator register (square, compare,
+// shift the result bit in) instead of 12 VALU instructions per 64 evaluations.  Points are the A operand (rows), hypotheses
+// the B operand (columns): lane l holds the results of hypothesis (l & 31) for 16 of a step's 32 points (rows
+// (j & 3) + 8 (j >> 2) + 4 (l >> 5), j = accumulator register).
+//
+// Because a lane belongs to ONE hypothesis, everything behind tier 1 is lane-parallel: each lane pushes its survivors onto its
+// own LDS queue (one word per step with survivors: the step and its 16 survivor bits; slot-major, so the 64 lanes of a push hit 64 banks), and a round of the exact tier has
+// every lane pop one point of its own queue and evaluate it under its own hypothesis (E in 18 VGPRs) into its own (count, sum,
+// sum of squares): no wave reduction anywhere, the two lanes of a hypothesis are added once at the end.  Rounds start when a
+// queue is nearly full and go on until every queue is down to kLow, so with hypotheses of similar load in a wave (the
+// heaviest-first order is dealt row-major here) nearly all lanes are busy in every round.
+//
+// Ranges.  fp16 holds 2^-14 .. 2^16 at full precision, so both sides of the r' chain are scaled by exact powers of two: the
+// point terms by s_p (data set: the largest term maximum lands in [2^13, 2^14)), the hypothesis entries by s_h (per
+// hypothesis: the largest entry in [2^10, 2^11)); the dB chain (bf16: fp32's range) carries s_p^2 and s_h^2, so the compare
+// r''^2 > dB'' is the unscaled one.
+//
+// Bound (in scaled units).  x = hi + mid + res, |res| <= 2^-22 |x| (fp16 subnormals are not flushed by the matrix unit —
+// tools/micro/mfma_bf16_filter.hip probes it — and a flush would cost < 2^-23 relative anyway).  Dropped products per term:
+// mid*mid, res*x, x*res <= 3.1 * 2^-22 |m_t E_t|.  Accumulation: every product of two fp16 is exact in fp32; the matrix unit
+// truncates each aligned addend at the unit of the largest one (probe: <= 3.9 * 2^-23 sum |products| observed), bounded here by
+// one ulp of the largest term per addend: 17 * 2^-23 sum |products| per instruction, 34 * 2^-23 for the chain of two.  Together
+//   |r''_mfma - r''| <= delta'' = 5.2e-6 sum_t |E_t| s_h M_t s_p        (M_t: data-set maximum of |m_t|).
+// dB: bf16 has 8 significant bits, |bf(x) - x| <= 2^-8 |x|, so |bf(q) bf(g) - q g| <= (2^-7 + 2^-16) |q g|, accumulation 17 * 2^-23:
+// eps = 0.008 times sum |q_k g_k| is added through six
+// more slots of the same instruction, all parts rounded up, so the accumulated value is an upper bound of the exact dB.
+// With (x - d)^2 >= x^2 / (1 + k) - d^2 / k, k = 2^-5:   r''^2 > dB''_up + delta''^2 (1 + k) / k  =>  c^2 r^2 >= dB / (1 + k)  =>
+// r^2 / dB >= T  when  c^2 (1 + k) T <= 1, and the derivation at the top of sfm_score.hip applies from there (sed_fl >= (1 - 5 * 2^-53)
+// r_fl^2 / db_fl; T carries the factor 1 + 1e-5 for the fp64 roundings and the square / compare of the test).  The slack
+// rides in the constant slot of the dB chain.  A hypothesis whose magnitudes fall outside the scaled ranges, or with a NaN,
+// gets an infinite slack: nothing is rejected and the exact tier decides everything.
+#pragma once
+
+#ifndef SFM_MATRIX_OCC
+#define SFM_MATRIX_OCC 4     // blocks per CU the matrix-pipe kernel is compiled for (32 KiB of queues each)
+#endif
+#ifndef SFM_MATRIX_POPS
+#define SFM_MATRIX_POPS 2    // points a lane pops per round of the exact tier
+#endif
+#ifndef SFM_MATRIX_STATS
+#define SFM_MATRIX_STATS 0   // diagnostic build: rounds of the exact tier, points popped, push-loop iterations (sfm_debug_matrix_stats)
+#endif
+
+namespace matrixscore {
+
+#if SFM_MATRIX_STATS
+__device__ unsigned long long g_matrix_stats[4];
+#endif
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+constexpr int kTile = 32;        // points per step
+constexpr int kHyps = 32;        // hypotheses per wave
+constexpr int kBlocks = 3;       // K16 operand blocks per step: r' slots 0..15, r' slots 16..31, dB slots 0..15
+constexpr int kCap = 32;         // entries per lane queue (a power of two: the queue is a ring); an entry is one step's survivors
+constexpr int kHigh = kCap - 4;  // a step pushes at most one entry per lane: rounds start when a queue holds this many ...
+constexpr int kLow = 8;          // ... and stop when every queue is down to this
+constexpr double kKappa = 1.0 / 32.0;
+constexpr int kPops = SFM_MATRIX_POPS;
+constexpr int kPointTop = 14, kHypTop = 11;   // scaled magnitudes: point terms < 2^14, hypothesis entries < 2^11
+constexpr int64_t kMaxPoints = sfmws::kMatrixMaxPoints;
+static_assert(kMaxPoints / kTile <= 65536, "a queue entry keeps the step in 16 bits");
+
+__host__ __device__ inline int64_t steps_of(int64_t n) { return (n + kTile - 1) / kTile; }
+__host__ __device__ inline int64_t table_bytes(int64_t n) { return steps_of(n) * kBlocks * 64 * 16; }
+
+// factor carried by the prepared a-side coordinates for this kernel (host side)
+inline double scale_for(double thr) {
+    const double T = thr * (1.0 + 1.0 / 1024.0) * (1.0 + 1e-5);
+    return (T > 1e-30 && T < 1e30) ? (1.0 - 1e-6) / sqrt(T * (1.0 + kKappa)) : 0.0;   // NaN compares false
+}
+
+SFM_DEVICE float bf_round(double x) { return (float)(__bf16)(float)x; }   // nearest (double rounding: < 2^-8 (1 + 2^-15))
+SFM_DEVICE float bf_up(float x) {   // smallest bf16 >= x for x >= 0 (NaN stays NaN, inf stays inf)
+    const float r = (float)(__bf16)x;
+    if (!(r < x)) return r;
+    return __uint_as_float(__float_as_uint(r) + 0x10000u);
+}
+// x (already scaled into fp16's range) = hi + mid + res
+SFM_DEVICE void split2(double x, float& hi, float& mid) {
+    hi = (float)(_Float16)(float)x;
+    mid = (float)(_Float16)(float)(x - (double)hi);
+    if (!(fabs(x) < 1e300)) mid = hi;   // inf / NaN: keep the poison in both parts (inf - inf would be NaN anyway)
+}
+// power of two s with s * x in [2^(top-1), 2^top) (x > 0 finite), else 1
+SFM_DEVICE float scale_to(float x, int top) {
+    if (!(x > 1e-30f) || !(x < 1e30f)) return 1.0f;
+    int ex;
+    (void)frexpf(x, &ex);   // x = f 2^ex, f in [0.5, 1)
+    return ldexpf(1.0f, top - ex);
+}
+// Data-set side of the scaling, the same in the table kernel and in the scoring kernel: M_t >= |m_t| of every point (from the
+// maxima score_prepare_kernel left; w >= the third coordinate of the scaled a) and the power of two s_p.  ok = false (then
+// s_p = 1 and every hypothesis runs with its filter off): magnitudes for which s_p or the s_p^2 of the dB chain would leave
+// fp32's comfortable range — no finite input may turn into an inf or NaN inside the filter, because the test reads the SIGN
+// of dB - r^2.
+struct DataScale {
+    float sp;
+    bool ok;
+};
+SFM_DEVICE DataScale data_scale(const uint32_t* maxima, float w, float (&M)[9]) {
+    const float Xa = __uint_as_float(maxima[0]) * (1.0f + 1e-6f), Ya = __uint_as_float(maxima[1]) * (1.0f + 1e-6f);
+    const float Xb = __uint_as_float(maxima[2]) * (1.0f + 1e-6f), Yb = __uint_as_float(maxima[3]) * (1.0f + 1e-6f);
+    M[0] = Xb * Xa; M[1] = Xb * Ya; M[2] = Xb * w; M[3] = Yb * Xa; M[4] = Yb * Ya; M[5] = Yb * w; M[6] = Xa; M[7] = Ya; M[8] = w;
+    float mmax = 0.f;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) mmax = fmaxf(mmax, M[j] * (1.0f + 1e-6f));
+    DataScale d;
+    d.sp = scale_to(mmax, kPointTop);
+    const float qmax = fmaxf(fmaxf(Xb * Xb, Yb * Yb), 1.0f) * (d.sp * d.sp);   // largest |q_k| s_p^2
+    d.ok = (mmax > 1e-12f) && (mmax < 1e12f) && (qmax < 1e30f) && (d.sp * d.sp > 1e-30f) && (w > 0.0f);
+    if (!d.ok) d.sp = 1.0f;
+    return d;
+}
+
+// slot tables: r' slot s = 3 t + v  (t = term 0..8, v = 0: m_hi E_hi, 1: m_hi E_mid, 2: m_mid E_hi), slots 27..31 zero;
+// dB slot s: 0..5 q_k g_k, 6..11 |q_k| (eps |g_k|), 12: s_p^2 * slack / s_p^2, 13..15 zero
+SFM_DEVICE float point_slot_r(const float (&mh)[9], const float (&mm)[9], int s) {
+    if (s >= 27) return 0.0f;
+    return (s % 3 == 2) ? mm[s / 3] : mh[s / 3];
+}
+SFM_DEVICE float hyp_slot_r(const float (&eh)[9], const float (&em)[9], int s) {
+    if (s >= 27) return 0.0f;
+    return (s % 3 == 1) ? em[s / 3] : eh[s / 3];
+}
+
+// Operand table of the points: for step t (32 points), block b, lane l = 32 half + point: the 8 sixteen-bit values of slots
+// 8 half .. 8 half + 7 of block b — one coalesced 1 KiB load per block and step.  `ws` holds the data-set maxima (of the
+// coordinates scaled by c) that score_prepare_kernel left.  Rows past n are zero (they are masked out of the last step).
+__global__ __launch_bounds__(64) void matrix_prepare_kernel(const Corr* __restrict__ corr, int n, double c,
+                                                           const unsigned char* __restrict__ ws, uint4* __restrict__ table) {
+    const int t = blockIdx.x;
+    const int l = threadIdx.x;
+    const int i = t * kTile + (l & 31);
+    const int half = l >> 5;
+    float M[9];
+    const DataScale data = data_scale(reinterpret_cast<const uint32_t*>(ws), (float)c * (1.0f + 1e-6f), M);
+    const double sp = (double)data.sp;
+    float mh[9], mm[9], q[6];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) mh[j] = mm[j] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) q[j] = 0.0f;
+    if (i < n && data.ok) {   // (filter off for the data set: all-zero operands, so that no product can be a NaN)
+        const Corr p = corr[i];
+        const double xa = p.xa * c, ya = p.ya * c;
+        const double m[9] = {p.xb * xa, p.xb * ya, p.xb * c, p.yb * xa, p.yb * ya, p.yb * c, xa, ya, c};
+#pragma unroll
+        for (int j = 0; j < 9; ++j) split2(m[j] * sp, mh[j], mm[j]);
+        const double qq[6] = {p.xb * p.xb, p.xb * p.yb, p.yb * p.yb, p.xb, p.yb, 1.0};
+#pragma unroll
+        for (int j = 0; j < 6; ++j) q[j] = (float)(qq[j] * (sp * sp));
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        f16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (_Float16)point_slot_r(mh, mm, 16 * b + 8 * half + j);
+        table[((size_t)t * kBlocks + b) * 64 + l] = __builtin_bit_cast(uint4, v);
+    }
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int s = 8 * half + j;
+        float x = 0.0f;
+        if (s < 6) x = bf_round(q[s]);
+        else if (s < 12) x = bf_up(fabsf(q[s - 6]) * (1.0f + 1e-6f));
+        else if (s == 12) x = (i < n) ? (float)(sp * sp) : 0.0f;
+        v[j] = (__bf16)x;
+    }
+    table[((size_t)t * kBlocks + 2) * 64 + l] = __builtin_bit_cast(uint4, v);
+}
+
+// One wave: 32 hypotheses (entries [32 wave, 32 wave + 32) of the processing order) over the steps of one range of the points.
+__global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
+    const Corr* __restrict__ pts, const unsigned char* __restrict__ ws, const uint4* __restrict__ table, int n,
+    const double* __restrict__ E, const int32_t* __restrict__ S, int h_count, double thr, double a_scale,
+    const int32_t* __restrict__ order, int32_t* __restrict__ cnt, double* __restrict__ s1, double* __restrict__ s2, int units,
+    int steps_per_unit, unsigned char* __restrict__ split) {
+    __shared__ uint32_t queues[256 / kWave][kCap][kWave];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    int block_of_range = blockIdx.x, unit = 0;
+    if (units > 1) {   // `units` consecutive blocks take the same hypotheses over one range of the points each
+        unit = block_of_range % units;
+        block_of_range /= units;
+    }
+    const int wave = block_of_range * (256 / kWave) + wave_in_block;
+    const int h0 = wave * kHyps;
+    if (h0 >= h_count) return;   // (no block-level synchronisation in this kernel)
+    const int col = lane & 31, half = lane >> 5;
+    const bool valid = h0 + col < h_count;
+    const int slot = min(h0 + col, h_count - 1);
+    const int h = order != nullptr ? order[slot] : slot;
+
+    // ---- this lane's hypothesis: exact entries for tier 2, scaled split entries and the dB form for tier 1
+    double e[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) e[j] = E[(int64_t)h * 9 + j];
+    constexpr float up = 1.0f + 1e-5f;
+    float M[9];
+    const DataScale data = data_scale(reinterpret_cast<const uint32_t*>(ws), (float)a_scale * (1.0f + 1e-6f), M);
+    const float sp = data.sp;
+    float emax = 0.f, poison = 0.f;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        emax = fmaxf(emax, fabsf((float)e[j]));
+        poison += (float)e[j] * 0.0f;   // NaN anywhere in E must poison the bounds (fmaxf would drop it)
+    }
+    const float sh = scale_to(emax, kHypTop);
+    f16x8 B0, B1;
+    bf16x8 B2;
+    {
+        float eh[9], em[9];
+        float weighted = 0.f;   // sum_t |E_t| s_h M_t s_p
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            split2(e[j] * (double)sh, eh[j], em[j]);
+            weighted += fabsf((float)e[j]) * (1.0f + 1e-6f) * sh * (M[j] * sp);
+        }
+        const float delta = 5.2e-6f * weighted * up + poison;
+        const float slack = (delta * delta) * (float)((1.0 + kKappa) / kKappa) * up + poison;   // in scaled units
+        const double g[6] = {e[0] * e[0] + e[1] * e[1], 2.0 * (e[0] * e[3] + e[1] * e[4]), e[3] * e[3] + e[4] * e[4],
+                             2.0 * (e[0] * e[6] + e[1] * e[7]), 2.0 * (e[3] * e[6] + e[4] * e[7]), e[6] * e[6] + e[7] * e[7]};
+        constexpr float eps = 0.008f;   // >= (1 + 2^-8)^2 - 1 + 20 * 2^-23 = 0.00783 with 2 % to spare
+        float gmax = 0.f;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) gmax = fmaxf(gmax, fabsf((float)g[j]));
+        // filter off for this hypothesis (every operand zero, infinite slack: r'' = 0, dB'' = +inf, nothing rejected and
+        // nothing that could turn into a NaN): magnitudes outside the scaled ranges, a NaN or inf entry, thr off
+        const bool armed = data.ok && (emax > 1e-12f) && (emax < 1e12f) && (gmax > 1e-20f) && (gmax < 1e24f) && (slack == slack) &&
+                           (slack < 1e30f) && (a_scale != 0.0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            B0[j] = (_Float16)(armed ? hyp_slot_r(eh, em, 8 * half + j) : 0.0f);
+            B1[j] = (_Float16)(armed ? hyp_slot_r(eh, em, 16 + 8 * half + j) : 0.0f);
+        }
+        const double sh2 = (double)sh * (double)sh;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int s = 8 * half + j;
+            float x = 0.0f;
+            if (s < 6) x = armed ? bf_round(g[s] * sh2) : 0.0f;
+            else if (s < 12) x = armed ? bf_up(fabsf((float)(g[s - 6] * sh2)) * eps * up) : 0.0f;
+            else if (s == 12) x = armed ? bf_up(slack / (sp * sp) * up) : INFINITY;   // the point side carries s_p^2 in this slot
+            B2[j] = (__bf16)x;
+        }
+    }
+
+    // The lane's queue is a ring of entries (step << 16 | the step's 16 survivor bits), pushed at `tail`, popped at `head`; the
+    // entry being consumed lives in registers (`cur` = its remaining bits, `cur_base` = index of its row 0).  Points of a
+    // hypothesis are therefore scored — and their errors summed — in the order of the points, whatever the other lanes of the
+    // wave do (when rounds happen depends on the fullest queue of the wave, and which hypotheses share a wave on the arrival
+    // order of the counting sort's atomics: a stack would make the summation order, i.e. the last bits of the sums, vary from
+    // run to run).  One entry per step and lane instead of one per survivor: the push is a single predicated store.
+    int c = 0;
+    unsigned head = 0, tail = 0, cur = 0;
+    int cur_base = 0;
+    double a1 = 0.0, a2 = 0.0;
+    uint32_t* const my_queue = &queues[wave_in_block][0][lane];   // slot k at my_queue[k * kWave]
+#if SFM_MATRIX_STATS
+    unsigned stat_rounds = 0, stat_pops = 0, stat_push_iterations = 0;
+#endif
+
+    // one round of the exact tier: every lane takes up to kPops of its queued points (their gathers in flight together) and
+    // scores them, in queue order, under its own hypothesis
+    auto round = [&]() __attribute__((always_inline)) {
+        Corr p[kPops];
+        bool active[kPops];
+#pragma unroll
+        for (int k = 0; k < kPops; ++k) {
+            if (cur == 0u && head != tail) {
+                const unsigned entry = my_queue[(head & (kCap - 1)) * kWave];
+                ++head;
+                cur = entry & 0xffffu;
+                cur_base = (int)(entry >> 16) * kTile + 4 * half;
+            }
+            active[k] = cur != 0u;
+            const int lz = __builtin_clz(cur | 1u);           // 16..31 for a live entry: bit 15 - j is register j
+            cur &= ~(0x80000000u >> lz);
+            const int j = lz - 16;
+            const int i = active[k] ? cur_base + (j & 3) + 8 * (j >> 2) : 0;
+            p[k] = pts[i];
+        }
+#if SFM_MATRIX_STATS
+        stat_rounds += kPops;
+#pragma unroll
+        for (int k = 0; k < kPops; ++k) stat_pops += active[k] ? 1u : 0u;
+#endif
+#pragma unroll
+        for (int k = 0; k < kPops; ++k) {
+            const double sed = sfm::sed_value(e, p[k].xa, p[k].ya, p[k].xb, p[k].yb);
+            const bool ok = active[k] && (sed <= thr);
+            c += ok ? 1 : 0;
+            const double kept = ok ? sed : 0.0;   // masked once; its square is the masked square
+            a1 += kept;
+            a2 += kept * kept;
+        }
+    };
+
+    const int steps_total = (int)steps_of(n);
+    const int step_begin = units > 1 ? unit * steps_per_unit : 0;
+    const int step_end = units > 1 ? min(step_begin + steps_per_unit, steps_total) : steps_total;
+    if (step_begin < step_end) {
+        const uint4* __restrict__ src = table + lane;
+        uint4 A[kBlocks];
+#pragma unroll
+        for (int b = 0; b < kBlocks; ++b) A[b] = src[((size_t)step_begin * kBlocks + b) * 64];
+        for (int t = step_begin; t < step_end; ++t) {
+            uint4 An[kBlocks];
+            const uint4* nxt = src + (size_t)min(t + 1, step_end - 1) * kBlocks * 64;
+#pragma unroll
+            for (int b = 0; b < kBlocks; ++b) An[b] = nxt[b * 64];
+            float16v r = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, d = r;
+            r = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[0]), B0, r, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[2]), B2, d, 0, 0, 0);
+            r = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[1]), B1, r, 0, 0, 0);
+            // rejected bits, register 0 ending up in bit 15: the sign of dB - r^2 (one rounding: the sign is exact, and zero
+            // — equality — keeps the point) shifted in with an alignbit.  A NaN with its sign set counts as rejected, which is
+            // what the exact tier would decide for it (sed = NaN is not <= thr).
+            unsigned rejected = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                rejected = __builtin_amdgcn_alignbit(rejected, __float_as_uint(__builtin_fmaf(-r[j], r[j], d[j])), 31);
+            unsigned keep = ~rejected & 0xffffu;   // bit 15 - j: row (j & 3) + 8 (j >> 2) + 4 half of this step
+            if ((t + 1) * kTile > n) {   // wave-uniform: the last step of a point count that is no multiple of 32
+                unsigned in_range = 0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    in_range |= (t * kTile + (j & 3) + 8 * (j >> 2) + 4 * half < n) ? (1u << (15 - j)) : 0u;
+                keep &= in_range;
+            }
+            if (keep != 0u) {   // push: one entry with this step's survivors
+                my_queue[(tail & (kCap - 1)) * kWave] = ((unsigned)t << 16) | keep;
+                ++tail;
+            }
+            if (__builtin_amdgcn_ballot_w64((int)(tail - head) >= kHigh) != 0ull) {
+                __builtin_amdgcn_wave_barrier();
+                do round(); while (__builtin_amdgcn_ballot_w64((int)(tail - head) > kLow) != 0ull);
+            }
+#pragma unroll
+            for (int b = 0; b < kBlocks; ++b) A[b] = An[b];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    while (__builtin_amdgcn_ballot_w64(tail != head || cur != 0u) != 0ull) round();
+#if SFM_MATRIX_STATS
+    if (lane == 0) {
+        atomicAdd(&g_matrix_stats[0], (unsigned long long)stat_rounds);
+        atomicAdd(&g_matrix_stats[2], (unsigned long long)stat_push_iterations);
+    }
+    atomicAdd(&g_matrix_stats[1], (unsigned long long)stat_pops);
+#endif
+
+    // the eight sample points are never counted and always summed (ransac.py:70-79): the scan treated them like any other
+    // point; the first lane of each hypothesis (in the wave of its first range) re-scores them exactly and patches its totals
+    if ((units <= 1 || unit == 0) && half == 0) {
+        const int32_t* sample = S + (int64_t)h * 8;
+        for (int k = 0; k < 8; ++k) {
+            const Corr p = pts[sample[k]];
+            const double sed = sfm::sed_value(e, p.xa, p.ya, p.xb, p.yb);
+            const bool counted = sed <= thr;   // already in (c, a1, a2)
+            c += counted ? -1 : 0;
+            const double extra = counted ? 0.0 : sed;   // NaN / inf propagate: such a model never wins
+            a1 += extra;
+            a2 += extra * extra;
+        }
+    }
+    // the two lanes of a hypothesis: first half + second half
+    const int c_other = __shfl_xor(c, 32, 64);
+    const double a1_other = __shfl_xor(a1, 32, 64), a2_other = __shfl_xor(a2, 32, 64);
+    const int ck = c + c_other;
+    const double s1k = half == 0 ? a1 + a1_other : a1_other + a1;
+    const double s2k = half == 0 ? a2 + a2_other : a2_other + a2;
+    if (half != 0 || !valid) return;
+    if (units <= 1) {
+        cnt[h] = ck;
+        s1[h] = s1k;
+        s2[h] = s2k;
+        return;
+    }
+    // range split: publish this range's partial, count in; the range that arrives last adds the partials in range order
+    // (see score_sed_filtered_kernel for the hand-off form)
+    const int64_t hp = sfmws::split_padded(h_count);
+    int32_t* arrivals = reinterpret_cast<int32_t*>(split);
+    int32_t* part_c = arrivals + hp;
+    double* part_a1 = reinterpret_cast<double*>(part_c + sfmws::kSplitMaxUnits * hp);
+    double* part_a2 = part_a1 + sfmws::kSplitMaxUnits * hp;
+    __hip_atomic_store(part_c + unit * hp + h, ck, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(part_a1 + unit * hp + h, s1k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(part_a2 + unit * hp + h, s2k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int arrived = __hip_atomic_fetch_add(arrivals + h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (arrived == units - 1) {
+        int total = 0;
+        double t1 = 0.0, t2 = 0.0;
+        for (int uu = 0; uu < units; ++uu) {
+            const int pc = __hip_atomic_load(part_c + uu * hp + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double p1 = __hip_atomic_load(part_a1 + uu * hp + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double p2 = __hip_atomic_load(part_a2 + uu * hp + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            total += pc;
+            t1 = (uu == 0) ? p1 : t1 + p1;
+            t2 = (uu == 0) ? p2 : t2 + p2;
+        }
+        cnt[h] = total;
+        s1[h] = t1;
+        s2[h] = t2;
+    }
+}
+
+}  // namespace matrixscore

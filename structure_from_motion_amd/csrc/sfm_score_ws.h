@@ -3,6 +3,7 @@
 // fused pass in spare blocks of its own launch.
 //
 //   [batch x 4 uint32 maxima][batch x n float4 points][kPointsPad bytes][batch x kBuckets int32][batch x h_count int32]
+//   and for one pair: [range-split region][operand table of the matrix-pipe kernel]   (below)
 //
 // maxima: data-set maxima of |xa'|, |ya'|, |xb|, |yb| of the fp32 points as bit patterns (non-negative floats order
 // like unsigned ints).  buckets: per pair 256 ints — class counters of the longest-first ordering in large launches;
@@ -16,9 +17,9 @@
 namespace sfmws {
 
 constexpr int kEstimatePoints = 1024;        // points scanned by the cost pre-pass
-constexpr int kClasses = 12;                 // coarse cost classes: 10 - floor(log2(survivors)), 0 survivors last
+constexpr int kClasses = 45;                 // cost classes: quarter octaves of the survivor count (4 per power of two, heaviest first), 0 survivors last
 constexpr int kClassStride = 16;             // ints between class counters: one 64-byte line each
-constexpr int kBuckets = 16 * kClassStride;  // ints reserved per batch entry
+constexpr int kBuckets = 48 * kClassStride;  // ints reserved per batch entry
 constexpr int64_t kPointsPad = 4096;         // bytes after the fp32 points: the scoring loop prefetches up to 3 KiB past a pair's last point
 
 // fused small pass (n <= kSmallMaxPoints): the fit launch prepares the points in blocks of kPrepPoints
@@ -42,7 +43,10 @@ __host__ __device__ inline int64_t ws_order_offset(int64_t n, int64_t batch) {
 // Range split of a single-pair launch (sfm_score.hip): a wave's hypotheses are scored over up to kSplitMaxUnits ranges of
 // the points by different waves.  Behind the scoring order: one arrival counter per hypothesis, then the ranges' partial
 // counts and sums —  [h_pad int32 arrivals][kSplitMaxUnits x h_pad int32][kSplitMaxUnits x h_pad f64][kSplitMaxUnits x h_pad f64]
-constexpr int kSplitMaxUnits = 4;
+#ifndef SFM_SPLIT_MAX_UNITS
+#define SFM_SPLIT_MAX_UNITS 4
+#endif
+constexpr int kSplitMaxUnits = SFM_SPLIT_MAX_UNITS;
 __host__ __device__ inline int64_t split_padded(int64_t h_count) { return (h_count + 3) & ~(int64_t)3; }
 __host__ __device__ inline int64_t ws_split_offset(int64_t n, int64_t h_count) {   // batch == 1
     return ((ws_order_offset(n, 1) + 4 * h_count + 15) / 16) * 16;
@@ -50,8 +54,17 @@ __host__ __device__ inline int64_t ws_split_offset(int64_t n, int64_t h_count) {
 __host__ __device__ inline int64_t split_bytes(int64_t h_count) {
     return split_padded(h_count) * (4 + kSplitMaxUnits * (4 + 8 + 8));
 }
+// Operand table of the matrix-pipe kernel (sfm_score_matrix.h; single pair, at most kMatrixMaxPoints points): per step of 32
+// points three blocks of 64 lanes x 16 bytes (96 bytes per point), behind the range-split region.
+constexpr int64_t kMatrixMaxPoints = 65536;
+__host__ __device__ inline int64_t matrix_table_bytes(int64_t n) {
+    return n <= kMatrixMaxPoints ? ((n + 31) / 32) * 3 * 64 * 16 : 0;
+}
+__host__ __device__ inline int64_t ws_matrix_offset(int64_t n, int64_t h_count) {   // batch == 1
+    return ((ws_split_offset(n, h_count) + split_bytes(h_count) + 255) / 256) * 256;
+}
 __host__ __device__ inline int64_t workspace_bytes_for(int64_t n, int64_t h_count, int64_t batch) {
-    if (batch == 1) return ws_split_offset(n, h_count) + split_bytes(h_count);
+    if (batch == 1) return ws_matrix_offset(n, h_count) + matrix_table_bytes(n);
     return ws_order_offset(n, batch) + 4 * h_count * batch;
 }
 

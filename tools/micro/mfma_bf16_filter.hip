@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void bf16_filter_count_kernel(const uint4* __r
     // quadratic form of dB in fp64 from the fp64 E
     const double g[6] = {e[0] * e[0] + e[1] * e[1], 2.0 * (e[0] * e[3] + e[1] * e[4]), e[3] * e[3] + e[4] * e[4],
                          2.0 * (e[0] * e[6] + e[1] * e[7]), 2.0 * (e[3] * e[6] + e[4] * e[7]), e[6] * e[6] + e[7] * e[7]};
-    constexpr float eps = 0.004f;   // >= 2^-8 (1 + 2^-8) + 20 * 2^-23
+    constexpr float eps = 0.008f;   // >= (1 + 2^-8)^2 - 1 + 20 * 2^-23 (bf16: 8 significant bits, unit roundoff 2^-8)
     float gmax = 0.f;
 #pragma unroll
     for (int j = 0; j < 6; ++j) gmax = fmaxf(gmax, fabsf((float)g[j]));
