@@ -1204,8 +1204,11 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
     // tier 1 on the matrix pipe (sfm_score_matrix.h): SFM_SCORE_MATRIX=1 / 0 forces it on (where it applies) / off
     const char* matrix_choice = getenv("SFM_SCORE_MATRIX");   // (read per call: the tests switch it)
     const int matrix_env = matrix_choice ? atoi(matrix_choice) : -1;
-    const bool matrix = batch == 1 && n <= matrixscore::kMaxPoints && n >= 64 && h_count >= matrixscore::kHyps &&
-                        (matrix_env > 0 || (matrix_env < 0 && false));
+    // By itself from 65 536 hypotheses on (waves of 32 hypotheses: fewer leave the chip short of waves; 50 000 x 100 000: 1.96 vs
+    // 2.44 ms, x 125 000: 2.18 vs 3.07, 30 000 x 200 000: 2.10 vs 2.95; x 50 000 a tie, below that the VALU kernel wins:
+    // profiles/r03/README.md)
+    const bool matrix = batch == 1 && n <= matrixscore::kMaxPoints &&
+                        (matrix_env > 0 || (matrix_env < 0 && h_count >= 65536 && n >= 4096));
     // Small point sets are prepared by one block per pair, which stores the maxima itself; the zeroing kernel is then
     // only needed for the class counters of the ordering pre-pass (a small pass is a chain of ~4 us launches).
     const unsigned prepare_blocks = n <= 8192 ? 1u : grid_stride(n, 256, 64);
@@ -1224,7 +1227,8 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
     // give the gain back (2.286 ms), launches of one or two generations lose (20 000 x 40 000: 0.480 vs 0.458 ms with
     // four ranges), more generations have no tail to speak of (profiles/r03/README.md).  SFM_SCORE_SPLIT=0 switches it
     // off, =k forces k ranges.
-    static const int split_env = getenv("SFM_SCORE_SPLIT") ? atoi(getenv("SFM_SCORE_SPLIT")) : -1;
+    const char* split_choice = getenv("SFM_SCORE_SPLIT");   // (read per call: the tests switch it)
+    const int split_env = split_choice ? atoi(split_choice) : -1;
     int units = 1, chunks_per_unit = 0;
     if (batch == 1 && split_env != 0) {
         const int64_t launch_waves = (h_count + hpw - 1) / hpw;
@@ -1242,15 +1246,14 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
     }
     if (matrix) {
         // waves of 32 hypotheses: ranges of the points so that the launch has about four generations (3072 resident waves)
-        static const int split_env2 = getenv("SFM_SCORE_SPLIT") ? atoi(getenv("SFM_SCORE_SPLIT")) : -1;
         const int64_t waves32 = (h_count + matrixscore::kHyps - 1) / matrixscore::kHyps;
-        int want = split_env2 > 0 ? split_env2 : (int)std::min<int64_t>(kSplitMaxUnits, std::max<int64_t>(1, (4 * 3072 + waves32 - 1) / waves32));
+        int want = split_env > 0 ? split_env : (int)std::min<int64_t>(kSplitMaxUnits, std::max<int64_t>(1, (4 * 3072 + waves32 - 1) / waves32));
         want = std::max(1, std::min(want, kSplitMaxUnits));
         const int steps = (int)matrixscore::steps_of(n);
         int steps_per_unit = (steps + want - 1) / want;
-        if (split_env2 <= 0) steps_per_unit = std::max(steps_per_unit, 128);   // ranges under 4096 points are mostly epilogue
+        if (split_env <= 0) steps_per_unit = std::max(steps_per_unit, 128);   // ranges under 4096 points are mostly epilogue
         int m_units = (steps + steps_per_unit - 1) / steps_per_unit;
-        if (m_units <= 1 || split_env2 == 0 ||
+        if (m_units <= 1 || split_env == 0 ||
             !sfmhost::grid_fits((int64_t)grid_for(waves32, 256 / kWave) * (int64_t)m_units, 1, 256)) {
             m_units = 1;
             steps_per_unit = steps;

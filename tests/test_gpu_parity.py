@@ -963,6 +963,14 @@ def _score_both(dev, corr, E, S, thr):
     return exact, filt
 
 
+@pytest.fixture(params=["filtered", "matrix"])
+def score_kernel(request, monkeypatch):
+    """Both two-tier scoring kernels: the VALU filter (score_sed_filtered_kernel) and the matrix-pipe one
+    (score_sed_matrix_kernel, csrc/sfm_score_matrix.h), whatever the library's size rule would pick."""
+    monkeypatch.setenv("SFM_SCORE_MATRIX", "1" if request.param == "matrix" else "0")
+    return request.param
+
+
 def _assert_same_scores(exact, filt):
     np.testing.assert_array_equal(filt[0], exact[0])                      # counts: bit-exact
     for a, b in ((filt[1], exact[1]), (filt[2], exact[2])):                # sums: summation order only
@@ -974,7 +982,7 @@ def _assert_same_scores(exact, filt):
 @pytest.mark.parametrize("thr", [1.5e-6, 1e-3, 0.0, 1e-12, 1e30, -1.0, float("nan"), float("inf"),
                                  # around the range in which the threshold is folded into the prepared coordinates
                                  1e-31, 9e-31, 1.1e-30, 1e-20, 9e29, 1.1e30, 1e38, 1e300, 5e-324])
-def test_filtered_score_equals_exact(dev, n, h, thr):
+def test_filtered_score_equals_exact(dev, score_kernel, n, h, thr):
     _, _, _, corr = scene(n)
     S = orc.philox_sample_table(13, 0, h, n)
     E, _, _ = orc.fit_hypotheses(corr, S)
@@ -986,15 +994,19 @@ def test_filtered_score_equals_exact(dev, n, h, thr):
         np.testing.assert_allclose(filt[2], s2_o, rtol=1e-13)
 
 
-@pytest.mark.parametrize("hpw", [1, 2, 4])
+@pytest.mark.parametrize("hpw", [1, 2, 4, "matrix"])
 def test_filtered_score_every_loop_remainder(dev, monkeypatch, hpw):
     """Every hypotheses-per-wave variant of the two-tier kernel (forced with SFM_SCORE_HPW: small launches would always
     pick one per wave) over point counts that hit each exit of the staged point-load loop — 0, 1, 2, ... full steps of
     128 (the loop is unrolled over 2 or 3 stages), with 0, 1 or 2 tail chunks, full and partial — and hypothesis counts
     that leave slots of the last wave empty.  Counts equal to the all-fp64 kernel's, sums to summation order; a high
     threshold so that the exact tier runs every few steps, a low one so that it almost never does."""
-    monkeypatch.setenv("SFM_SCORE_HPW", str(hpw))
-    for n in (8, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 320, 383, 384, 385, 449, 512, 640, 767, 1000):
+    if hpw == "matrix":   # the matrix-pipe kernel: steps of 32 points, the last one masked; 32 hypothesis slots per wave
+        monkeypatch.setenv("SFM_SCORE_MATRIX", "1")
+    else:
+        monkeypatch.setenv("SFM_SCORE_MATRIX", "0")
+        monkeypatch.setenv("SFM_SCORE_HPW", str(hpw))
+    for n in (8, 31, 32, 33, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 320, 383, 384, 385, 449, 512, 640, 767, 1000):
         _, _, _, corr = scene(n, seed=n)
         for h in (1, 3, 4, 5, 9):
             S = orc.philox_sample_table(n + h, 0, h, n)
@@ -1005,7 +1017,7 @@ def test_filtered_score_every_loop_remainder(dev, monkeypatch, hpw):
 
 
 @pytest.mark.parametrize("scale", [1e-30, 1e-20, 1e-3, 1e3, 1e20, 1e36, 1e40, 1e150, 1e-150, 1e-300])
-def test_filtered_score_extreme_matrix_scales(dev, scale):
+def test_filtered_score_extreme_matrix_scales(dev, score_kernel, scale):
     """SED is scale-free in E, but the fp32 tier over/underflows: every such pair must fall through to
     the exact tier (same counts as the exact kernel at every scale)."""
     n, h = 2000, 96
@@ -1016,7 +1028,7 @@ def test_filtered_score_extreme_matrix_scales(dev, scale):
     _assert_same_scores(exact, filt)
 
 
-def test_filtered_score_pixel_units_and_bad_matrices(dev):
+def test_filtered_score_pixel_units_and_bad_matrices(dev, score_kernel):
     """Un-normalised (pixel) coordinates -> large coordinate maxima; plus NaN / inf / zero matrices."""
     n, h = 3000, 64
     pa, pb, K, _ = scene(n)
@@ -1040,7 +1052,7 @@ def test_filtered_score_pixel_units_and_bad_matrices(dev):
     _assert_same_scores(*_score_both(dev, corr_nan, F, S, 1.0))
 
 
-def test_filtered_score_threshold_ties(dev):
+def test_filtered_score_threshold_ties(dev, score_kernel):
     """Thresholds placed exactly on a point's SED (<= is inclusive) and one ulp below."""
     n, h = 1500, 32
     _, _, _, corr = scene(n)
@@ -1057,7 +1069,7 @@ def test_filtered_score_threshold_ties(dev):
             np.testing.assert_array_equal(filt[0], cnt_o)
 
 
-def test_filtered_score_full_size_equals_exact(dev):
+def test_filtered_score_full_size_equals_exact(dev, score_kernel):
     """50k x 20k: the two kernels agree on every count."""
     n, h = 50_000, 20_000
     _, _, _, corr = scene(n)
@@ -1069,6 +1081,49 @@ def test_filtered_score_full_size_equals_exact(dev):
     assert torch.equal(exact[0], filt[0])
     torch.testing.assert_close(filt[1], exact[1], rtol=1e-13, atol=0, equal_nan=True)
     torch.testing.assert_close(filt[2], exact[2], rtol=1e-13, atol=0, equal_nan=True)
+
+
+@pytest.mark.parametrize("split", ["0", "2", "3", "4"])
+@pytest.mark.parametrize("order", ["0", "1"])
+def test_matrix_score_ranges_and_order(dev, monkeypatch, split, order):
+    """The matrix-pipe kernel with its points cut into 1..4 ranges (partials published per range, added in range order by the
+    range that arrives last) and with / without the heaviest-first order: counts equal to the all-fp64 kernel's, the sums to
+    summation order — and the same bits when the launch is repeated (a lane's queue is first-in first-out, so the order in
+    which a hypothesis' errors are added does not depend on the hypotheses it shares a wave with)."""
+    monkeypatch.setenv("SFM_SCORE_MATRIX", "1")
+    monkeypatch.setenv("SFM_SCORE_SPLIT", split)
+    monkeypatch.setenv("SFM_SCORE_ORDER", order)
+    n, h = 9000, 2500
+    _, _, _, corr = scene(n)
+    S = orc.philox_sample_table(31, 0, h, n)
+    E, _, _ = orc.fit_hypotheses(corr, S)
+    for thr in (1.5e-6, 1e-3):
+        exact, filt = _score_both(dev, corr, E, S, thr)
+        _assert_same_scores(exact, filt)
+        _, again = _score_both(dev, corr, E, S, thr)
+        for a, b in zip(filt, again):
+            np.testing.assert_array_equal(a.view(np.int64) if a.dtype == np.float64 else a,
+                                          b.view(np.int64) if b.dtype == np.float64 else b)
+
+
+def test_score_kernel_size_rule_picks_the_matrix_kernel(dev, monkeypatch):
+    """Left to itself (no SFM_SCORE_MATRIX) a single-pair launch of 65 536 hypotheses or more runs the matrix-pipe kernel:
+    same counts as the all-fp64 kernel, and as the VALU-filter kernel forced with SFM_SCORE_MATRIX=0."""
+    monkeypatch.delenv("SFM_SCORE_MATRIX", raising=False)
+    n, h = 4099, 70_000
+    _, _, _, corr = scene(n)
+    corr_d = dev.to_device(corr).reshape(1, n, 4)
+    S = dev.sample_philox(7, 0, h, n)
+    E, _ = dev.fit_eight_point(corr_d, S)
+    exact = dev.score_sed(corr_d, E, S, 1.5e-6, exact_only=True)
+    default = dev.score_sed(corr_d, E, S, 1.5e-6)
+    monkeypatch.setenv("SFM_SCORE_MATRIX", "0")
+    valu = dev.score_sed(corr_d, E, S, 1.5e-6)
+    assert torch.equal(exact[0], default[0]) and torch.equal(exact[0], valu[0])
+    torch.testing.assert_close(default[1], exact[1], rtol=1e-13, atol=0, equal_nan=True)
+    torch.testing.assert_close(default[2], exact[2], rtol=1e-13, atol=0, equal_nan=True)
+    # the two filtered kernels add in different orders: if the default launch had run the VALU kernel, these would be equal bits
+    assert not torch.equal(default[1].view(torch.int64), valu[1].view(torch.int64))
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -1287,7 +1342,7 @@ def test_batched_pipeline_status_codes(dev):
     assert res[0].status in (batched.OK, batched.NO_MODEL)
 
 
-def test_filtered_score_randomized_sweep(dev):
+def test_filtered_score_randomized_sweep(dev, score_kernel):
     """200 random (matrix family, scale, threshold, size) combinations: the two-tier kernel's counts equal the
     all-fp64 kernel's bit for bit, sums to summation-order accuracy."""
     rng = np.random.default_rng(2024)
