@@ -39,6 +39,16 @@ BYTES_PER_EVAL = 32.0          # xa, ya, xb, yb as f64, read once per hypothesis
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); ~6290 measured-achievable
 SIMDS, CLOCK_GHZ = 1024, 2.4   # 256 CUs x 4 SIMD-32; max clock (MI355X_MICROARCH.md chip table)
 CYC_VALU, CYC_F64 = 2.0, 4.0   # spec issue cycles per wave64 instruction: v_fma_f32 2 (SIMD-32); fp64 at half rate
+CYC_MFMA = 8.0                 # vector-issue cycles a 32x32x16 16-bit MFMA holds (MI355X_MICROARCH.md cycle constants); it runs 32 on the matrix pipe
+
+
+def scoring_kernel_name(variant, n, h):
+    """Which scoring kernel sfm_score_sed launches for a single pair of this size (the rule in csrc/sfm_score.hip)."""
+    if variant == "exact":
+        return "score_sed_exact_kernel"
+    choice = os.environ.get("SFM_SCORE_MATRIX")
+    matrix = n <= 65536 and (int(choice) > 0 if choice not in (None, "") else (n >= 8192 and h >= 4096 and float(n) * h >= 5e8))
+    return "score_sed_matrix_kernel" if matrix else "score_sed_filtered_kernel"
 THR, MIN_EXTRA = 1.5e-6, 10    # reference apps/config/config.yaml:6-9 (RMS aggregation)
 C4_TOTAL = 1_000_000           # BASELINE.json configs[3]
 COUNTERS = os.path.join(REPO, "profiles", "score_traffic.json")
@@ -155,7 +165,7 @@ def roofline(n, h, kernel_ms, call_ms, variant):
     rec, stale = load_counters(n, h)
     out = {
         "bound": "valu-issue",
-        "kernel": "score_sed_filtered_kernel" if variant == "filtered" else "score_sed_exact_kernel",
+        "kernel": scoring_kernel_name(variant, n, h),
         "kernel_ms": kernel_ms,
         "score_call_ms": call_ms,
         "achieved": None, "peak": SIMDS * CLOCK_GHZ, "unit": "G wave-instruction issue cycles/s", "frac": None,
@@ -167,21 +177,27 @@ def roofline(n, h, kernel_ms, call_ms, variant):
         "hbm_physical": None,
         "counters_stale": stale,
         "note": "frac = (VALU wave-instructions per launch x spec issue cycles: 2 per wave64 instruction, 4 per fp64 "
-                "one) / (1024 SIMDs x 2.4 GHz x kernel time by HIP events around the kernel); counters from "
-                "profiles/score_traffic.json (rocprofv3 --pmc, separate passes)",
+                "one, 8 of vector issue per 16-bit MFMA) / (1024 SIMDs x 2.4 GHz x kernel time by HIP events around the "
+                "kernel); counters from profiles/score_traffic.json (rocprofv3 --pmc, separate passes)",
     }
     if rec is None or variant != "filtered":
+        return out
+    if rec.get("kernel_short") and rec["kernel_short"] != out["kernel"]:
+        out["counters_stale"] = True   # the committed counters are another kernel's
         return out
     c = rec["counters"]
     f64 = sum(c.get(k, 0.0) for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64",
                                       "SQ_INSTS_VALU_TRANS_F64"))
     valu = c["SQ_INSTS_VALU"]
     mfma = c.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0)
-    cycles = (valu - f64) * CYC_VALU + f64 * CYC_F64
+    mfma_insts = c.get("SQ_INSTS_MFMA", 0.0)
+    cycles = (valu - f64) * CYC_VALU + f64 * CYC_F64 + mfma_insts * CYC_MFMA
     out["achieved"] = cycles / seconds / 1e9
     out["frac"] = out["achieved"] / out["peak"]
     out["valu"] = {"insts_per_launch": valu, "fp64_insts": f64, "per_64_evals": valu / (evals / 64.0),
-                   "issue_cycles_per_simd": cycles / SIMDS, "mfma_mops_f32": mfma or None}
+                   "issue_cycles_per_simd": cycles / SIMDS, "mfma_mops_f32": mfma or None, "mfma_insts": mfma_insts or None,
+                   "matrix_pipe_busy_frac": (c["SQ_VALU_MFMA_BUSY_CYCLES"] / SIMDS / (seconds * CLOCK_GHZ * 1e9)
+                                             if c.get("SQ_VALU_MFMA_BUSY_CYCLES") else None)}
     if "GRBM_GUI_ACTIVE" in c and c.get("profiled_kernel_ms"):
         clock = c["GRBM_GUI_ACTIVE"] / 8.0 / (c["profiled_kernel_ms"] * 1e-3) / 1e9
         out["valu"]["clock_GHz_under_profiler"] = clock
@@ -416,8 +432,14 @@ def main():
         # the same pass with each scoring kernel, 3 steps each: the all-fp64 kernel (every evaluation in fp64) and
         # the default two-tier kernel (conservative fp32 reject filter + the same fp64 routine for the survivors)
         variants = {}
-        for name, env in (("exact_f64", "exact"), ("filtered", "filtered")):
+        # and the two-tier kernel with tier 1 on the matrix pipe (the default from 65 536 hypotheses on)
+        saved_matrix = os.environ.get("SFM_SCORE_MATRIX")
+        for name, env, matrix in (("exact_f64", "exact", None), ("filtered", "filtered", "0"), ("matrix", "filtered", "1")):
             os.environ["SFM_SCORE_KERNEL"] = env
+            if matrix is None:
+                os.environ.pop("SFM_SCORE_MATRIX", None)
+            else:
+                os.environ["SFM_SCORE_MATRIX"] = matrix
             engine.step(args.seed + 77)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -428,6 +450,10 @@ def main():
             variants[name] = {"ms_per_step": wall * 1e3, "value": float(n) * h / wall,
                               "kernel_ms": float(np.mean([a.elapsed_time(b) for a, b in kernel_ev[:3]]))}
         os.environ.pop("SFM_SCORE_KERNEL", None)
+        if saved_matrix is None:
+            os.environ.pop("SFM_SCORE_MATRIX", None)
+        else:
+            os.environ["SFM_SCORE_MATRIX"] = saved_matrix
 
     variant = os.environ.get("SFM_SCORE_KERNEL", "filtered")
     if args.graph:

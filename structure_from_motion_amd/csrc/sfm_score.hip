@@ -1204,11 +1204,12 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
     // tier 1 on the matrix pipe (sfm_score_matrix.h): SFM_SCORE_MATRIX=1 / 0 forces it on (where it applies) / off
     const char* matrix_choice = getenv("SFM_SCORE_MATRIX");   // (read per call: the tests switch it)
     const int matrix_env = matrix_choice ? atoi(matrix_choice) : -1;
-    // By itself from 65 536 hypotheses on (waves of 32 hypotheses: fewer leave the chip short of waves; 50 000 x 100 000: 1.96 vs
-    // 2.44 ms, x 125 000: 2.18 vs 3.07, 30 000 x 200 000: 2.10 vs 2.95; x 50 000 a tie, below that the VALU kernel wins:
-    // profiles/r03/README.md)
+    // By itself when the launch is large enough to fill the chip with its waves of 32 hypotheses over ranges of the points: at
+    // least 8192 points, 4096 hypotheses and 5 x 10^8 evaluations (same box: 50 000 x 100 000 1.79 vs 2.48 ms, x 125 000 2.30 vs
+    // 3.11, x 20 000 0.44 vs 0.62, x 10 000 0.37 vs 0.41; 20 000 x 40 000 0.36 vs 0.46; but 16 000 x 16 000 0.25 vs 0.16,
+    // 8192 x 25 000 0.23 vs 0.14: every wave pays ~500 instructions of operand preparation; profiles/r03/README.md)
     const bool matrix = batch == 1 && n <= matrixscore::kMaxPoints &&
-                        (matrix_env > 0 || (matrix_env < 0 && h_count >= 65536 && n >= 4096));
+                        (matrix_env > 0 || (matrix_env < 0 && n >= 8192 && h_count >= 4096 && (double)n * (double)h_count >= 5e8));
     // Small point sets are prepared by one block per pair, which stores the maxima itself; the zeroing kernel is then
     // only needed for the class counters of the ordering pre-pass (a small pass is a chain of ~4 us launches).
     const unsigned prepare_blocks = n <= 8192 ? 1u : grid_stride(n, 256, 64);
@@ -1245,13 +1246,16 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
         }
     }
     if (matrix) {
-        // waves of 32 hypotheses: ranges of the points so that the launch has about four generations (3072 resident waves)
+        // Waves of 32 hypotheses are few (3125 at 100 000 hypotheses, against 12 288 resident ones) and long: the points are cut
+        // into ranges so that the launch has about eight generations of waves — 50 000 x 100 000: 1.79 ms with 8 ranges, 1.96 with
+        // 4, 3.4 with 2; x 20 000: 0.43 ms with 16 ranges, 0.69 with 8, 1.24 with 4 (profiles/r03/README.md).  A range keeps at
+        // least 64 steps (2048 points): each range of a hypothesis pays its own epilogue.
         const int64_t waves32 = (h_count + matrixscore::kHyps - 1) / matrixscore::kHyps;
-        int want = split_env > 0 ? split_env : (int)std::min<int64_t>(kSplitMaxUnits, std::max<int64_t>(1, (4 * 3072 + waves32 - 1) / waves32));
+        int want = split_env > 0 ? split_env : (int)std::min<int64_t>(kSplitMaxUnits, std::max<int64_t>(1, (8 * 3072 + waves32 - 1) / waves32));
         want = std::max(1, std::min(want, kSplitMaxUnits));
         const int steps = (int)matrixscore::steps_of(n);
         int steps_per_unit = (steps + want - 1) / want;
-        if (split_env <= 0) steps_per_unit = std::max(steps_per_unit, 128);   // ranges under 4096 points are mostly epilogue
+        if (split_env <= 0) steps_per_unit = std::max(steps_per_unit, 64);
         int m_units = (steps + steps_per_unit - 1) / steps_per_unit;
         if (m_units <= 1 || split_env == 0 ||
             !sfmhost::grid_fits((int64_t)grid_for(waves32, 256 / kWave) * (int64_t)m_units, 1, 256)) {

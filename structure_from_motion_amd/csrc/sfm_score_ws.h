@@ -43,10 +43,7 @@ __host__ __device__ inline int64_t ws_order_offset(int64_t n, int64_t batch) {
 // Range split of a single-pair launch (sfm_score.hip): a wave's hypotheses are scored over up to kSplitMaxUnits ranges of
 // the points by different waves.  Behind the scoring order: one arrival counter per hypothesis, then the ranges' partial
 // counts and sums —  [h_pad int32 arrivals][kSplitMaxUnits x h_pad int32][kSplitMaxUnits x h_pad f64][kSplitMaxUnits x h_pad f64]
-#ifndef SFM_SPLIT_MAX_UNITS
-#define SFM_SPLIT_MAX_UNITS 4
-#endif
-constexpr int kSplitMaxUnits = SFM_SPLIT_MAX_UNITS;
+constexpr int kSplitMaxUnits = 16;
 __host__ __device__ inline int64_t split_padded(int64_t h_count) { return (h_count + 3) & ~(int64_t)3; }
 __host__ __device__ inline int64_t ws_split_offset(int64_t n, int64_t h_count) {   // batch == 1
     return ((ws_order_offset(n, 1) + 4 * h_count + 15) / 16) * 16;

@@ -1107,10 +1107,11 @@ def test_matrix_score_ranges_and_order(dev, monkeypatch, split, order):
 
 
 def test_score_kernel_size_rule_picks_the_matrix_kernel(dev, monkeypatch):
-    """Left to itself (no SFM_SCORE_MATRIX) a single-pair launch of 65 536 hypotheses or more runs the matrix-pipe kernel:
-    same counts as the all-fp64 kernel, and as the VALU-filter kernel forced with SFM_SCORE_MATRIX=0."""
+    """Left to itself (no SFM_SCORE_MATRIX) a single-pair launch of at least 8192 points, 4096 hypotheses and 5 x 10^8
+    evaluations runs the matrix-pipe kernel: same counts as the all-fp64 kernel, and as the VALU-filter kernel forced with
+    SFM_SCORE_MATRIX=0."""
     monkeypatch.delenv("SFM_SCORE_MATRIX", raising=False)
-    n, h = 4099, 70_000
+    n, h = 8200, 62_000
     _, _, _, corr = scene(n)
     corr_d = dev.to_device(corr).reshape(1, n, 4)
     S = dev.sample_philox(7, 0, h, n)

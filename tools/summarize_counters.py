@@ -47,14 +47,21 @@ def main():
     trace_ms = None
     if stats:
         shutil.copy(stats[0], os.path.join(out, "kernel_stats.csv"))
-        for row in csv.DictReader(open(stats[0])):
-            if "score_sed_filtered_kernel" in row["Name"] or "score_sed_mfma_kernel" in row["Name"]:
-                trace_ms = float(row["AverageNs"]) * 1e-6
-    kernels = sorted({k for (_, k) in values if "score_sed_filtered_kernel" in k or "score_sed_mfma_kernel" in k})
+
+    def scoring(name):
+        return "score_sed_filtered_kernel" in name or "score_sed_matrix_kernel" in name
+
+    kernels = sorted({k for (_, k) in values if scoring(k)},
+                     key=lambda k: -sum(sum(v) for (p, kk), v in spans.items() if kk == k))   # the one the time went to
     if not kernels:
         print("no scoring-kernel dispatches found under", out)
         return
     kernel = kernels[0]
+    short = "score_sed_matrix_kernel" if "score_sed_matrix_kernel" in kernel else "score_sed_filtered_kernel"
+    if stats:
+        for row in csv.DictReader(open(stats[0])):
+            if short in row["Name"]:
+                trace_ms = float(row["AverageNs"]) * 1e-6
     counters = {c: sum(v) / len(v) for (c, k), v in values.items() if k == kernel}
     sq_span = spans.get(("sq", kernel))
     if sq_span:
@@ -67,6 +74,7 @@ def main():
         git = ""
     rec = {
         "kernel": kernel[:120],
+        "kernel_short": short,
         "matches": matches,
         "hypotheses": hyp,
         "source_sha": build.score_source_sha(),
