@@ -121,10 +121,12 @@ int sfm_hartley_normalize(const double* coords, int64_t n, double* out, void* st
  * cnt[b,h] = #non-sample points with sed <= thr; s1 / s2 = sum of sed / sed^2 over the 8 sample points
  * plus those survivors.  cnt: dev int32 [batch,h_count]; s1, s2: dev [batch,h_count].
  * workspace: dev scratch of at least sfm_score_workspace_bytes(n, h_count, batch) bytes, 16-byte aligned; it
- * enables the two-tier kernel (conservative fp32 pre-filter + exact fp64 evaluation of the survivors, hypotheses
- * processed longest-first; a single-pair launch of 3 to 8 generations of waves is cut into two ranges of the points whose
- * partial results are added in range order: a fixed order; identical counts and inlier decisions).  NULL selects the
- * all-fp64 kernel. */
+ * enables the two-tier kernels (a conservative reject filter + exact fp64 evaluation of the survivors, hypotheses
+ * processed longest-first; identical counts and inlier decisions, sums in a fixed order): the fp32 VALU filter, and for a
+ * single pair of at least 8192 points, 4096 hypotheses and 5e8 evaluations (at most 65 536 points) the kernel with the
+ * filter on the fp16 / bf16 matrix pipe and a lane-per-hypothesis exact tier (SFM_SCORE_MATRIX=1 / 0 forces it on / off).
+ * Large single-pair launches are cut into ranges of the points whose partial results are added in range order.  NULL selects
+ * the all-fp64 kernel. */
 int64_t sfm_score_workspace_bytes(int64_t n, int64_t h_count, int64_t batch);
 int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t* S, int64_t h_count,
                   int64_t batch, double thr, int32_t* cnt, double* s1, double* s2, void* workspace,
