@@ -449,84 +449,75 @@ __global__ __launch_bounds__(256) void score_estimate_kernel(const unsigned char
     for (int k = 0; k < HPW; ++k) {
         const int total = sfm::wave_sum(c[k]);
         const int h = h0 + k;
-        if (h < h_count && lane == 0) estimate[b * (int64_t)h_count + h] = total;
+        if (h < h_count && lane == 0) estimate[b * (int64_t)h_count + h] = total * 16;   // survivors per 1024 points, in sixteenths
     }
 }
 
-// 0 = heaviest ... kClasses-1 = no survivors at all.  Quarter octaves: the matrix-pipe kernel (sfm_score_matrix.h) runs the 32
-// hypotheses of a wave in lock step through its exact tier, so a wave's hypotheses should differ by tens of per cent, not by 2 x.
-SFM_DEVICE int cost_class(int survivors) {
-    if (survivors <= 0) return kClasses - 1;
-    const int lg = 31 - __builtin_clz((unsigned)survivors);                           // 0..10 (kEstimatePoints = 1024)
-    const int quarter = lg >= 2 ? (int)(((unsigned)survivors >> (lg - 2)) & 3u) : 0;   // the two bits below the leading one
-    return max(0, 4 * (10 - lg) + (3 - quarter));
+// Cost class of a hypothesis from its estimate = filter survivors per 1024 points in units of 1/16 (0 .. 16384): sixteen classes
+// per power of two, heaviest first, kClasses - 1 = no survivors at all.  The matrix-pipe kernel (sfm_score_matrix.h) runs the 32
+// hypotheses of a wave in lock step through its exact tier, so a wave's hypotheses should differ by per cents, not by 2 x
+// (lane utilisation 0.66 with octave classes, 0.77 with quarter octaves, 0.8x with these and its 4096-point estimate).
+SFM_DEVICE int cost_class(int estimate) {
+    if (estimate <= 0) return kClasses - 1;
+    const unsigned e = (unsigned)min(estimate, 16384);
+    const int lg = 31 - __builtin_clz(e);                                               // 0..14
+    const int sixteenth = lg >= 4 ? (int)((e >> (lg - 4)) & 15u) : (int)((e << (4 - lg)) & 15u);   // the four bits below the leading one
+    return 16 * (14 - lg) + (15 - sixteenth);
 }
-static_assert(kEstimatePoints == 1024 && kClasses == 45, "cost_class covers survivor counts up to 2^10 in 44 classes + one for zero");
+static_assert(kEstimatePoints == 1024 && kClasses == 16 * 15 + 1, "cost_class: estimates up to 2^14 in 240 classes + one for zero");
 
-// Histogram of the cost classes: waves combine through LDS, one global atomic per block and class, and every
-// class counter sits on its own cache line (atomics on one line serialise at ~10 ns each).
+// Histogram of the cost classes: a block counts in LDS (one LDS atomic per thread), then one global atomic per block and
+// non-empty class, every class counter on its own cache line (atomics on one line serialise at ~10 ns each).
 __global__ __launch_bounds__(256) void score_class_count_kernel(const int32_t* __restrict__ estimate, int h_count,
                                                                 int32_t* __restrict__ buckets) {
-    __shared__ int block_count[kClasses];
+    static_assert(kClasses <= 256, "one thread per class");
+    __shared__ int block_count[256];
     const int64_t b = blockIdx.y;
     const int h = blockIdx.x * blockDim.x + threadIdx.x;
-    const int cls = h < h_count ? cost_class(estimate[b * (int64_t)h_count + h]) : -1;
-    const int lane = threadIdx.x & (kWave - 1);
-    if (threadIdx.x < kClasses) block_count[threadIdx.x] = 0;
+    block_count[threadIdx.x] = 0;
     __syncthreads();
-#pragma unroll
-    for (int c = 0; c < kClasses; ++c) {
-        const unsigned long long mask = __ballot(cls == c);
-        if (lane == 0 && mask != 0ull) atomicAdd(&block_count[c], (int)__popcll(mask));
-    }
+    if (h < h_count) atomicAdd(&block_count[cost_class(estimate[b * (int64_t)h_count + h])], 1);
     __syncthreads();
     if (threadIdx.x < kClasses && block_count[threadIdx.x] != 0)
         atomicAdd(buckets + b * kBuckets + threadIdx.x * kClassStride, block_count[threadIdx.x]);
 }
 
-// counts -> start offsets (heaviest class first); one thread per batch entry
-__global__ void score_class_scan_kernel(int32_t* __restrict__ buckets, int64_t batch) {
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= batch) return;
-    int run = 0;
-    for (int c = 0; c < kClasses; ++c) {
-        const int v = buckets[b * kBuckets + c * kClassStride];
-        buckets[b * kBuckets + c * kClassStride] = run;
-        run += v;
+// counts -> start offsets (heaviest class first); one block per batch entry, inclusive scan of the 256 class slots in LDS
+__global__ __launch_bounds__(256) void score_class_scan_kernel(int32_t* __restrict__ buckets, int64_t batch) {
+    __shared__ int scan[256];
+    const int64_t b = blockIdx.x;
+    const int c = threadIdx.x;
+    const int own = c < kClasses ? buckets[b * kBuckets + c * kClassStride] : 0;
+    scan[c] = own;
+    __syncthreads();
+#pragma unroll
+    for (int off = 1; off < 256; off <<= 1) {
+        const int below = c >= off ? scan[c - off] : 0;
+        __syncthreads();
+        scan[c] += below;
+        __syncthreads();
     }
+    if (c < kClasses) buckets[b * kBuckets + c * kClassStride] = scan[c] - own;   // exclusive
 }
 
-// order[...] = hypothesis indices grouped by class, heaviest first (arbitrary order inside a class)
+// order[...] = hypothesis indices grouped by class, heaviest first (arbitrary order inside a class: the rank inside the
+// block is the return value of the LDS atomic)
 __global__ __launch_bounds__(256) void score_class_scatter_kernel(const int32_t* __restrict__ estimate, int h_count,
                                                                   int32_t* __restrict__ buckets,
                                                                   int32_t* __restrict__ order) {
-    __shared__ int wave_count[256 / kWave][kClasses];
-    __shared__ int wave_base[256 / kWave][kClasses];
+    __shared__ int block_count[256];
+    __shared__ int block_base[256];
     const int64_t b = blockIdx.y;
     const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    block_count[threadIdx.x] = 0;
+    __syncthreads();
     const int cls = h < h_count ? cost_class(estimate[b * (int64_t)h_count + h]) : -1;
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    int before_me = 0;
-#pragma unroll
-    for (int c = 0; c < kClasses; ++c) {
-        const unsigned long long mask = __ballot(cls == c);
-        if (lane == 0) wave_count[wave][c] = (int)__popcll(mask);
-        if (cls == c)
-            before_me = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-    }
+    const int rank = cls >= 0 ? atomicAdd(&block_count[cls], 1) : 0;
     __syncthreads();
-    if (threadIdx.x < kClasses) {
-        const int c = threadIdx.x;
-        int total = 0;
-        for (int w = 0; w < 256 / kWave; ++w) total += wave_count[w][c];
-        int base = total ? atomicAdd(buckets + b * kBuckets + c * kClassStride, total) : 0;
-        for (int w = 0; w < 256 / kWave; ++w) {
-            wave_base[w][c] = base;
-            base += wave_count[w][c];
-        }
-    }
+    if (threadIdx.x < kClasses && block_count[threadIdx.x] != 0)
+        block_base[threadIdx.x] = atomicAdd(buckets + b * kBuckets + threadIdx.x * kClassStride, block_count[threadIdx.x]);
     __syncthreads();
-    if (cls >= 0) order[b * (int64_t)h_count + wave_base[wave][cls] + before_me] = h;
+    if (cls >= 0) order[b * (int64_t)h_count + block_base[cls] + rank] = h;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1008,7 +999,7 @@ int launch_filtered(const FilteredLaunch& a) {
         SFM_REQUIRE_GRID("sfm_score_sed (ordering pre-pass)", a.h_count, 256, 256, a.batch);
         const dim3 per_hyp(grid_for(a.h_count, 256), (unsigned)a.batch);
         hipLaunchKernelGGL(score_class_count_kernel, per_hyp, dim3(256), 0, a.st, a.cnt, a.h_count, a.buckets);
-        hipLaunchKernelGGL(score_class_scan_kernel, dim3(grid_for(a.batch, 64)), dim3(64), 0, a.st, a.buckets, a.batch);
+        hipLaunchKernelGGL(score_class_scan_kernel, dim3((unsigned)a.batch), dim3(256), 0, a.st, a.buckets, a.batch);
         hipLaunchKernelGGL(score_class_scatter_kernel, per_hyp, dim3(256), 0, a.st, a.cnt, a.h_count, a.buckets, a.order);
         const int rc = check_launch("score order kernels");
         if (rc != SFM_OK) return rc;
@@ -1039,35 +1030,29 @@ int launch_filtered(const FilteredLaunch& a) {
     return check_launch("score_sed_filtered_kernel");
 }
 
-// The ordering pre-pass (cost estimate per hypothesis with the VALU filter, counting sort by class): `cnt` doubles as the
-// estimate buffer, it is rewritten by the scoring kernel afterwards.
-int launch_order(const FilteredLaunch& a) {
-    constexpr int HPW = 4;
-    const int64_t waves = (a.h_count + HPW - 1) / HPW;
-    const dim3 grid(grid_for(waves, 256 / kWave), (unsigned)a.batch);
-    hipLaunchKernelGGL((score_estimate_kernel<HPW, true>), grid, dim3(256), 0, a.st, a.ws, a.n, a.E, a.h_count, a.thr, a.a_scale,
-                       a.cnt);
-    const dim3 per_hyp(grid_for(a.h_count, 256), (unsigned)a.batch);
-    hipLaunchKernelGGL(score_class_count_kernel, per_hyp, dim3(256), 0, a.st, a.cnt, a.h_count, a.buckets);
-    hipLaunchKernelGGL(score_class_scan_kernel, dim3(grid_for(a.batch, 64)), dim3(64), 0, a.st, a.buckets, a.batch);
-    hipLaunchKernelGGL(score_class_scatter_kernel, per_hyp, dim3(256), 0, a.st, a.cnt, a.h_count, a.buckets, a.order);
-    return check_launch("score order kernels");
-}
-
 // Scoring launch with tier 1 on the matrix pipe (sfm_score_matrix.h): one pair, workspace prepared with that kernel's scale.
 int launch_matrix(const FilteredLaunch& a) {
     using namespace matrixscore;
     const uint4* table = reinterpret_cast<const uint4*>(a.ws + ws_matrix_offset(a.n, a.h_count));
     hipLaunchKernelGGL(matrix_prepare_kernel, dim3((unsigned)steps_of(a.n)), dim3(64), 0, a.st, a.corr, a.n, a.a_scale, a.ws,
                        const_cast<uint4*>(table));
+    const int64_t waves = (a.h_count + kHyps - 1) / kHyps;
+    const unsigned blocks = grid_for(waves, 256 / kWave);
     const int32_t* order_arg = nullptr;
     if (a.use_order) {
-        const int rc = launch_order(a);
+        // cost pre-pass with this kernel's own tier 1 over the first kEstimateSteps steps (survivors per 1024 points into `cnt`,
+        // which the scoring launch rewrites), then the counting sort by class
+        hipLaunchKernelGGL(score_sed_matrix_kernel<true>, dim3(blocks), dim3(256), 0, a.st, a.corr, a.ws, table, a.n, a.E, a.S,
+                           a.h_count, a.thr, a.a_scale, (const int32_t*)nullptr, a.cnt, a.s1, a.s2, 1, kEstimateSteps,
+                           (unsigned char*)nullptr);
+        const dim3 per_hyp(grid_for(a.h_count, 256), (unsigned)a.batch);
+        hipLaunchKernelGGL(score_class_count_kernel, per_hyp, dim3(256), 0, a.st, a.cnt, a.h_count, a.buckets);
+        hipLaunchKernelGGL(score_class_scan_kernel, dim3((unsigned)a.batch), dim3(256), 0, a.st, a.buckets, a.batch);
+        hipLaunchKernelGGL(score_class_scatter_kernel, per_hyp, dim3(256), 0, a.st, a.cnt, a.h_count, a.buckets, a.order);
+        const int rc = check_launch("score order kernels");
         if (rc != SFM_OK) return rc;
         order_arg = a.order;
     }
-    const int64_t waves = (a.h_count + kHyps - 1) / kHyps;
-    const unsigned blocks = grid_for(waves, 256 / kWave);
     unsigned char* split = nullptr;
     if (a.units > 1) {
         split = a.ws + ws_split_offset(a.n, a.h_count);
@@ -1075,7 +1060,7 @@ int launch_matrix(const FilteredLaunch& a) {
                            reinterpret_cast<int32_t*>(split), (int64_t)a.h_count);
     }
     if (g_event_before) (void)hipEventRecord(g_event_before, a.st);
-    hipLaunchKernelGGL(score_sed_matrix_kernel, dim3(blocks * (unsigned)a.units), dim3(256), 0, a.st, a.corr, a.ws, table, a.n, a.E,
+    hipLaunchKernelGGL(score_sed_matrix_kernel<false>, dim3(blocks * (unsigned)a.units), dim3(256), 0, a.st, a.corr, a.ws, table, a.n, a.E,
                        a.S, a.h_count, a.thr, a.a_scale, order_arg, a.cnt, a.s1, a.s2, a.units, a.chunks_per_unit, split);
     if (g_event_after) (void)hipEventRecord(g_event_after, a.st);
     return check_launch("score_sed_matrix_kernel");

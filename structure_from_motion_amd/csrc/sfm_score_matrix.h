@@ -68,6 +68,10 @@ constexpr int kHigh = kCap - 4;  // a step pushes at most one entry per lane: ro
 constexpr int kLow = 8;          // ... and stop when every queue is down to this
 constexpr double kKappa = 1.0 / 32.0;
 constexpr int kPops = SFM_MATRIX_POPS;
+#ifndef SFM_MATRIX_ESTIMATE_STEPS
+#define SFM_MATRIX_ESTIMATE_STEPS 128
+#endif
+constexpr int kEstimateSteps = SFM_MATRIX_ESTIMATE_STEPS;   // steps of 32 points the cost pre-pass scans (4096 points)
 constexpr int kPointTop = 14, kHypTop = 11;   // scaled magnitudes: point terms < 2^14, hypothesis entries < 2^11
 constexpr int64_t kMaxPoints = sfmws::kMatrixMaxPoints;
 static_assert(kMaxPoints / kTile <= 65536, "a queue entry keeps the step in 16 bits");
@@ -183,12 +187,17 @@ __global__ __launch_bounds__(64) void matrix_prepare_kernel(const Corr* __restri
 }
 
 // One wave: 32 hypotheses (entries [32 wave, 32 wave + 32) of the processing order) over the steps of one range of the points.
+// ESTIMATE: the cost pre-pass of this kernel — tier 1 alone over the first `steps_per_unit` steps, cnt[h] = the survivors per 1024
+// points in sixteenths (what the counting sort's classes are defined on).  With 1024 points the estimate is 52 +- 7 for a typical hypothesis
+// and the 32 hypotheses a wave runs in lock step differ by that noise (lane utilisation 0.77); tier 1 on the matrix pipe makes
+// 4096 points as cheap as 1024 were on the VALU.
+template <bool ESTIMATE>
 __global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
     const Corr* __restrict__ pts, const unsigned char* __restrict__ ws, const uint4* __restrict__ table, int n,
     const double* __restrict__ E, const int32_t* __restrict__ S, int h_count, double thr, double a_scale,
     const int32_t* __restrict__ order, int32_t* __restrict__ cnt, double* __restrict__ s1, double* __restrict__ s2, int units,
     int steps_per_unit, unsigned char* __restrict__ split) {
-    __shared__ uint32_t queues[256 / kWave][kCap][kWave];
+    __shared__ uint32_t queues[ESTIMATE ? 1 : 256 / kWave][ESTIMATE ? 1 : kCap][kWave];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     int block_of_range = blockIdx.x, unit = 0;
@@ -268,7 +277,7 @@ __global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
     unsigned head = 0, tail = 0, cur = 0;
     int cur_base = 0;
     double a1 = 0.0, a2 = 0.0;
-    uint32_t* const my_queue = &queues[wave_in_block][0][lane];   // slot k at my_queue[k * kWave]
+    uint32_t* const my_queue = &queues[ESTIMATE ? 0 : wave_in_block][0][lane];   // slot k at my_queue[k * kWave]
 #if SFM_MATRIX_STATS
     unsigned stat_rounds = 0, stat_pops = 0, stat_push_iterations = 0;
 #endif
@@ -311,7 +320,9 @@ __global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
 
     const int steps_total = (int)steps_of(n);
     const int step_begin = units > 1 ? unit * steps_per_unit : 0;
-    const int step_end = units > 1 ? min(step_begin + steps_per_unit, steps_total) : steps_total;
+    const int step_end = ESTIMATE ? min(steps_per_unit, steps_total)
+                                  : (units > 1 ? min(step_begin + steps_per_unit, steps_total) : steps_total);
+    unsigned survivors = 0;   // ESTIMATE
     if (step_begin < step_end) {
         const uint4* __restrict__ src = table + lane;
         uint4 A[kBlocks];
@@ -341,17 +352,28 @@ __global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
                     in_range |= (t * kTile + (j & 3) + 8 * (j >> 2) + 4 * half < n) ? (1u << (15 - j)) : 0u;
                 keep &= in_range;
             }
-            if (keep != 0u) {   // push: one entry with this step's survivors
-                my_queue[(tail & (kCap - 1)) * kWave] = ((unsigned)t << 16) | keep;
-                ++tail;
-            }
-            if (__builtin_amdgcn_ballot_w64((int)(tail - head) >= kHigh) != 0ull) {
-                __builtin_amdgcn_wave_barrier();
-                do round(); while (__builtin_amdgcn_ballot_w64((int)(tail - head) > kLow) != 0ull);
+            if (ESTIMATE) {
+                survivors += (unsigned)__builtin_popcount(keep);
+            } else {
+                if (keep != 0u) {   // push: one entry with this step's survivors
+                    my_queue[(tail & (kCap - 1)) * kWave] = ((unsigned)t << 16) | keep;
+                    ++tail;
+                }
+                if (__builtin_amdgcn_ballot_w64((int)(tail - head) >= kHigh) != 0ull) {
+                    __builtin_amdgcn_wave_barrier();
+                    do round(); while (__builtin_amdgcn_ballot_w64((int)(tail - head) > kLow) != 0ull);
+                }
             }
 #pragma unroll
             for (int b = 0; b < kBlocks; ++b) A[b] = An[b];
         }
+    }
+    if (ESTIMATE) {   // survivors per 1024 points of this hypothesis (both lanes) in sixteenths, at least 1 when there was any
+        const unsigned both = survivors + (unsigned)__shfl_xor((int)survivors, 32, 64);
+        const unsigned scanned = (unsigned)min(step_end * kTile, n);
+        const unsigned sixteenths = (unsigned)(((unsigned long long)both * 16384ull) / (scanned > 0u ? scanned : 1u));
+        if (half == 0 && valid) cnt[h] = (int32_t)(both > 0u && sixteenths == 0u ? 1u : sixteenths);
+        return;
     }
     __builtin_amdgcn_wave_barrier();
     while (__builtin_amdgcn_ballot_w64(tail != head || cur != 0u) != 0ull) round();

@@ -17,9 +17,9 @@
 namespace sfmws {
 
 constexpr int kEstimatePoints = 1024;        // points scanned by the cost pre-pass
-constexpr int kClasses = 45;                 // cost classes: quarter octaves of the survivor count (4 per power of two, heaviest first), 0 survivors last
+constexpr int kClasses = 16 * 15 + 1;        // cost classes: sixteen per power of two of the estimate (heaviest first), 0 survivors last
 constexpr int kClassStride = 16;             // ints between class counters: one 64-byte line each
-constexpr int kBuckets = 48 * kClassStride;  // ints reserved per batch entry
+constexpr int kBuckets = 256 * kClassStride; // ints reserved per batch entry (16 KiB)
 constexpr int64_t kPointsPad = 4096;         // bytes after the fp32 points: the scoring loop prefetches up to 3 KiB past a pair's last point
 
 // fused small pass (n <= kSmallMaxPoints): the fit launch prepares the points in blocks of kPrepPoints
