@@ -1036,13 +1036,17 @@ int launch_matrix(const FilteredLaunch& a) {
     const uint4* table = reinterpret_cast<const uint4*>(a.ws + ws_matrix_offset(a.n, a.h_count));
     hipLaunchKernelGGL(matrix_prepare_kernel, dim3((unsigned)steps_of(a.n)), dim3(64), 0, a.st, a.corr, a.n, a.a_scale, a.ws,
                        const_cast<uint4*>(table));
+    static_assert(kBlocks * 2 * 16 == 96, "matrix_hyp_table_bytes");
+    const uint4* hyp_table = reinterpret_cast<const uint4*>(a.ws + ws_matrix_hyp_offset(a.n, a.h_count));
+    hipLaunchKernelGGL(matrix_hypothesis_kernel, dim3(grid_for(2 * (int64_t)a.h_count, 256)), dim3(256), 0, a.st, a.ws, a.E,
+                       a.h_count, a.a_scale, const_cast<uint4*>(hyp_table));
     const int64_t waves = (a.h_count + kHyps - 1) / kHyps;
     const unsigned blocks = grid_for(waves, 256 / kWave);
     const int32_t* order_arg = nullptr;
     if (a.use_order) {
         // cost pre-pass with this kernel's own tier 1 over the first kEstimateSteps steps (survivors per 1024 points into `cnt`,
         // which the scoring launch rewrites), then the counting sort by class
-        hipLaunchKernelGGL(score_sed_matrix_kernel<true>, dim3(blocks), dim3(256), 0, a.st, a.corr, a.ws, table, a.n, a.E, a.S,
+        hipLaunchKernelGGL(score_sed_matrix_kernel<true>, dim3(blocks), dim3(256), 0, a.st, a.corr, hyp_table, table, a.n, a.E, a.S,
                            a.h_count, a.thr, a.a_scale, (const int32_t*)nullptr, a.cnt, a.s1, a.s2, 1, kEstimateSteps,
                            (unsigned char*)nullptr);
         const dim3 per_hyp(grid_for(a.h_count, 256), (unsigned)a.batch);
@@ -1060,7 +1064,7 @@ int launch_matrix(const FilteredLaunch& a) {
                            reinterpret_cast<int32_t*>(split), (int64_t)a.h_count);
     }
     if (g_event_before) (void)hipEventRecord(g_event_before, a.st);
-    hipLaunchKernelGGL(score_sed_matrix_kernel<false>, dim3(blocks * (unsigned)a.units), dim3(256), 0, a.st, a.corr, a.ws, table, a.n, a.E,
+    hipLaunchKernelGGL(score_sed_matrix_kernel<false>, dim3(blocks * (unsigned)a.units), dim3(256), 0, a.st, a.corr, hyp_table, table, a.n, a.E,
                        a.S, a.h_count, a.thr, a.a_scale, order_arg, a.cnt, a.s1, a.s2, a.units, a.chunks_per_unit, split);
     if (g_event_after) (void)hipEventRecord(g_event_after, a.st);
     return check_launch("score_sed_matrix_kernel");

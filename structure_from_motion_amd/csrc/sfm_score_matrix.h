@@ -78,6 +78,7 @@ static_assert(kMaxPoints / kTile <= 65536, "a queue entry keeps the step in 16 b
 
 __host__ __device__ inline int64_t steps_of(int64_t n) { return (n + kTile - 1) / kTile; }
 __host__ __device__ inline int64_t table_bytes(int64_t n) { return steps_of(n) * kBlocks * 64 * 16; }
+__host__ __device__ inline int64_t hyp_table_bytes(int64_t h_count) { return h_count * 2 * kBlocks * 16; }
 
 // factor carried by the prepared a-side coordinates for this kernel (host side)
 inline double scale_for(double thr) {
@@ -186,34 +187,15 @@ __global__ __launch_bounds__(64) void matrix_prepare_kernel(const Corr* __restri
     table[((size_t)t * kBlocks + 2) * 64 + l] = __builtin_bit_cast(uint4, v);
 }
 
-// One wave: 32 hypotheses (entries [32 wave, 32 wave + 32) of the processing order) over the steps of one range of the points.
-// ESTIMATE: the cost pre-pass of this kernel — tier 1 alone over the first `steps_per_unit` steps, cnt[h] = the survivors per 1024
-// points in sixteenths (what the counting sort's classes are defined on).  With 1024 points the estimate is 52 +- 7 for a typical hypothesis
-// and the 32 hypotheses a wave runs in lock step differ by that noise (lane utilisation 0.77); tier 1 on the matrix pipe makes
-// 4096 points as cheap as 1024 were on the VALU.
-template <bool ESTIMATE>
-__global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
-    const Corr* __restrict__ pts, const unsigned char* __restrict__ ws, const uint4* __restrict__ table, int n,
-    const double* __restrict__ E, const int32_t* __restrict__ S, int h_count, double thr, double a_scale,
-    const int32_t* __restrict__ order, int32_t* __restrict__ cnt, double* __restrict__ s1, double* __restrict__ s2, int units,
-    int steps_per_unit, unsigned char* __restrict__ split) {
-    __shared__ uint32_t queues[ESTIMATE ? 1 : 256 / kWave][ESTIMATE ? 1 : kCap][kWave];
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
-    int block_of_range = blockIdx.x, unit = 0;
-    if (units > 1) {   // `units` consecutive blocks take the same hypotheses over one range of the points each
-        unit = block_of_range % units;
-        block_of_range /= units;
-    }
-    const int wave = block_of_range * (256 / kWave) + wave_in_block;
-    const int h0 = wave * kHyps;
-    if (h0 >= h_count) return;   // (no block-level synchronisation in this kernel)
-    const int col = lane & 31, half = lane >> 5;
-    const bool valid = h0 + col < h_count;
-    const int slot = min(h0 + col, h_count - 1);
-    const int h = order != nullptr ? order[slot] : slot;
-
-    // ---- this lane's hypothesis: exact entries for tier 2, scaled split entries and the dB form for tier 1
+// Operand table of the hypotheses: for hypothesis h and half (0: slots 0..7, 1: slots 8..15 of each block) the three B
+// fragments of tier 1 — the scaled fp16 hi / mid split of E for the two r' blocks and the bf16 dB form with its absolute terms
+// and the slack.  One thread per (hypothesis, half).
+__global__ __launch_bounds__(256) void matrix_hypothesis_kernel(const unsigned char* __restrict__ ws, const double* __restrict__ E,
+                                                                int h_count, double a_scale, uint4* __restrict__ hyp_table) {
+    const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= 2 * (int64_t)h_count) return;
+    const int64_t h = item >> 1;
+    const int half = (int)(item & 1);
     double e[9];
 #pragma unroll
     for (int j = 0; j < 9; ++j) e[j] = E[(int64_t)h * 9 + j];
@@ -266,6 +248,49 @@ __global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
             B2[j] = (__bf16)x;
         }
     }
+
+    uint4* out = hyp_table + item * kBlocks;
+    out[0] = __builtin_bit_cast(uint4, B0);
+    out[1] = __builtin_bit_cast(uint4, B1);
+    out[2] = __builtin_bit_cast(uint4, B2);
+}
+
+// One wave: 32 hypotheses (entries [32 wave, 32 wave + 32) of the processing order) over the steps of one range of the points.
+// ESTIMATE: the cost pre-pass of this kernel — tier 1 alone over the first `steps_per_unit` steps, cnt[h] = the survivors per 1024
+// points in sixteenths (what the counting sort's classes are defined on).  With 1024 points the estimate is 52 +- 7 for a typical hypothesis
+// and the 32 hypotheses a wave runs in lock step differ by that noise (lane utilisation 0.77); tier 1 on the matrix pipe makes
+// 4096 points as cheap as 1024 were on the VALU.
+template <bool ESTIMATE>
+__global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
+    const Corr* __restrict__ pts, const uint4* __restrict__ hyp_table, const uint4* __restrict__ table, int n,
+    const double* __restrict__ E, const int32_t* __restrict__ S, int h_count, double thr, double a_scale,
+    const int32_t* __restrict__ order, int32_t* __restrict__ cnt, double* __restrict__ s1, double* __restrict__ s2, int units,
+    int steps_per_unit, unsigned char* __restrict__ split) {
+    __shared__ uint32_t queues[ESTIMATE ? 1 : 256 / kWave][ESTIMATE ? 1 : kCap][kWave];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    int block_of_range = blockIdx.x, unit = 0;
+    if (units > 1) {   // `units` consecutive blocks take the same hypotheses over one range of the points each
+        unit = block_of_range % units;
+        block_of_range /= units;
+    }
+    const int wave = block_of_range * (256 / kWave) + wave_in_block;
+    const int h0 = wave * kHyps;
+    if (h0 >= h_count) return;   // (no block-level synchronisation in this kernel)
+    const int col = lane & 31, half = lane >> 5;
+    const bool valid = h0 + col < h_count;
+    const int slot = min(h0 + col, h_count - 1);
+    const int h = order != nullptr ? order[slot] : slot;
+
+    // ---- this lane's hypothesis: exact entries for the exact tier; the B operands of tier 1 come from the table
+    // matrix_hypothesis_kernel wrote once per launch (a hypothesis is scored by up to 16 range waves and the cost pre-pass)
+    double e[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) e[j] = E[(int64_t)h * 9 + j];
+    const uint4* __restrict__ operands = hyp_table + ((int64_t)h * 2 + half) * kBlocks;
+    const f16x8 B0 = __builtin_bit_cast(f16x8, operands[0]);
+    const f16x8 B1 = __builtin_bit_cast(f16x8, operands[1]);
+    const bf16x8 B2 = __builtin_bit_cast(bf16x8, operands[2]);
 
     // The lane's queue is a ring of entries (step << 16 | the step's 16 survivor bits), pushed at `tail`, popped at `head`; the
     // entry being consumed lives in registers (`cur` = its remaining bits, `cur_base` = index of its row 0).  Points of a

@@ -3,7 +3,7 @@
 // fused pass in spare blocks of its own launch.
 //
 //   [batch x 4 uint32 maxima][batch x n float4 points][kPointsPad bytes][batch x kBuckets int32][batch x h_count int32]
-//   and for one pair: [range-split region][operand table of the matrix-pipe kernel]   (below)
+//   and for one pair: [range-split region][operand tables of the matrix-pipe kernel: points, hypotheses]   (below)
 //
 // maxima: data-set maxima of |xa'|, |ya'|, |xb|, |yb| of the fp32 points as bit patterns (non-negative floats order
 // like unsigned ints).  buckets: per pair 256 ints — class counters of the longest-first ordering in large launches;
@@ -60,8 +60,15 @@ __host__ __device__ inline int64_t matrix_table_bytes(int64_t n) {
 __host__ __device__ inline int64_t ws_matrix_offset(int64_t n, int64_t h_count) {   // batch == 1
     return ((ws_split_offset(n, h_count) + split_bytes(h_count) + 255) / 256) * 256;
 }
+// ... and behind it that kernel's operand table of the hypotheses: 2 halves x 3 blocks x 16 bytes each
+__host__ __device__ inline int64_t ws_matrix_hyp_offset(int64_t n, int64_t h_count) {   // batch == 1
+    return ((ws_matrix_offset(n, h_count) + matrix_table_bytes(n) + 255) / 256) * 256;
+}
+__host__ __device__ inline int64_t matrix_hyp_table_bytes(int64_t n, int64_t h_count) {
+    return n <= kMatrixMaxPoints ? h_count * 96 : 0;
+}
 __host__ __device__ inline int64_t workspace_bytes_for(int64_t n, int64_t h_count, int64_t batch) {
-    if (batch == 1) return ws_matrix_offset(n, h_count) + matrix_table_bytes(n);
+    if (batch == 1) return ws_matrix_hyp_offset(n, h_count) + matrix_hyp_table_bytes(n, h_count);
     return ws_order_offset(n, batch) + 4 * h_count * batch;
 }
 

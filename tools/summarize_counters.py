@@ -49,7 +49,8 @@ def main():
         shutil.copy(stats[0], os.path.join(out, "kernel_stats.csv"))
 
     def scoring(name):
-        return "score_sed_filtered_kernel" in name or "score_sed_matrix_kernel" in name
+        # (score_sed_matrix_kernel<true> is that kernel's cost pre-pass, not the scoring launch)
+        return "score_sed_filtered_kernel" in name or ("score_sed_matrix_kernel" in name and "<true>" not in name)
 
     kernels = sorted({k for (_, k) in values if scoring(k)},
                      key=lambda k: -sum(sum(v) for (p, kk), v in spans.items() if kk == k))   # the one the time went to
@@ -60,7 +61,7 @@ def main():
     short = "score_sed_matrix_kernel" if "score_sed_matrix_kernel" in kernel else "score_sed_filtered_kernel"
     if stats:
         for row in csv.DictReader(open(stats[0])):
-            if short in row["Name"]:
+            if scoring(row["Name"]) and short in row["Name"]:
                 trace_ms = float(row["AverageNs"]) * 1e-6
     counters = {c: sum(v) / len(v) for (c, k), v in values.items() if k == kernel}
     sq_span = spans.get(("sq", kernel))
