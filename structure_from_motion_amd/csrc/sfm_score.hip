@@ -169,7 +169,9 @@ __global__ __launch_bounds__(256) void score_reset_kernel(unsigned char* __restr
 }
 
 // arrival counters of a range-split launch (one per hypothesis): re-armed before every scoring launch
-__global__ __launch_bounds__(256) void score_split_reset_kernel(int32_t* __restrict__ arrivals, int64_t h_count) {
+__global__ __launch_bounds__(256) void score_split_reset_kernel(int32_t* __restrict__ arrivals, int64_t h_count,
+                                                                int64_t ints_per_pair = 0) {
+    arrivals += (int64_t)blockIdx.y * ints_per_pair;   // a batch keeps one region per pair
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < h_count; i += (int64_t)gridDim.x * blockDim.x)
         arrivals[i] = 0;
 }
@@ -1033,25 +1035,30 @@ int launch_filtered(const FilteredLaunch& a) {
 // Scoring launch with tier 1 on the matrix pipe (sfm_score_matrix.h): one pair, workspace prepared with that kernel's scale.
 int launch_matrix(const FilteredLaunch& a) {
     using namespace matrixscore;
-    const uint4* table = reinterpret_cast<const uint4*>(a.ws + ws_matrix_offset(a.n, a.h_count));
-    hipLaunchKernelGGL(matrix_prepare_kernel, dim3((unsigned)steps_of(a.n)), dim3(64), 0, a.st, a.corr, a.n, a.a_scale, a.ws,
+    const unsigned pairs = (unsigned)a.batch;
+    const uint4* table = reinterpret_cast<const uint4*>(a.ws + ws_matrix_offset(a.n, a.h_count, a.batch));
+    hipLaunchKernelGGL(matrix_prepare_kernel, dim3((unsigned)steps_of(a.n), pairs), dim3(64), 0, a.st, a.corr, a.n, a.a_scale, a.ws,
                        const_cast<uint4*>(table));
     static_assert(kBlocks * 2 * 16 == 96, "matrix_hyp_table_bytes");
-    const uint4* hyp_table = reinterpret_cast<const uint4*>(a.ws + ws_matrix_hyp_offset(a.n, a.h_count));
-    hipLaunchKernelGGL(matrix_hypothesis_kernel, dim3(grid_for(2 * (int64_t)a.h_count, 256)), dim3(256), 0, a.st, a.ws, a.E,
+    const uint4* hyp_table = reinterpret_cast<const uint4*>(a.ws + ws_matrix_hyp_offset(a.n, a.h_count, a.batch));
+    hipLaunchKernelGGL(matrix_hypothesis_kernel, dim3(grid_for(2 * (int64_t)a.h_count, 256), pairs), dim3(256), 0, a.st, a.ws, a.E,
                        a.h_count, a.a_scale, const_cast<uint4*>(hyp_table));
     const int64_t waves = (a.h_count + kHyps - 1) / kHyps;
     const unsigned blocks = grid_for(waves, 256 / kWave);
+    // batches: flat grid of 8-pair groups (the kernel's block -> (pair, block) map), `units` range blocks per block of a pair; a
+    // single pair: blocks x ranges
+    const int blocks_per_pair = a.batch > 1 ? (int)blocks : 0;
+    const unsigned flat = a.batch > 1 ? blocks * (unsigned)((a.batch + 7) / 8 * 8) : blocks;
     const int32_t* order_arg = nullptr;
     if (a.use_order) {
-        // cost pre-pass with this kernel's own tier 1 over the first kEstimateSteps steps (survivors per 1024 points into `cnt`,
-        // which the scoring launch rewrites), then the counting sort by class
-        hipLaunchKernelGGL(score_sed_matrix_kernel<true>, dim3(blocks), dim3(256), 0, a.st, a.corr, hyp_table, table, a.n, a.E, a.S,
-                           a.h_count, a.thr, a.a_scale, (const int32_t*)nullptr, a.cnt, a.s1, a.s2, 1, kEstimateSteps,
-                           (unsigned char*)nullptr);
-        const dim3 per_hyp(grid_for(a.h_count, 256), (unsigned)a.batch);
+        // cost pre-pass with this kernel's own tier 1 over the first steps (survivors per 1024 points, in sixteenths, into
+        // `cnt`, which the scoring launch rewrites), then the counting sort by class
+        hipLaunchKernelGGL(score_sed_matrix_kernel<true>, dim3(flat), dim3(256), 0, a.st, a.corr, hyp_table, table, a.n, a.E, a.S,
+                           a.h_count, a.thr, a.a_scale, (const int32_t*)nullptr, a.cnt, a.s1, a.s2, 1, estimate_steps(a.n),
+                           (unsigned char*)nullptr, (int)a.batch, blocks_per_pair);
+        const dim3 per_hyp(grid_for(a.h_count, 256), pairs);
         hipLaunchKernelGGL(score_class_count_kernel, per_hyp, dim3(256), 0, a.st, a.cnt, a.h_count, a.buckets);
-        hipLaunchKernelGGL(score_class_scan_kernel, dim3((unsigned)a.batch), dim3(256), 0, a.st, a.buckets, a.batch);
+        hipLaunchKernelGGL(score_class_scan_kernel, dim3(pairs), dim3(256), 0, a.st, a.buckets, a.batch);
         hipLaunchKernelGGL(score_class_scatter_kernel, per_hyp, dim3(256), 0, a.st, a.cnt, a.h_count, a.buckets, a.order);
         const int rc = check_launch("score order kernels");
         if (rc != SFM_OK) return rc;
@@ -1059,13 +1066,14 @@ int launch_matrix(const FilteredLaunch& a) {
     }
     unsigned char* split = nullptr;
     if (a.units > 1) {
-        split = a.ws + ws_split_offset(a.n, a.h_count);
-        hipLaunchKernelGGL(score_split_reset_kernel, dim3(grid_stride(a.h_count, 256, 1024)), dim3(256), 0, a.st,
-                           reinterpret_cast<int32_t*>(split), (int64_t)a.h_count);
+        split = a.ws + (a.batch > 1 ? ws_batch_split_offset(a.n, a.h_count, a.batch) : ws_split_offset(a.n, a.h_count));
+        hipLaunchKernelGGL(score_split_reset_kernel, dim3(grid_stride(a.h_count, 256, 1024), pairs), dim3(256), 0, a.st,
+                           reinterpret_cast<int32_t*>(split), (int64_t)a.h_count, split_bytes(a.h_count) / 4);
     }
     if (g_event_before) (void)hipEventRecord(g_event_before, a.st);
-    hipLaunchKernelGGL(score_sed_matrix_kernel<false>, dim3(blocks * (unsigned)a.units), dim3(256), 0, a.st, a.corr, hyp_table, table, a.n, a.E,
-                       a.S, a.h_count, a.thr, a.a_scale, order_arg, a.cnt, a.s1, a.s2, a.units, a.chunks_per_unit, split);
+    hipLaunchKernelGGL(score_sed_matrix_kernel<false>, dim3(flat * (unsigned)a.units), dim3(256), 0, a.st, a.corr, hyp_table, table, a.n,
+                       a.E, a.S, a.h_count, a.thr, a.a_scale, order_arg, a.cnt, a.s1, a.s2, a.units, a.chunks_per_unit, split,
+                       (int)a.batch, blocks_per_pair * a.units);
     if (g_event_after) (void)hipEventRecord(g_event_after, a.st);
     return check_launch("score_sed_matrix_kernel");
 }
@@ -1197,8 +1205,16 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
     // least 8192 points, 4096 hypotheses and 5 x 10^8 evaluations (same box: 50 000 x 100 000 1.79 vs 2.48 ms, x 125 000 2.30 vs
     // 3.11, x 20 000 0.44 vs 0.62, x 10 000 0.37 vs 0.41; 20 000 x 40 000 0.36 vs 0.46; but 16 000 x 16 000 0.25 vs 0.16,
     // 8192 x 25 000 0.23 vs 0.14: every wave pays ~500 instructions of operand preparation; profiles/r03/README.md)
-    const bool matrix = batch == 1 && n <= matrixscore::kMaxPoints &&
-                        (matrix_env > 0 || (matrix_env < 0 && n >= 8192 && h_count >= 4096 && (double)n * (double)h_count >= 5e8));
+    // A batch of pairs: larger pairs only — 64 x 20 000 x 4 000: 2.63 vs 3.05 ms for the whole batched pipeline, but C5 = 256 x
+    // 10 000 x 2 000 is a tie at best (3.13-3.23 vs 3.21 ms: per pair an operand table, a cost pre-pass over an eighth of
+    // the points, a counting sort and ranges of 39 steps, each with its own prologue) and stays with the VALU kernel.
+    const int64_t waves32_all = (h_count + matrixscore::kHyps - 1) / matrixscore::kHyps * batch;
+    const bool matrix_fits = n <= matrixscore::kMaxPoints &&
+                             sfmhost::grid_fits((int64_t)grid_for((h_count + 31) / 32, 256 / kWave) * ((batch + 7) / 8 * 8), 1, 256);
+    const bool matrix_pays = batch == 1 ? (n >= 8192 && h_count >= 4096 && (double)n * (double)h_count >= 5e8)
+                                        : (n >= 16384 && h_count >= 2048 && waves32_all >= 6144 &&
+                                           (double)n * (double)h_count * (double)batch >= 5e8);
+    const bool matrix = matrix_fits && (matrix_env > 0 || (matrix_env < 0 && matrix_pays));
     // Small point sets are prepared by one block per pair, which stores the maxima itself; the zeroing kernel is then
     // only needed for the class counters of the ordering pre-pass (a small pass is a chain of ~4 us launches).
     const unsigned prepare_blocks = n <= 8192 ? 1u : grid_stride(n, 256, 64);
@@ -1240,18 +1256,20 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
         // 4, 3.4 with 2; x 20 000: 0.43 ms with 16 ranges, 0.69 with 8, 1.24 with 4 (profiles/r03/README.md).  A range keeps at
         // least 64 steps (2048 points): each range of a hypothesis pays its own epilogue.
         const int64_t waves32 = (h_count + matrixscore::kHyps - 1) / matrixscore::kHyps;
-        int want = split_env > 0 ? split_env : (int)std::min<int64_t>(kSplitMaxUnits, std::max<int64_t>(1, (8 * 3072 + waves32 - 1) / waves32));
+        // a batch: ranges until a pair's waves fill one XCD (512 resident waves) — see the kernel's block map
+        const int64_t by_size = batch > 1 ? (512 + waves32 - 1) / waves32 : (8 * 3072 + waves32 - 1) / waves32;
+        int want = split_env > 0 ? split_env : (int)std::min<int64_t>(kSplitMaxUnits, std::max<int64_t>(1, by_size));
         want = std::max(1, std::min(want, kSplitMaxUnits));
         const int steps = (int)matrixscore::steps_of(n);
         int steps_per_unit = (steps + want - 1) / want;
-        if (split_env <= 0) steps_per_unit = std::max(steps_per_unit, 64);
+        if (split_env <= 0) steps_per_unit = std::max(steps_per_unit, batch > 1 ? 32 : 64);
         int m_units = (steps + steps_per_unit - 1) / steps_per_unit;
         if (m_units <= 1 || split_env == 0 ||
-            !sfmhost::grid_fits((int64_t)grid_for(waves32, 256 / kWave) * (int64_t)m_units, 1, 256)) {
+            !sfmhost::grid_fits((int64_t)grid_for(waves32, 256 / kWave) * (int64_t)m_units * ((batch + 7) / 8 * 8), 1, 256)) {
             m_units = 1;
             steps_per_unit = steps;
         }
-        const FilteredLaunch margs{(const Corr*)corr, ws, (int)n, E, S, (int)h_count, thr, order_env != 0 && h_count >= 2048, cnt, s1, s2,
+        const FilteredLaunch margs{(const Corr*)corr, ws, (int)n, E, S, (int)h_count, thr, order_env != 0 && h_count > (batch > 1 ? 64 : 2047), cnt, s1, s2,
                                    buckets, order, batch, st, true, a_scale, m_units, steps_per_unit};
         return launch_matrix(margs);
     }

@@ -71,13 +71,19 @@ constexpr int kPops = SFM_MATRIX_POPS;
 #ifndef SFM_MATRIX_ESTIMATE_STEPS
 #define SFM_MATRIX_ESTIMATE_STEPS 128
 #endif
-constexpr int kEstimateSteps = SFM_MATRIX_ESTIMATE_STEPS;   // steps of 32 points the cost pre-pass scans (4096 points)
+constexpr int kEstimateSteps = SFM_MATRIX_ESTIMATE_STEPS;   // steps of 32 points the cost pre-pass scans at most (4096 points)
 constexpr int kPointTop = 14, kHypTop = 11;   // scaled magnitudes: point terms < 2^14, hypothesis entries < 2^11
 constexpr int64_t kMaxPoints = sfmws::kMatrixMaxPoints;
 static_assert(kMaxPoints / kTile <= 65536, "a queue entry keeps the step in 16 bits");
 
 __host__ __device__ inline int64_t steps_of(int64_t n) { return (n + kTile - 1) / kTile; }
 __host__ __device__ inline int64_t table_bytes(int64_t n) { return steps_of(n) * kBlocks * 64 * 16; }
+// ... and an eighth of a smaller point set, but no fewer than 1024 points: the pre-pass is tier 1 over that share of the points
+__host__ __device__ inline int estimate_steps(int64_t n) {
+    const int64_t eighth = steps_of(n) / 8;
+    return (int)(eighth < 32 ? 32 : eighth > kEstimateSteps ? kEstimateSteps : eighth);
+}
+
 __host__ __device__ inline int64_t hyp_table_bytes(int64_t h_count) { return h_count * 2 * kBlocks * 16; }
 
 // factor carried by the prepared a-side coordinates for this kernel (host side)
@@ -145,6 +151,10 @@ SFM_DEVICE float hyp_slot_r(const float (&eh)[9], const float (&em)[9], int s) {
 // coordinates scaled by c) that score_prepare_kernel left.  Rows past n are zero (they are masked out of the last step).
 __global__ __launch_bounds__(64) void matrix_prepare_kernel(const Corr* __restrict__ corr, int n, double c,
                                                            const unsigned char* __restrict__ ws, uint4* __restrict__ table) {
+    const int64_t pair = blockIdx.y;
+    corr += pair * (int64_t)n;
+    ws += 16 * pair;                                   // this pair's maxima
+    table += pair * steps_of(n) * kBlocks * 64;
     const int t = blockIdx.x;
     const int l = threadIdx.x;
     const int i = t * kTile + (l & 31);
@@ -194,6 +204,10 @@ __global__ __launch_bounds__(256) void matrix_hypothesis_kernel(const unsigned c
                                                                 int h_count, double a_scale, uint4* __restrict__ hyp_table) {
     const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (item >= 2 * (int64_t)h_count) return;
+    const int64_t pair = blockIdx.y;
+    ws += 16 * pair;                                   // this pair's maxima
+    E += pair * (int64_t)h_count * 9;
+    hyp_table += pair * (int64_t)h_count * 2 * kBlocks;
     const int64_t h = item >> 1;
     const int half = (int)(item & 1);
     double e[9];
@@ -265,12 +279,36 @@ __global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
     const Corr* __restrict__ pts, const uint4* __restrict__ hyp_table, const uint4* __restrict__ table, int n,
     const double* __restrict__ E, const int32_t* __restrict__ S, int h_count, double thr, double a_scale,
     const int32_t* __restrict__ order, int32_t* __restrict__ cnt, double* __restrict__ s1, double* __restrict__ s2, int units,
-    int steps_per_unit, unsigned char* __restrict__ split) {
+    int steps_per_unit, unsigned char* __restrict__ split, int batch, int blocks_per_pair) {
     __shared__ uint32_t queues[ESTIMATE ? 1 : 256 / kWave][ESTIMATE ? 1 : kCap][kWave];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     int block_of_range = blockIdx.x, unit = 0;
-    if (units > 1) {   // `units` consecutive blocks take the same hypotheses over one range of the points each
+    if (batch > 1) {
+        // XCD-aware block -> (pair, block of the pair) map, as in score_sed_filtered_kernel: workgroups are dealt round-robin
+        // over the 8 XCDs by linear id, so all blocks of a pair get ids of one residue class mod 8 and the pair's operand
+        // table (96 bytes per point) and fp64 points stay in ONE L2 — and the pair's points are cut into ranges until its waves
+        // fill an XCD by themselves: with eight small pairs resident per XCD their tables (1.3 MB each at 10 000 points) thrash
+        // the 4 MB L2 (C5 without ranges: 4.6 ms against 3.2 with the VALU kernel, whose points take 16 bytes each).
+        const int label = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int64_t pair = (int64_t)(j / blocks_per_pair) * 8 + label;
+        block_of_range = j % blocks_per_pair;
+        if (pair >= batch) return;   // padding of the last group of eight
+        if (units > 1) {
+            unit = block_of_range % units;
+            block_of_range /= units;
+            split += pair * sfmws::split_bytes(h_count);
+        }
+        pts += pair * (int64_t)n;
+        table += pair * steps_of(n) * kBlocks * 64;
+        hyp_table += pair * (int64_t)h_count * 2 * kBlocks;
+        E += pair * (int64_t)h_count * 9;
+        S += pair * (int64_t)h_count * 8;
+        if (order != nullptr) order += pair * (int64_t)h_count;
+        cnt += pair * (int64_t)h_count;
+        s1 += pair * (int64_t)h_count;
+        s2 += pair * (int64_t)h_count;
+    } else if (units > 1) {   // `units` consecutive blocks take the same hypotheses over one range of the points each
         unit = block_of_range % units;
         block_of_range /= units;
     }

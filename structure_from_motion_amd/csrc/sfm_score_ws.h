@@ -3,7 +3,7 @@
 // fused pass in spare blocks of its own launch.
 //
 //   [batch x 4 uint32 maxima][batch x n float4 points][kPointsPad bytes][batch x kBuckets int32][batch x h_count int32]
-//   and for one pair: [range-split region][operand tables of the matrix-pipe kernel: points, hypotheses]   (below)
+//   then, for one pair, the range-split region, and the operand tables of the matrix-pipe kernel: points, hypotheses   (below)
 //
 // maxima: data-set maxima of |xa'|, |ya'|, |xb|, |yb| of the fp32 points as bit patterns (non-negative floats order
 // like unsigned ints).  buckets: per pair 256 ints — class counters of the longest-first ordering in large launches;
@@ -51,25 +51,30 @@ __host__ __device__ inline int64_t ws_split_offset(int64_t n, int64_t h_count) {
 __host__ __device__ inline int64_t split_bytes(int64_t h_count) {
     return split_padded(h_count) * (4 + kSplitMaxUnits * (4 + 8 + 8));
 }
-// Operand table of the matrix-pipe kernel (sfm_score_matrix.h; single pair, at most kMatrixMaxPoints points): per step of 32
-// points three blocks of 64 lanes x 16 bytes (96 bytes per point), behind the range-split region.
+// Operand tables of the matrix-pipe kernel (sfm_score_matrix.h; at most kMatrixMaxPoints points per pair), behind everything
+// else: per pair and step of 32 points three blocks of 64 lanes x 16 bytes (96 bytes per point), then per pair and hypothesis
+// 2 halves x 3 blocks x 16 bytes.
 constexpr int64_t kMatrixMaxPoints = 65536;
-__host__ __device__ inline int64_t matrix_table_bytes(int64_t n) {
+__host__ __device__ inline int64_t matrix_table_bytes(int64_t n) {   // one pair
     return n <= kMatrixMaxPoints ? ((n + 31) / 32) * 3 * 64 * 16 : 0;
 }
-__host__ __device__ inline int64_t ws_matrix_offset(int64_t n, int64_t h_count) {   // batch == 1
-    return ((ws_split_offset(n, h_count) + split_bytes(h_count) + 255) / 256) * 256;
-}
-// ... and behind it that kernel's operand table of the hypotheses: 2 halves x 3 blocks x 16 bytes each
-__host__ __device__ inline int64_t ws_matrix_hyp_offset(int64_t n, int64_t h_count) {   // batch == 1
-    return ((ws_matrix_offset(n, h_count) + matrix_table_bytes(n) + 255) / 256) * 256;
-}
-__host__ __device__ inline int64_t matrix_hyp_table_bytes(int64_t n, int64_t h_count) {
+__host__ __device__ inline int64_t matrix_hyp_table_bytes(int64_t n, int64_t h_count) {   // one pair
     return n <= kMatrixMaxPoints ? h_count * 96 : 0;
 }
+// (a batch of pairs keeps one range-split region per pair in front of the tables: the matrix-pipe kernel splits batches too)
+__host__ __device__ inline int64_t ws_batch_split_offset(int64_t n, int64_t h_count, int64_t batch) {   // batch > 1
+    return ((ws_order_offset(n, batch) + 4 * h_count * batch + 15) / 16) * 16;
+}
+__host__ __device__ inline int64_t ws_matrix_offset(int64_t n, int64_t h_count, int64_t batch) {
+    const int64_t before = batch == 1 ? ws_split_offset(n, h_count) + split_bytes(h_count)
+                                      : ws_batch_split_offset(n, h_count, batch) + (n <= kMatrixMaxPoints ? batch * split_bytes(h_count) : 0);
+    return ((before + 255) / 256) * 256;
+}
+__host__ __device__ inline int64_t ws_matrix_hyp_offset(int64_t n, int64_t h_count, int64_t batch) {
+    return ((ws_matrix_offset(n, h_count, batch) + batch * matrix_table_bytes(n) + 255) / 256) * 256;
+}
 __host__ __device__ inline int64_t workspace_bytes_for(int64_t n, int64_t h_count, int64_t batch) {
-    if (batch == 1) return ws_matrix_hyp_offset(n, h_count) + matrix_hyp_table_bytes(n, h_count);
-    return ws_order_offset(n, batch) + 4 * h_count * batch;
+    return ws_matrix_hyp_offset(n, h_count, batch) + batch * matrix_hyp_table_bytes(n, h_count);
 }
 
 // fp32 record of one correspondence as tier 1 reads it; a_scale: 1 for the two-sided test, c ~ 1/sqrt(T) for the

@@ -1106,6 +1106,22 @@ def test_matrix_score_ranges_and_order(dev, monkeypatch, split, order):
                                           b.view(np.int64) if b.dtype == np.float64 else b)
 
 
+@pytest.mark.parametrize("batch,n,h", [(5, 700, 70), (9, 300, 33), (17, 2100, 40), (3, 4099, 300)])
+def test_matrix_score_batches(dev, monkeypatch, batch, n, h):
+    """The matrix-pipe kernel on a batch of pairs (blocks of a pair share one L2: groups of eight pairs, the last one
+    padded; per-pair maxima, operand tables, cost order): every pair's counts equal the all-fp64 kernel's."""
+    monkeypatch.setenv("SFM_SCORE_MATRIX", "1")
+    corr = np.stack([scene(n, seed=40 + b)[3] for b in range(batch)])
+    S = np.stack([orc.philox_sample_table(50 + b, 0, h, n) for b in range(batch)])
+    E = np.stack([orc.fit_hypotheses(corr[b], S[b])[0] for b in range(batch)])
+    args = (dev.to_device(corr), dev.to_device(E.reshape(batch, h, 9)), dev.to_device(S, torch.int32))
+    for thr in (1.5e-6, 1e-3):
+        exact = [t.cpu().numpy() for t in dev.score_sed(*args, thr, exact_only=True)]
+        filt = [t.cpu().numpy() for t in dev.score_sed(*args, thr)]
+        for b in range(batch):
+            _assert_same_scores([x[b] for x in exact], [x[b] for x in filt])
+
+
 def test_score_kernel_size_rule_picks_the_matrix_kernel(dev, monkeypatch):
     """Left to itself (no SFM_SCORE_MATRIX) a single-pair launch of at least 8192 points, 4096 hypotheses and 5 x 10^8
     evaluations runs the matrix-pipe kernel: same counts as the all-fp64 kernel, and as the VALU-filter kernel forced with
