@@ -1039,7 +1039,7 @@ int launch_matrix(const FilteredLaunch& a) {
     const uint4* table = reinterpret_cast<const uint4*>(a.ws + ws_matrix_offset(a.n, a.h_count, a.batch));
     hipLaunchKernelGGL(matrix_prepare_kernel, dim3((unsigned)steps_of(a.n), pairs), dim3(64), 0, a.st, a.corr, a.n, a.a_scale, a.ws,
                        const_cast<uint4*>(table));
-    static_assert(kBlocks * 2 * 16 == 96, "matrix_hyp_table_bytes");
+    static_assert(kBlocks * 2 * 16 == 96, "sfm_score_ws.h sizes the tables: 3 blocks");
     const uint4* hyp_table = reinterpret_cast<const uint4*>(a.ws + ws_matrix_hyp_offset(a.n, a.h_count, a.batch));
     hipLaunchKernelGGL(matrix_hypothesis_kernel, dim3(grid_for(2 * (int64_t)a.h_count, 256), pairs), dim3(256), 0, a.st, a.ws, a.E,
                        a.h_count, a.a_scale, const_cast<uint4*>(hyp_table));

@@ -2,11 +2,14 @@
 //
 // Tier 1 of score_sed_filtered_kernel is two small contractions per (point, hypothesis):
 //   r'[i,h] = sum_t m_t(i) E_t(h),  m = (xb xa', xb ya', xb c, yb xa', yb ya', yb c, xa', ya', c)          (9 terms)
-//   dB[i,h] = sum_k q_k(i) g_k(h),  q = (xb^2, xb yb, yb^2, xb, yb, 1),  g = the quadratic form of lb0^2 + lb1^2 in E
+//   dS[i,h] = sum_k q_k(i) g_k(h),  the quadratic forms of dB = lb0^2 + lb1^2 (lb = E^T b) in (xb^2, xb yb, yb^2, xb, yb, 1) and of
+//             dA = la0^2 + la1^2 (la = E a) in (xa^2, xa ya, ya^2, xa, ya, 1), summed: by the harmonic-mean inequality
+//             sed = r^2 (1 / dA + 1 / dB) >= 4 r^2 / (dA + dB) — tight where dA = dB, never weaker than 2 r^2 / max(dA, dB); it lets
+//             1.05 x the true inliers through where the one-sided r^2 / dB of the VALU filter lets 1.42 x (12 terms)
 // On v_mfma_f32_32x32x2_f32 they cost more than the 12 VALU instructions they replace (round 2: fp32 MFMA runs at the VALU
 // rate).  The 16-bit MFMAs run at 16 x that rate, and a value is the sum of two fp16 values to 2^-22:
 //   r'  ~ sum_t  m_hi E_hi + m_hi E_mid + m_mid E_hi                                   27 products, K = 32: 2 x v_mfma_f32_32x32x16_f16
-//   dB <= sum_k bf(q_k) bf(g_k) + sum_k up(|q_k|) up(eps |g_k|) + slack(h)             13 products, K = 16: 1 x v_mfma_f32_32x32x16_bf16
+//   dS / 4 <= sum_k bf(q_k) bf(g_k / 4) + slack(h) + eps sum_k |g_k / 4| Q_k            13 products, K = 16: 1 x v_mfma_f32_32x32x16_bf16
 // per 32 points x 32 hypotheses: 96 matrix cycles and 3 VALU instructions per accumulator register (square, compare,
 // shift the result bit in) instead of 12 VALU instructions per 64 evaluations.  Points are the A operand (rows), hypotheses
 // the B operand (columns): lane l holds the results of hypothesis (l & 31) for 16 of a step's 32 points (rows
@@ -30,12 +33,13 @@
 // truncates each aligned addend at the unit of the largest one (probe: <= 3.9 * 2^-23 sum |products| observed), bounded here by
 // one ulp of the largest term per addend: 17 * 2^-23 sum |products| per instruction, 34 * 2^-23 for the chain of two.  Together
 //   |r''_mfma - r''| <= delta'' = 5.2e-6 sum_t |E_t| s_h M_t s_p        (M_t: data-set maximum of |m_t|).
-// dB: bf16 has 8 significant bits, |bf(x) - x| <= 2^-8 |x|, so |bf(q) bf(g) - q g| <= (2^-7 + 2^-16) |q g|, accumulation 17 * 2^-23:
-// eps = 0.008 times sum |q_k g_k| is added through six
-// more slots of the same instruction, all parts rounded up, so the accumulated value is an upper bound of the exact dB.
-// With (x - d)^2 >= x^2 / (1 + k) - d^2 / k, k = 2^-5:   r''^2 > dB''_up + delta''^2 (1 + k) / k  =>  c^2 r^2 >= dB / (1 + k)  =>
-// r^2 / dB >= T  when  c^2 (1 + k) T <= 1, and the derivation at the top of sfm_score.hip applies from there (sed_fl >= (1 - 5 * 2^-53)
-// r_fl^2 / db_fl; T carries the factor 1 + 1e-5 for the fp64 roundings and the square / compare of the test).  The slack
+// dS: bf16 has 8 significant bits, |bf(x) - x| <= 2^-8 |x|, so |bf(q) bf(g) - q g| <= (2^-7 + 2^-16) |q g|, accumulation 17 * 2^-23:
+// eps = 0.008 times sum |g_k| Q_k (Q_k: data-set maximum of |q_k|) rides with the slack, rounded up, so the accumulated value is an
+// upper bound of the exact (dA + dB) / 4.  (Per-point absolute terms |q_k| eps |g_k| in twelve more slots are tighter — 3.77 instead
+// of 3.87 % of the evaluations survive — but need a second operand block, 128 bytes per point, and lose: 1.59 vs 1.49 ms.)
+// With (x - d)^2 >= x^2 / (1 + k) - d^2 / k, k = 2^-5:   r''^2 > (dS'' / 4)_up + delta''^2 (1 + k) / k  =>  c^2 r^2 >= (dS / 4) / (1 + k)  =>
+// 4 r^2 / dS >= T  when  c^2 (1 + k) T <= 1, and sed_fl >= (1 - 5 * 2^-53) r_fl^2 (1 / da_fl + 1 / db_fl) >= (1 - 5 * 2^-53) 4 r_fl^2 /
+// (da_fl + db_fl) (T carries the factor 1 + 1e-5 for the fp64 roundings and the one rounding of the test).  The slack
 // rides in the constant slot of the dB chain.  A hypothesis whose magnitudes fall outside the scaled ranges, or with a NaN,
 // gets an infinite slack: nothing is rejected and the exact tier decides everything.
 #pragma once
@@ -62,7 +66,7 @@ typedef float float16v __attribute__((ext_vector_type(16)));
 
 constexpr int kTile = 32;        // points per step
 constexpr int kHyps = 32;        // hypotheses per wave
-constexpr int kBlocks = 3;       // K16 operand blocks per step: r' slots 0..15, r' slots 16..31, dB slots 0..15
+constexpr int kBlocks = 3;       // K16 operand blocks per step: r' slots 0..15 and 16..31 (fp16), denominator slots 0..15 (bf16)
 constexpr int kCap = 32;         // entries per lane queue (a power of two: the queue is a ring); an entry is one step's survivors
 constexpr int kHigh = kCap - 4;  // a step pushes at most one entry per lane: rounds start when a queue holds this many ...
 constexpr int kLow = 8;          // ... and stop when every queue is down to this
@@ -119,6 +123,7 @@ SFM_DEVICE float scale_to(float x, int top) {
 struct DataScale {
     float sp;
     bool ok;
+    float Q[12];   // data-set maxima of |q_k| (unscaled): the b-side monomials of dB, then the a-side ones of dA
 };
 SFM_DEVICE DataScale data_scale(const uint32_t* maxima, float w, float (&M)[9]) {
     const float Xa = __uint_as_float(maxima[0]) * (1.0f + 1e-6f), Ya = __uint_as_float(maxima[1]) * (1.0f + 1e-6f);
@@ -129,14 +134,18 @@ SFM_DEVICE DataScale data_scale(const uint32_t* maxima, float w, float (&M)[9]) 
     for (int j = 0; j < 9; ++j) mmax = fmaxf(mmax, M[j] * (1.0f + 1e-6f));
     DataScale d;
     d.sp = scale_to(mmax, kPointTop);
-    const float qmax = fmaxf(fmaxf(Xb * Xb, Yb * Yb), 1.0f) * (d.sp * d.sp);   // largest |q_k| s_p^2
+    const float xa = w > 0.0f ? Xa / w : 0.0f, ya = w > 0.0f ? Ya / w : 0.0f;   // the a side of the denominator form is unscaled
+    const float qmax = fmaxf(fmaxf(fmaxf(Xb * Xb, Yb * Yb), fmaxf(xa * xa, ya * ya)), 1.0f) * (d.sp * d.sp);   // largest |q_k| s_p^2
     d.ok = (mmax > 1e-12f) && (mmax < 1e12f) && (qmax < 1e30f) && (d.sp * d.sp > 1e-30f) && (w > 0.0f);
     if (!d.ok) d.sp = 1.0f;
+    constexpr float up = 1.0f + 1e-5f;   // xa, ya are quotients of rounded values
+    d.Q[0] = Xb * Xb; d.Q[1] = Xb * Yb; d.Q[2] = Yb * Yb; d.Q[3] = Xb; d.Q[4] = Yb; d.Q[5] = 1.0f;
+    d.Q[6] = xa * xa * up; d.Q[7] = xa * ya * up; d.Q[8] = ya * ya * up; d.Q[9] = xa * up; d.Q[10] = ya * up; d.Q[11] = 1.0f;
     return d;
 }
 
 // slot tables: r' slot s = 3 t + v  (t = term 0..8, v = 0: m_hi E_hi, 1: m_hi E_mid, 2: m_mid E_hi), slots 27..31 zero;
-// dB slot s: 0..5 q_k g_k, 6..11 |q_k| (eps |g_k|), 12: s_p^2 * slack / s_p^2, 13..15 zero
+// denominator slot s (one bf16 block): 0..5 qB_k gB_k / 4, 6..11 qA_k gA_k / 4, 12: s_p^2 * (slack + eps sum_k |g_k| Q_k) / s_p^2, 13..15 zero
 SFM_DEVICE float point_slot_r(const float (&mh)[9], const float (&mm)[9], int s) {
     if (s >= 27) return 0.0f;
     return (s % 3 == 2) ? mm[s / 3] : mh[s / 3];
@@ -162,20 +171,21 @@ __global__ __launch_bounds__(64) void matrix_prepare_kernel(const Corr* __restri
     float M[9];
     const DataScale data = data_scale(reinterpret_cast<const uint32_t*>(ws), (float)c * (1.0f + 1e-6f), M);
     const double sp = (double)data.sp;
-    float mh[9], mm[9], q[6];
+    float mh[9], mm[9], q[12];
 #pragma unroll
     for (int j = 0; j < 9; ++j) mh[j] = mm[j] = 0.0f;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) q[j] = 0.0f;
+    for (int j = 0; j < 12; ++j) q[j] = 0.0f;
     if (i < n && data.ok) {   // (filter off for the data set: all-zero operands, so that no product can be a NaN)
         const Corr p = corr[i];
         const double xa = p.xa * c, ya = p.ya * c;
         const double m[9] = {p.xb * xa, p.xb * ya, p.xb * c, p.yb * xa, p.yb * ya, p.yb * c, xa, ya, c};
 #pragma unroll
         for (int j = 0; j < 9; ++j) split2(m[j] * sp, mh[j], mm[j]);
-        const double qq[6] = {p.xb * p.xb, p.xb * p.yb, p.yb * p.yb, p.xb, p.yb, 1.0};
+        const double qq[12] = {p.xb * p.xb, p.xb * p.yb, p.yb * p.yb, p.xb, p.yb, 1.0,      // dB = lb0^2 + lb1^2, lb = E^T b
+                               p.xa * p.xa, p.xa * p.ya, p.ya * p.ya, p.xa, p.ya, 1.0};     // dA = la0^2 + la1^2, la = E a
 #pragma unroll
-        for (int j = 0; j < 6; ++j) q[j] = (float)(qq[j] * (sp * sp));
+        for (int j = 0; j < 12; ++j) q[j] = (float)(qq[j] * (sp * sp));
     }
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -189,8 +199,7 @@ __global__ __launch_bounds__(64) void matrix_prepare_kernel(const Corr* __restri
     for (int j = 0; j < 8; ++j) {
         const int s = 8 * half + j;
         float x = 0.0f;
-        if (s < 6) x = bf_round(q[s]);
-        else if (s < 12) x = bf_up(fabsf(q[s - 6]) * (1.0f + 1e-6f));
+        if (s < 12) x = bf_round(q[s]);
         else if (s == 12) x = (i < n) ? (float)(sp * sp) : 0.0f;
         v[j] = (__bf16)x;
     }
@@ -236,12 +245,15 @@ __global__ __launch_bounds__(256) void matrix_hypothesis_kernel(const unsigned c
         }
         const float delta = 5.2e-6f * weighted * up + poison;
         const float slack = (delta * delta) * (float)((1.0 + kKappa) / kKappa) * up + poison;   // in scaled units
-        const double g[6] = {e[0] * e[0] + e[1] * e[1], 2.0 * (e[0] * e[3] + e[1] * e[4]), e[3] * e[3] + e[4] * e[4],
-                             2.0 * (e[0] * e[6] + e[1] * e[7]), 2.0 * (e[3] * e[6] + e[4] * e[7]), e[6] * e[6] + e[7] * e[7]};
-        constexpr float eps = 0.008f;   // >= (1 + 2^-8)^2 - 1 + 20 * 2^-23 = 0.00783 with 2 % to spare
+        // (dA + dB) / 4 as quadratic forms of b = (xb, yb, 1) and a = (xa, ya, 1): lb = E^T b (columns of E), la = E a (rows)
+        const double g[12] = {0.25 * (e[0] * e[0] + e[1] * e[1]), 0.5 * (e[0] * e[3] + e[1] * e[4]), 0.25 * (e[3] * e[3] + e[4] * e[4]),
+                              0.5 * (e[0] * e[6] + e[1] * e[7]), 0.5 * (e[3] * e[6] + e[4] * e[7]), 0.25 * (e[6] * e[6] + e[7] * e[7]),
+                              0.25 * (e[0] * e[0] + e[3] * e[3]), 0.5 * (e[0] * e[1] + e[3] * e[4]), 0.25 * (e[1] * e[1] + e[4] * e[4]),
+                              0.5 * (e[0] * e[2] + e[3] * e[5]), 0.5 * (e[1] * e[2] + e[4] * e[5]), 0.25 * (e[2] * e[2] + e[5] * e[5])};
+        constexpr float eps = 0.008f;   // >= (1 + 2^-8)^2 - 1 + 40 * 2^-23 = 0.00783 with 2 % to spare
         float gmax = 0.f;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) gmax = fmaxf(gmax, fabsf((float)g[j]));
+        for (int j = 0; j < 12; ++j) gmax = fmaxf(gmax, fabsf((float)g[j]));
         // filter off for this hypothesis (every operand zero, infinite slack: r'' = 0, dB'' = +inf, nothing rejected and
         // nothing that could turn into a NaN): magnitudes outside the scaled ranges, a NaN or inf entry, thr off
         const bool armed = data.ok && (emax > 1e-12f) && (emax < 1e12f) && (gmax > 1e-20f) && (gmax < 1e24f) && (slack == slack) &&
@@ -252,13 +264,19 @@ __global__ __launch_bounds__(256) void matrix_hypothesis_kernel(const unsigned c
             B1[j] = (_Float16)(armed ? hyp_slot_r(eh, em, 16 + 8 * half + j) : 0.0f);
         }
         const double sh2 = (double)sh * (double)sh;
+        // the bf16 roundings of the twelve products and the accumulation: eps sum_k |g_k| Q_k with the data-set maxima Q_k — a
+        // constant per hypothesis that rides with the slack (per-point absolute terms would cost a second operand block:
+        // 128 instead of 96 bytes per point, measured as the bigger loss)
+        float rounding = 0.f;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) rounding += fabsf((float)(g[j] * sh2)) * (1.0f + 1e-6f) * (data.Q[j] * (1.0f + 1e-6f));
+        rounding *= eps * up;   // in units of s_h^2 (the point side multiplies by s_p^2)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int s = 8 * half + j;
             float x = 0.0f;
-            if (s < 6) x = armed ? bf_round(g[s] * sh2) : 0.0f;
-            else if (s < 12) x = armed ? bf_up(fabsf((float)(g[s - 6] * sh2)) * eps * up) : 0.0f;
-            else if (s == 12) x = armed ? bf_up(slack / (sp * sp) * up) : INFINITY;   // the point side carries s_p^2 in this slot
+            if (s < 12) x = armed ? bf_round(g[s] * sh2) : 0.0f;
+            else if (s == 12) x = armed ? bf_up((slack / (sp * sp) + rounding) * up) : INFINITY;   // the point side carries s_p^2 in this slot
             B2[j] = (__bf16)x;
         }
     }
