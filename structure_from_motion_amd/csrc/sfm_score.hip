@@ -1205,14 +1205,14 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
     // least 8192 points, 4096 hypotheses and 5 x 10^8 evaluations (same box: 50 000 x 100 000 1.79 vs 2.48 ms, x 125 000 2.30 vs
     // 3.11, x 20 000 0.44 vs 0.62, x 10 000 0.37 vs 0.41; 20 000 x 40 000 0.36 vs 0.46; but 16 000 x 16 000 0.25 vs 0.16,
     // 8192 x 25 000 0.23 vs 0.14: every wave pays ~500 instructions of operand preparation; profiles/r03/README.md)
-    // A batch of pairs: larger pairs only — 64 x 20 000 x 4 000: 2.63 vs 3.05 ms for the whole batched pipeline, but C5 = 256 x
-    // 10 000 x 2 000 is a tie at best (3.13-3.23 vs 3.21 ms: per pair an operand table, a cost pre-pass over an eighth of
-    // the points, a counting sort and ranges of 39 steps, each with its own prologue) and stays with the VALU kernel.
+    // A batch of pairs (whole batched pipeline, VALU vs matrix kernel): C5 = 256 x 10 000 x 2 000 3.26 vs 3.04 ms, 128 x 16 384 x
+    // 2 048 2.76 vs 2.38, 64 x 20 000 x 4 000 3.05 vs 2.63 — per pair an operand table, a cost pre-pass over an eighth of the
+    // points, a counting sort and ranges with their own prologues, so the gain is smaller than for one large pair.
     const int64_t waves32_all = (h_count + matrixscore::kHyps - 1) / matrixscore::kHyps * batch;
     const bool matrix_fits = n <= matrixscore::kMaxPoints &&
                              sfmhost::grid_fits((int64_t)grid_for((h_count + 31) / 32, 256 / kWave) * ((batch + 7) / 8 * 8), 1, 256);
     const bool matrix_pays = batch == 1 ? (n >= 8192 && h_count >= 4096 && (double)n * (double)h_count >= 5e8)
-                                        : (n >= 16384 && h_count >= 2048 && waves32_all >= 6144 &&
+                                        : (n >= 8192 && h_count >= 1024 && waves32_all >= 6144 &&
                                            (double)n * (double)h_count * (double)batch >= 5e8);
     const bool matrix = matrix_fits && (matrix_env > 0 || (matrix_env < 0 && matrix_pays));
     // Small point sets are prepared by one block per pair, which stores the maxima itself; the zeroing kernel is then
