@@ -412,8 +412,8 @@ def test_value_types():
 
 
 def test_bench_roofline_is_a_valu_issue_bound(monkeypatch, tmp_path):
-    """bench.py's roofline block: bound = valu-issue with frac = priced VALU instructions / (1024 SIMDs x 2.4 GHz x
-    kernel time) <= 1 for the committed counters, both HBM views beside it, and `counters_stale` raised as soon as the
+    """bench.py's roofline block: bound = valu-issue with frac = priced VALU (+ MFMA issue) instructions / (1024 SIMDs x
+    2.4 GHz x kernel time) <= 1 for the committed counters, both HBM views beside it, and `counters_stale` raised as soon as the
     record's fingerprint is not the one of the kernel sources in the tree; per-rank shards scale the record."""
     import importlib.util
     import json
@@ -425,14 +425,16 @@ def test_bench_roofline_is_a_valu_issue_bound(monkeypatch, tmp_path):
     spec.loader.exec_module(bench)
     rec = json.load(open(os.path.join(REPO, "profiles", "score_traffic.json")))
     n, h = rec["matches"], rec["hypotheses"]
-    roof = bench.roofline(n, h, kernel_ms=2.4, call_ms=2.5, variant="filtered")
-    assert roof["bound"] == "valu-issue" and 0.3 < roof["frac"] <= 1.0
+    monkeypatch.delenv("SFM_SCORE_MATRIX", raising=False)
+    assert bench.scoring_kernel_name("filtered", n, h) == rec["kernel_short"]   # the record is of the kernel the bench line runs
+    roof = bench.roofline(n, h, kernel_ms=1.5, call_ms=1.6, variant="filtered")
+    assert roof["bound"] == "valu-issue" and 0.3 < roof["frac"] <= 1.0 and roof["kernel"] == rec["kernel_short"]
     c = rec["counters"]
     f64 = sum(c[k] for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"))
-    cycles = (c["SQ_INSTS_VALU"] - f64) * 2.0 + f64 * 4.0
-    assert isclose(roof["frac"], cycles / 1024 / 2.4e9 / 2.4e-3, rel_tol=1e-12)
+    cycles = (c["SQ_INSTS_VALU"] - f64) * 2.0 + f64 * 4.0 + c.get("SQ_INSTS_MFMA", 0.0) * 8.0
+    assert isclose(roof["frac"], cycles / 1024 / 2.4e9 / 1.5e-3, rel_tol=1e-12)
     assert roof["hbm_algorithmic"]["frac"] > 1.0            # the L2-resident set: reported, labelled "not a bound"
-    assert roof["hbm_physical"]["frac"] < 0.05
+    assert roof["hbm_physical"]["frac"] < 0.1
     assert roof["traffic"] == (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
     assert roof["counters_stale"] == (rec["source_sha"] != build.score_source_sha())
     # a record taken on other sources is flagged, a record for another workload is not used
@@ -440,13 +442,13 @@ def test_bench_roofline_is_a_valu_issue_bound(monkeypatch, tmp_path):
     path = tmp_path / "score_traffic.json"
     path.write_text(json.dumps(stale))
     monkeypatch.setattr(bench, "COUNTERS", str(path))
-    assert bench.roofline(n, h, 2.4, 2.5, "filtered")["counters_stale"] is True
+    assert bench.roofline(n, h, 1.5, 1.6, "filtered")["counters_stale"] is True
     # another hypothesis count on the same point set (a multi-GPU shard): counters scale with the hypotheses, and say so
     shard = bench.roofline(n, h * 5 // 4, 3.0, 3.1, "filtered")
     assert shard["counters_from"]["scaled_from_hypotheses"] == h
     assert isclose(shard["frac"], 1.25 * cycles / 1024 / 2.4e9 / 3.0e-3, rel_tol=1e-12)
     # another point set: the record does not apply
-    other = bench.roofline(n + 1, h, 2.4, 2.5, "filtered")
+    other = bench.roofline(n + 1, h, 1.5, 1.6, "filtered")
     assert other["frac"] is None and other["counters_stale"] is None
 
 
