@@ -72,6 +72,10 @@ constexpr int kHigh = kCap - 4;  // a step pushes at most one entry per lane: ro
 constexpr int kLow = 8;          // ... and stop when every queue is down to this
 constexpr double kKappa = 1.0 / 32.0;
 constexpr int kPops = SFM_MATRIX_POPS;
+#ifndef SFM_MATRIX_AHEAD
+#define SFM_MATRIX_AHEAD 1
+#endif
+constexpr int kAhead = SFM_MATRIX_AHEAD;   // steps of operand loads in flight
 #ifndef SFM_MATRIX_ESTIMATE_STEPS
 #define SFM_MATRIX_ESTIMATE_STEPS 128
 #endif
@@ -406,18 +410,20 @@ __global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
     unsigned survivors = 0;   // ESTIMATE
     if (step_begin < step_end) {
         const uint4* __restrict__ src = table + lane;
-        uint4 A[kBlocks];
+        // operand loads run kAhead steps ahead of the step being processed (register stages shifted down once per step)
+        uint4 A[kAhead + 1][kBlocks];
 #pragma unroll
-        for (int b = 0; b < kBlocks; ++b) A[b] = src[((size_t)step_begin * kBlocks + b) * 64];
+        for (int a = 0; a < kAhead; ++a)
+#pragma unroll
+            for (int b = 0; b < kBlocks; ++b) A[a][b] = src[((size_t)min(step_begin + a, step_end - 1) * kBlocks + b) * 64];
         for (int t = step_begin; t < step_end; ++t) {
-            uint4 An[kBlocks];
-            const uint4* nxt = src + (size_t)min(t + 1, step_end - 1) * kBlocks * 64;
+            const uint4* nxt = src + (size_t)min(t + kAhead, step_end - 1) * kBlocks * 64;
 #pragma unroll
-            for (int b = 0; b < kBlocks; ++b) An[b] = nxt[b * 64];
+            for (int b = 0; b < kBlocks; ++b) A[kAhead][b] = nxt[b * 64];
             float16v r = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, d = r;
-            r = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[0]), B0, r, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[2]), B2, d, 0, 0, 0);
-            r = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[1]), B1, r, 0, 0, 0);
+            r = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[0][0]), B0, r, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[0][2]), B2, d, 0, 0, 0);
+            r = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[0][1]), B1, r, 0, 0, 0);
             // rejected bits, register 0 ending up in bit 15: the sign of dB - r^2 (one rounding: the sign is exact, and zero
             // — equality — keeps the point) shifted in with an alignbit.  A NaN with its sign set counts as rejected, which is
             // what the exact tier would decide for it (sed = NaN is not <= thr).
@@ -446,7 +452,9 @@ __global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
                 }
             }
 #pragma unroll
-            for (int b = 0; b < kBlocks; ++b) A[b] = An[b];
+            for (int a = 0; a < kAhead; ++a)
+#pragma unroll
+                for (int b = 0; b < kBlocks; ++b) A[a][b] = A[a + 1][b];
         }
     }
     if (ESTIMATE) {   // survivors per 1024 points of this hypothesis (both lanes) in sixteenths, at least 1 when there was any
