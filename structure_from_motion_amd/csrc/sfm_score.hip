@@ -1053,8 +1053,13 @@ int launch_matrix(const FilteredLaunch& a) {
     if (a.use_order) {
         // cost pre-pass with this kernel's own tier 1 over the first steps (survivors per 1024 points, in sixteenths, into
         // `cnt`, which the scoring launch rewrites), then the counting sort by class
-        hipLaunchKernelGGL(score_sed_matrix_kernel<true>, dim3(flat), dim3(256), 0, a.st, a.corr, hyp_table, table, a.n, a.E, a.S,
-                           a.h_count, a.thr, a.a_scale, (const int32_t*)nullptr, a.cnt, a.s1, a.s2, 1, estimate_steps(a.n),
+        const int e_steps = estimate_steps(a.n);
+        const int e_units = a.batch == 1 && e_steps >= 128 ? 4 : 1;   // a single pair: four ranges of the pre-pass's steps
+        if (e_units > 1)
+            hipLaunchKernelGGL(score_split_reset_kernel, dim3(grid_stride(a.h_count, 256, 1024)), dim3(256), 0, a.st, a.cnt,
+                               (int64_t)a.h_count);
+        hipLaunchKernelGGL(score_sed_matrix_kernel<true>, dim3(flat * (unsigned)e_units), dim3(256), 0, a.st, a.corr, hyp_table, table,
+                           a.n, a.E, a.S, a.h_count, a.thr, (const int32_t*)nullptr, a.cnt, a.s1, a.s2, e_units, e_steps / e_units,
                            (unsigned char*)nullptr, (int)a.batch, blocks_per_pair);
         const dim3 per_hyp(grid_for(a.h_count, 256), pairs);
         hipLaunchKernelGGL(score_class_count_kernel, per_hyp, dim3(256), 0, a.st, a.cnt, a.h_count, a.buckets);
@@ -1072,7 +1077,7 @@ int launch_matrix(const FilteredLaunch& a) {
     }
     if (g_event_before) (void)hipEventRecord(g_event_before, a.st);
     hipLaunchKernelGGL(score_sed_matrix_kernel<false>, dim3(flat * (unsigned)a.units), dim3(256), 0, a.st, a.corr, hyp_table, table, a.n,
-                       a.E, a.S, a.h_count, a.thr, a.a_scale, order_arg, a.cnt, a.s1, a.s2, a.units, a.chunks_per_unit, split,
+                       a.E, a.S, a.h_count, a.thr, order_arg, a.cnt, a.s1, a.s2, a.units, a.chunks_per_unit, split,
                        (int)a.batch, blocks_per_pair * a.units);
     if (g_event_after) (void)hipEventRecord(g_event_after, a.st);
     return check_launch("score_sed_matrix_kernel");

@@ -292,14 +292,15 @@ __global__ __launch_bounds__(256) void matrix_hypothesis_kernel(const unsigned c
 }
 
 // One wave: 32 hypotheses (entries [32 wave, 32 wave + 32) of the processing order) over the steps of one range of the points.
-// ESTIMATE: the cost pre-pass of this kernel — tier 1 alone over the first `steps_per_unit` steps, cnt[h] = the survivors per 1024
-// points in sixteenths (what the counting sort's classes are defined on).  With 1024 points the estimate is 52 +- 7 for a typical hypothesis
+// ESTIMATE: the cost pre-pass of this kernel — tier 1 alone over the first `units` x `steps_per_unit` steps (a single pair: in
+// `units` ranges by different waves, a pre-pass of 3125 waves over 128 steps each is latency-bound: 59 us, 4 x 32 steps: see
+// profiles/r03), cnt[h] = the survivors per 1024 points in sixteenths (what the counting sort's classes are defined on).  With 1024 points the estimate is 52 +- 7 for a typical hypothesis
 // and the 32 hypotheses a wave runs in lock step differ by that noise (lane utilisation 0.77); tier 1 on the matrix pipe makes
 // 4096 points as cheap as 1024 were on the VALU.
 template <bool ESTIMATE>
 __global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
     const Corr* __restrict__ pts, const uint4* __restrict__ hyp_table, const uint4* __restrict__ table, int n,
-    const double* __restrict__ E, const int32_t* __restrict__ S, int h_count, double thr, double a_scale,
+    const double* __restrict__ E, const int32_t* __restrict__ S, int h_count, double thr,
     const int32_t* __restrict__ order, int32_t* __restrict__ cnt, double* __restrict__ s1, double* __restrict__ s2, int units,
     int steps_per_unit, unsigned char* __restrict__ split, int batch, int blocks_per_pair) {
     __shared__ uint32_t queues[ESTIMATE ? 1 : 256 / kWave][ESTIMATE ? 1 : kCap][kWave];
@@ -405,8 +406,7 @@ __global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
 
     const int steps_total = (int)steps_of(n);
     const int step_begin = units > 1 ? unit * steps_per_unit : 0;
-    const int step_end = ESTIMATE ? min(steps_per_unit, steps_total)
-                                  : (units > 1 ? min(step_begin + steps_per_unit, steps_total) : steps_total);
+    const int step_end = units > 1 || ESTIMATE ? min(step_begin + steps_per_unit, steps_total) : steps_total;
     unsigned survivors = 0;   // ESTIMATE
     if (step_begin < step_end) {
         const uint4* __restrict__ src = table + lane;
@@ -459,9 +459,13 @@ __global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
     }
     if (ESTIMATE) {   // survivors per 1024 points of this hypothesis (both lanes) in sixteenths, at least 1 when there was any
         const unsigned both = survivors + (unsigned)__shfl_xor((int)survivors, 32, 64);
-        const unsigned scanned = (unsigned)min(step_end * kTile, n);
-        const unsigned sixteenths = (unsigned)(((unsigned long long)both * 16384ull) / (scanned > 0u ? scanned : 1u));
-        if (half == 0 && valid) cnt[h] = (int32_t)(both > 0u && sixteenths == 0u ? 1u : sixteenths);
+        const unsigned scanned = (unsigned)min(units * steps_per_unit * kTile, n);   // by all ranges of the pre-pass together
+        unsigned sixteenths = (unsigned)(((unsigned long long)both * 16384ull) / (scanned > 0u ? scanned : 1u));
+        sixteenths = both > 0u && sixteenths == 0u ? 1u : sixteenths;
+        if (half == 0 && valid) {
+            if (units > 1) atomicAdd(cnt + h, (int32_t)sixteenths);   // integer sums: any order (the launcher zeroed cnt)
+            else cnt[h] = (int32_t)sixteenths;
+        }
         return;
     }
     __builtin_amdgcn_wave_barrier();

@@ -16,6 +16,8 @@
 // hypothesis: the largest entry in [2^10, 2^11)); the dB chain (bf16: fp32's range) carries s_p^2 and s_h^2, so the compare
 // r''^2 > dB'' is the unscaled one.
 //
+// (This harness keeps the first form — one-sided dB with per-point absolute terms; the production kernel, csrc/sfm_score_matrix.h,
+// moved on to the harmonic-mean denominator (dA + dB) / 4.  bf16 has 8 significant bits: unit roundoff 2^-8.)
 // Bound (in scaled units; u16 = 2^-11).  x = hi + mid + res, |res| <= 2^-22 |x|, or 2^-15 absolute where mid would be
 // subnormal (taken as flushed).  Dropped products per term: mid*mid, res*x, x*res <= 3.1 * 2^-22 |m_t E_t| + the flush terms
 // (<= 2^-15 * 2^14 + 2^-15 * 2^11 per term: 0.6 against sum_t M_t |E_t| >= 2^23, i.e. < 2^-23 relative).  Accumulation: every
@@ -44,7 +46,7 @@ constexpr int kHyps = 32;      // hypotheses per wave
 constexpr int kBlocks = 3;     // K16 blocks per step: r' slots 0..15, r' slots 16..31, dB slots 0..15
 constexpr double kKappa = 1.0 / 32.0;
 
-SFM_DEVICE float bf_round(double x) { return (float)(__bf16)(float)x; }            // nearest (double rounding: < 2^-9 (1 + 2^-15))
+SFM_DEVICE float bf_round(double x) { return (float)(__bf16)(float)x; }            // nearest (double rounding: < 2^-8 (1 + 2^-15))
 SFM_DEVICE float bf_up(float x) {   // smallest bf16 >= x, x >= 0 (NaN stays NaN, inf stays inf)
     const float r = (float)(__bf16)x;
     if (!(r < x)) return r;
