@@ -500,7 +500,12 @@ def main():
             "higher_is_better": True,
             "scaling": scaling,
             "vs_baseline": None,
-            "dtype": "f64 (+ conservative f32 reject filter)" if variant == "filtered" else "f64",
+            # every counted decision and every summed error is fp64; the reject filter in front of it only ever discards pairs it
+            # proves to be outliers (fp16 / bf16 operands with fp32 accumulation on the matrix pipe, or fp32 on the VALU)
+            "dtype": ("f64" if variant != "filtered" else
+                      "f64 (+ conservative f16/bf16 matrix-pipe reject filter)"
+                      if scoring_kernel_name(variant, n, h) == "score_sed_matrix_kernel" else
+                      "f64 (+ conservative f32 reject filter)"),
             "data": "synthetic",
             "config": {
                 "workload": f"synthetic two-view, {n} correspondences x {total_h} RANSAC hypotheses "
