@@ -1122,6 +1122,22 @@ def test_matrix_score_batches(dev, monkeypatch, batch, n, h):
             _assert_same_scores([x[b] for x in exact], [x[b] for x in filt])
 
 
+def test_matrix_kernel_is_not_used_beyond_65536_points(dev, monkeypatch):
+    """Queue entries keep the step in 16 bits: a pair of more than 65 536 points runs the VALU-filter kernel even when the matrix
+    one is asked for — same bits as with SFM_SCORE_MATRIX=0, counts equal to the all-fp64 kernel's."""
+    n, h = 66_000, 96
+    _, _, _, corr = scene(n)
+    S = orc.philox_sample_table(3, 0, h, n)
+    E, _, _ = orc.fit_hypotheses(corr, S)
+    monkeypatch.setenv("SFM_SCORE_MATRIX", "1")
+    exact, asked = _score_both(dev, corr, E, S, 1.5e-6)
+    monkeypatch.setenv("SFM_SCORE_MATRIX", "0")
+    _, valu = _score_both(dev, corr, E, S, 1.5e-6)
+    _assert_same_scores(exact, asked)
+    for a, b in zip(asked, valu):
+        np.testing.assert_array_equal(a.view(np.int64) if a.dtype == np.float64 else a, b.view(np.int64) if b.dtype == np.float64 else b)
+
+
 def test_score_kernel_size_rule_picks_the_matrix_kernel(dev, monkeypatch):
     """Left to itself (no SFM_SCORE_MATRIX) a single-pair launch of at least 8192 points, 4096 hypotheses and 5 x 10^8
     evaluations runs the matrix-pipe kernel: same counts as the all-fp64 kernel, and as the VALU-filter kernel forced with
