@@ -29,6 +29,24 @@ def test_header_symbols_exported(native_lib):
     assert C.sizeof(_native.SelectResult) == 40
 
 
+def test_score_workspace_holds_every_region(native_lib):
+    """sfm_score_workspace_bytes (csrc/sfm_score_ws.h): fp32 points, class counters, scoring order, per-pair range-split
+    partials (16 ranges: 324 bytes per hypothesis) and the matrix-pipe kernel's operand tables (96 bytes per point and per
+    hypothesis, pairs of at most 65 536 points) — monotone in every argument, nothing for the tables beyond 65 536 points."""
+    size = native_lib.sfm_score_workspace_bytes
+    n, h = 50_000, 100_000
+    one = size(n, h, 1)
+    assert one >= 16 * n + 4 * h + 324 * h + 96 * (n + 31) // 32 * 32 + 96 * h
+    assert size(n + 32, h, 1) > one and size(n, h + 1, 1) > one
+    big = size(70_000, h, 1)
+    assert big < size(65_536, h, 1)            # no operand tables for a pair the matrix-pipe kernel cannot take
+    assert big >= 16 * 70_000 + 4 * h + 324 * h
+    batch = size(10_000, 2_000, 256)
+    assert batch >= 256 * (16 * 10_000 + 4 * 2_000 + 324 * 2_000 + 96 * 10_016 + 96 * 2_000)
+    assert size(10_000, 2_000, 257) > batch
+    assert size(-1, 5, 1) == -1 and size(5, -1, 1) == -1 and size(5, 5, -1) == -1
+
+
 def test_argument_validation_without_gpu(native_lib):
     """Bad sizes are rejected before any HIP call (safe on a CPU-only box)."""
     assert native_lib.sfm_sample_philox(1, 1, 0, 10, 7, 1, None, None) == -1
