@@ -40,18 +40,18 @@ HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); ~6290 measur
 SIMDS, CLOCK_GHZ = 1024, 2.4   # 256 CUs x 4 SIMD-32; max clock (MI355X_MICROARCH.md chip table)
 CYC_VALU, CYC_F64 = 2.0, 4.0   # spec issue cycles per wave64 instruction: v_fma_f32 2 (SIMD-32); fp64 at half rate
 CYC_MFMA = 8.0                 # vector-issue cycles a 32x32x16 16-bit MFMA holds (MI355X_MICROARCH.md cycle constants); it runs 32 on the matrix pipe
-
-
-def scoring_kernel_name(variant, n, h):
-    """Which scoring kernel sfm_score_sed launches for a single pair of this size (the rule in csrc/sfm_score.hip)."""
-    if variant == "exact":
-        return "score_sed_exact_kernel"
-    choice = os.environ.get("SFM_SCORE_MATRIX")
-    matrix = n <= 65536 and (int(choice) > 0 if choice not in (None, "") else (n >= 8192 and h >= 4096 and float(n) * h >= 5e8))
-    return "score_sed_matrix_kernel" if matrix else "score_sed_filtered_kernel"
 THR, MIN_EXTRA = 1.5e-6, 10    # reference apps/config/config.yaml:6-9 (RMS aggregation)
 C4_TOTAL = 1_000_000           # BASELINE.json configs[3]
 COUNTERS = os.path.join(REPO, "profiles", "score_traffic.json")
+
+
+def scoring_kernel_name(variant, n, h):
+    """Which scoring kernel sfm_score_sed launches for a single pair of this size (the library's own rule)."""
+    if variant == "exact":
+        return "score_sed_exact_kernel"
+    from structure_from_motion_amd import _native
+
+    return "score_sed_matrix_kernel" if _native.load().sfm_score_kernel_choice(n, h, 1) == 2 else "score_sed_filtered_kernel"
 
 
 def parse():

@@ -56,7 +56,7 @@ typedef struct sfm_select_result {
 
 /* Version of this interface: libsfm_hip.so reports the one it was compiled from (sfm_abi_version), the Python binding
  * and the torch op library (sfm_torch_ops_abi_version) refuse a library of another version. */
-#define SFM_ABI_VERSION 8
+#define SFM_ABI_VERSION 9
 
 const char* sfm_last_error(void);
 int sfm_abi_version(void);
@@ -128,6 +128,12 @@ int sfm_hartley_normalize(const double* coords, int64_t n, double* out, void* st
  * Large single-pair launches are cut into ranges of the points whose partial results are added in range order.  NULL selects
  * the all-fp64 kernel. */
 int64_t sfm_score_workspace_bytes(int64_t n, int64_t h_count, int64_t batch);
+/* Which kernel sfm_score_sed would launch for these sizes with a workspace, honouring SFM_SCORE_MATRIX: SFM_SCORE_KERNEL_FILTERED
+ * (fp32 VALU filter) or SFM_SCORE_KERNEL_MATRIX (fp16 / bf16 matrix-pipe filter); negative sizes: -1.  (For reports and tests:
+ * the results do not depend on it.) */
+#define SFM_SCORE_KERNEL_FILTERED 1
+#define SFM_SCORE_KERNEL_MATRIX 2
+int sfm_score_kernel_choice(int64_t n, int64_t h_count, int64_t batch);
 int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t* S, int64_t h_count,
                   int64_t batch, double thr, int32_t* cnt, double* s1, double* s2, void* workspace,
                   int64_t workspace_bytes, void* stream);

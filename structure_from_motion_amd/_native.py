@@ -15,7 +15,7 @@ AGG_SUM, AGG_SQUARE, AGG_MEAN, AGG_RMS = 0, 1, 2, 3
 FIT_DEGENERATE = 1
 MATCH_NCC, MATCH_SSD = 0, 1
 INT64_MAX = (1 << 63) - 1
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class SelectResult(C.Structure):
@@ -74,6 +74,7 @@ SIGNATURES = {
     "sfm_nms_finalize": [_P, _P, _I64, _I64, _P],
     "sfm_compact_nonzero": [_P, _I64, C.c_int32, _P, _P, _P, _P],
     "sfm_pyshuffle_table": [_P, _P, _I64, _I64, _P, _P, _I64, _P],
+    "sfm_score_kernel_choice": [_I64, _I64, _I64],
 }
 OTHER_SYMBOLS = ["sfm_last_error", "sfm_abi_version", "sfm_score_workspace_bytes", "sfm_fit_trace_doubles",
                  "sfm_match_summary_workspace_bytes"]

@@ -1032,6 +1032,27 @@ int launch_filtered(const FilteredLaunch& a) {
     return check_launch("score_sed_filtered_kernel");
 }
 
+// The size rule between the two filtered kernels of sfm_score_sed (and SFM_SCORE_MATRIX=1 / 0, which forces the matrix-pipe
+// kernel on where it applies / off).
+bool use_matrix_kernel(int64_t n, int64_t h_count, int64_t batch) {
+    const char* matrix_choice = getenv("SFM_SCORE_MATRIX");   // (read per call: the tests switch it)
+    const int matrix_env = matrix_choice ? atoi(matrix_choice) : -1;
+    // By itself when the launch is large enough to fill the chip with its waves of 32 hypotheses over ranges of the points: at
+    // least 8192 points, 4096 hypotheses and 5 x 10^8 evaluations (same box, VALU vs matrix kernel: 50 000 x 100 000 2.49 vs 1.49
+    // ms, x 125 000 2.97 vs 1.91, x 20 000 0.60 vs 0.43, 20 000 x 40 000 0.46 vs 0.31; but 16 000 x 16 000 0.16 vs 0.25, 8192 x
+    // 25 000 0.14 vs 0.23: the heaviest wave of a small launch takes ~0.2 ms whatever the size; profiles/r03/README.md)
+    // A batch of pairs (whole batched pipeline, VALU vs matrix kernel): C5 = 256 x 10 000 x 2 000 3.26 vs 3.04 ms, 128 x 16 384 x
+    // 2 048 2.76 vs 2.38, 64 x 20 000 x 4 000 3.05 vs 2.63 — per pair an operand table, a cost pre-pass over an eighth of the
+    // points, a counting sort and ranges with their own prologues, so the gain is smaller than for one large pair.
+    const int64_t waves32_all = (h_count + matrixscore::kHyps - 1) / matrixscore::kHyps * batch;
+    const bool matrix_fits = n <= matrixscore::kMaxPoints &&
+                             sfmhost::grid_fits((int64_t)grid_for((h_count + 31) / 32, 256 / kWave) * ((batch + 7) / 8 * 8), 1, 256);
+    const bool matrix_pays = batch == 1 ? (n >= 8192 && h_count >= 4096 && (double)n * (double)h_count >= 5e8)
+                                        : (n >= 8192 && h_count >= 1024 && waves32_all >= 6144 &&
+                                           (double)n * (double)h_count * (double)batch >= 5e8);
+    return matrix_fits && (matrix_env > 0 || (matrix_env < 0 && matrix_pays));
+}
+
 // Scoring launch with tier 1 on the matrix pipe (sfm_score_matrix.h): one pair, workspace prepared with that kernel's scale.
 int launch_matrix(const FilteredLaunch& a) {
     using namespace matrixscore;
@@ -1152,6 +1173,11 @@ int64_t sfm_score_workspace_bytes(int64_t n, int64_t h_count, int64_t batch) {
     return workspace_bytes_for(n, h_count, batch);
 }
 
+int sfm_score_kernel_choice(int64_t n, int64_t h_count, int64_t batch) {
+    if (n < 0 || h_count < 0 || batch < 0) return -1;
+    return use_matrix_kernel(n, h_count, batch) ? SFM_SCORE_KERNEL_MATRIX : SFM_SCORE_KERNEL_FILTERED;
+}
+
 int sfm_score_set_timing_events(void* before, void* after) {
     g_event_before = (hipEvent_t)before;
     g_event_after = (hipEvent_t)after;
@@ -1204,22 +1230,7 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
     // ... and its fixed cost (~25 us) needs enough points per hypothesis to be won back (measured break-even ~8k).
     const bool use_order = order_env >= 0 ? order_env != 0 : (waves * batch <= 12 * 5120 && n >= 8192);
     // tier 1 on the matrix pipe (sfm_score_matrix.h): SFM_SCORE_MATRIX=1 / 0 forces it on (where it applies) / off
-    const char* matrix_choice = getenv("SFM_SCORE_MATRIX");   // (read per call: the tests switch it)
-    const int matrix_env = matrix_choice ? atoi(matrix_choice) : -1;
-    // By itself when the launch is large enough to fill the chip with its waves of 32 hypotheses over ranges of the points: at
-    // least 8192 points, 4096 hypotheses and 5 x 10^8 evaluations (same box: 50 000 x 100 000 1.79 vs 2.48 ms, x 125 000 2.30 vs
-    // 3.11, x 20 000 0.44 vs 0.62, x 10 000 0.37 vs 0.41; 20 000 x 40 000 0.36 vs 0.46; but 16 000 x 16 000 0.25 vs 0.16,
-    // 8192 x 25 000 0.23 vs 0.14: every wave pays ~500 instructions of operand preparation; profiles/r03/README.md)
-    // A batch of pairs (whole batched pipeline, VALU vs matrix kernel): C5 = 256 x 10 000 x 2 000 3.26 vs 3.04 ms, 128 x 16 384 x
-    // 2 048 2.76 vs 2.38, 64 x 20 000 x 4 000 3.05 vs 2.63 — per pair an operand table, a cost pre-pass over an eighth of the
-    // points, a counting sort and ranges with their own prologues, so the gain is smaller than for one large pair.
-    const int64_t waves32_all = (h_count + matrixscore::kHyps - 1) / matrixscore::kHyps * batch;
-    const bool matrix_fits = n <= matrixscore::kMaxPoints &&
-                             sfmhost::grid_fits((int64_t)grid_for((h_count + 31) / 32, 256 / kWave) * ((batch + 7) / 8 * 8), 1, 256);
-    const bool matrix_pays = batch == 1 ? (n >= 8192 && h_count >= 4096 && (double)n * (double)h_count >= 5e8)
-                                        : (n >= 8192 && h_count >= 1024 && waves32_all >= 6144 &&
-                                           (double)n * (double)h_count * (double)batch >= 5e8);
-    const bool matrix = matrix_fits && (matrix_env > 0 || (matrix_env < 0 && matrix_pays));
+    const bool matrix = use_matrix_kernel(n, h_count, batch);
     // Small point sets are prepared by one block per pair, which stores the maxima itself; the zeroing kernel is then
     // only needed for the class counters of the ordering pre-pass (a small pass is a chain of ~4 us launches).
     const unsigned prepare_blocks = n <= 8192 ? 1u : grid_stride(n, 256, 64);

@@ -47,6 +47,23 @@ def test_score_workspace_holds_every_region(native_lib):
     assert size(-1, 5, 1) == -1 and size(5, -1, 1) == -1 and size(5, 5, -1) == -1
 
 
+def test_score_kernel_choice_rule(native_lib, monkeypatch):
+    """sfm_score_kernel_choice: 2 = the matrix-pipe kernel — single pairs from 8192 points x 4096 hypotheses x 5e8 evaluations,
+    batches from 8192 x 1024 per pair with 6144 waves and 5e8 evaluations over the batch, never beyond 65 536 points;
+    SFM_SCORE_MATRIX=1 / 0 forces it on (where it applies) / off."""
+    choice = native_lib.sfm_score_kernel_choice
+    monkeypatch.delenv("SFM_SCORE_MATRIX", raising=False)
+    assert choice(50_000, 100_000, 1) == 2 and choice(50_000, 125_000, 1) == 2 and choice(50_000, 10_000, 1) == 2
+    assert choice(5_000, 10_000, 1) == 1 and choice(16_000, 16_000, 1) == 1 and choice(8_191, 1_000_000, 1) == 1
+    assert choice(70_000, 100_000, 1) == 1
+    assert choice(10_000, 2_000, 256) == 2 and choice(10_000, 2_000, 16) == 1 and choice(4_000, 2_000, 256) == 1
+    monkeypatch.setenv("SFM_SCORE_MATRIX", "0")
+    assert choice(50_000, 100_000, 1) == 1
+    monkeypatch.setenv("SFM_SCORE_MATRIX", "1")
+    assert choice(300, 64, 1) == 2 and choice(70_000, 100_000, 1) == 1
+    assert choice(-1, 5, 1) == -1
+
+
 def test_argument_validation_without_gpu(native_lib):
     """Bad sizes are rejected before any HIP call (safe on a CPU-only box)."""
     assert native_lib.sfm_sample_philox(1, 1, 0, 10, 7, 1, None, None) == -1
