@@ -23,8 +23,9 @@ def main():
     corr_full = dev.normalize_correspondences(dev.to_device(pa), dev.to_device(pb), K).cpu().numpy()
     checked, boundary, t0 = 0, 0, time.time()
     for trial in range(trials):
-        n = int(rng.integers(8, 20000))
-        h = int(rng.integers(1, 40))
+        # SOAK_N_MIN / SOAK_H_MIN / SOAK_H_MAX move the size ranges (e.g. thousands of hypotheses: cost order, ranges of the points)
+        n = int(rng.integers(int(os.environ.get("SOAK_N_MIN", 8)), 20000))
+        h = int(rng.integers(int(os.environ.get("SOAK_H_MIN", 1)), int(os.environ.get("SOAK_H_MAX", 40))))
         corr = corr_full[rng.permutation(len(corr_full))[:n]].copy()
         if trial % 7 == 0:
             corr *= float(10.0 ** rng.uniform(0, 3))          # pixel-like coordinate ranges
@@ -76,7 +77,7 @@ def main():
                     sys.exit(1)
             checked += n * h
             boundary += int(ce.sum())
-        if trial % 200 == 0:
+        if trial % int(os.environ.get("SOAK_REPORT", 200)) == 0:
             print(f"trial {trial}: {checked:.3e} evaluations compared, {boundary:.3e} inliers, {time.time() - t0:.0f} s",
                   flush=True)
     print(f"OK: {trials} trials, {checked:.3e} evaluations, counts identical everywhere ({time.time() - t0:.0f} s)")
