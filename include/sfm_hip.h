@@ -56,7 +56,7 @@ typedef struct sfm_select_result {
 
 /* Version of this interface: libsfm_hip.so reports the one it was compiled from (sfm_abi_version), the Python binding
  * and the torch op library (sfm_torch_ops_abi_version) refuse a library of another version. */
-#define SFM_ABI_VERSION 9
+#define SFM_ABI_VERSION 10
 
 const char* sfm_last_error(void);
 int sfm_abi_version(void);
@@ -124,19 +124,47 @@ int sfm_hartley_normalize(const double* coords, int64_t n, double* out, void* st
  * enables the two-tier kernels (a conservative reject filter + exact fp64 evaluation of the survivors, hypotheses
  * processed longest-first; identical counts and inlier decisions, sums in a fixed order): the fp32 VALU filter, and for a
  * single pair of at least 8192 points, 4096 hypotheses and 5e8 evaluations (at most 65 536 points) the kernel with the
- * filter on the fp16 / bf16 matrix pipe and a lane-per-hypothesis exact tier (SFM_SCORE_MATRIX=1 / 0 forces it on / off).
+ * filter on the fp16 / bf16 matrix pipe and a lane-per-hypothesis exact tier (sfm_score_options.kernel forces it on / off).
  * Large single-pair launches are cut into ranges of the points whose partial results are added in range order.  NULL selects
  * the all-fp64 kernel. */
 int64_t sfm_score_workspace_bytes(int64_t n, int64_t h_count, int64_t batch);
-/* Which kernel sfm_score_sed would launch for these sizes with a workspace, honouring SFM_SCORE_MATRIX: SFM_SCORE_KERNEL_FILTERED
- * (fp32 VALU filter) or SFM_SCORE_KERNEL_MATRIX (fp16 / bf16 matrix-pipe filter); negative sizes: -1.  (For reports and tests:
- * the results do not depend on it.) */
-#define SFM_SCORE_KERNEL_FILTERED 1
-#define SFM_SCORE_KERNEL_MATRIX 2
-int sfm_score_kernel_choice(int64_t n, int64_t h_count, int64_t batch);
 int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t* S, int64_t h_count,
                   int64_t batch, double thr, int32_t* cnt, double* s1, double* s2, void* workspace,
                   int64_t workspace_bytes, void* stream);
+
+/* Launch options of the two-tier scoring kernels.  They change HOW a call is launched, never what it returns: counts and
+ * decisions are identical under every setting, the sums differ in their last bits between kernels / numbers of ranges
+ * (summation order) and are bit-identical from run to run under one setting.  The library does not read the process
+ * environment: a call carries its options (sfm_score_sed_ex; NULL = the process-wide defaults) and the embedding application
+ * sets the defaults once (sfm_score_set_default_options; the Python package translates SFM_SCORE_MATRIX / _HPW / _SPLIT /
+ * _ORDER / _ONE_SIDED / _XCD / _SYNC there when it is imported).  Safe to call from several threads: a default set is
+ * replaced as a whole. */
+#define SFM_SCORE_KERNEL_AUTO 0     /* the size rule described at sfm_score_sed */
+#define SFM_SCORE_KERNEL_FILTERED 1 /* fp32 VALU filter */
+#define SFM_SCORE_KERNEL_MATRIX 2   /* fp16 / bf16 matrix-pipe filter, where it applies (<= 65 536 points per pair), else FILTERED */
+typedef struct sfm_score_options {
+    int32_t kernel;        /* SFM_SCORE_KERNEL_AUTO / _FILTERED / _MATRIX */
+    int32_t hyps_per_wave; /* VALU-filter kernel: 0 = by launch size, or 1 / 2 / 4 */
+    int32_t split;         /* ranges of the points of a single pair: -1 = by launch size, 0 = none, k = k ranges (at most 16) */
+    int32_t order;         /* heaviest-first processing order: -1 = by launch size, 0 = index order, 1 = on */
+    int32_t one_sided;     /* VALU filter: -1 / 1 = one-sided test r^2 / dB (default), 0 = two-sided (ablation) */
+    int32_t xcd_map;       /* batches: -1 / 1 = all blocks of a pair on one XCD (default), 0 = plain (block, pair) grid */
+    int32_t block_sync;    /* sfm_ransac_pass_small: -1 = by size, k = block barrier every k loop iterations, 0 = never */
+    int32_t reserved;      /* 0 */
+} sfm_score_options;
+#define SFM_SCORE_OPTIONS_DEFAULT {SFM_SCORE_KERNEL_AUTO, 0, -1, -1, -1, -1, -1, 0}
+int sfm_score_sed_ex(const double* corr, int64_t n, const double* E, const int32_t* S, int64_t h_count,
+                     int64_t batch, double thr, int32_t* cnt, double* s1, double* s2, void* workspace,
+                     int64_t workspace_bytes, void* stream, const sfm_score_options* options);
+/* Process-wide defaults for calls without options (sfm_score_sed, sfm_ransac_pass_small, sfm_score_sed_ex(..., NULL));
+ * NULL restores SFM_SCORE_OPTIONS_DEFAULT.  _get copies the current set out. */
+int sfm_score_set_default_options(const sfm_score_options* options);
+int sfm_score_get_default_options(sfm_score_options* out);
+/* Which kernel a call would launch for these sizes with a workspace: SFM_SCORE_KERNEL_FILTERED or SFM_SCORE_KERNEL_MATRIX;
+ * negative sizes or bad options: -1.  (For reports and tests: the results do not depend on it.)  The plain form uses the
+ * process-wide defaults. */
+int sfm_score_kernel_choice(int64_t n, int64_t h_count, int64_t batch);
+int sfm_score_kernel_choice_ex(int64_t n, int64_t h_count, int64_t batch, const sfm_score_options* options);
 
 /* One whole RANSAC pass of a SMALL problem (one image pair, 8 <= n <= 8192, h_count <= 32768) in THREE lean launches
  * instead of the five of sfm_sample_fit_philox / sfm_fit_eight_point -> sfm_score_sed -> sfm_select_best -> sfm_inlier_mask, and the same
@@ -158,6 +186,19 @@ int sfm_ransac_pass_small(uint64_t seed, const uint64_t* seed_dev, int use_philo
                           int32_t* S, double* E, int32_t* flags, int32_t* cnt, double* s1, double* s2,
                           sfm_select_result* result, uint8_t* mask, void* workspace, int64_t workspace_bytes,
                           void* stream);
+
+/* Diagnostic of the matrix-pipe reject filter (tests measure the margin of its error bound with it; not on the product
+ * path): prepares the operand tables of one pair exactly as sfm_score_sed does and evaluates tier 1 — the three 16-bit
+ * matrix instructions — for EVERY (hypothesis, point), writing the raw fp32 accumulators instead of deciding on them.
+ * n <= 65536.  workspace as for sfm_score_sed(n, h_count, 1).  With n_pad = 32 * ceil(n / 32):
+ *   r_out  dev float [h_count, n_pad]   r'' = the scaled bilinear form c b^T E a s_p s_h as the matrix unit accumulated it
+ *   d_out  dev float [h_count, n_pad]   the accumulated upper bound of (dA + dB) / 4 s_p^2 s_h^2 + slack (a point is rejected
+ *                                       iff fma(-r'', r'', d) is negative); columns >= n are padding rows of zeros + slack
+ *   bound_out dev float [h_count, 8]    {delta'' (bound on |r''_mfma - r''|), slack'' = delta''^2 (1 + k) / k, s_h, armed (1 / 0),
+ *                                       s_p, the bf16-rounding term of the denominator chain in units of s_h^2, the constant
+ *                                       slot as stored, 0} */
+int sfm_debug_matrix_filter(const double* corr, int64_t n, const double* E, int64_t h_count, double thr, void* workspace,
+                            int64_t workspace_bytes, float* r_out, float* d_out, float* bound_out, void* stream);
 
 /* Measurement hook: the next sfm_score_sed calls of the calling thread record the hipEvent_t `before` / `after`
  * (passed as void*, either may be NULL) on the launch stream immediately around the scoring kernel itself — not the

@@ -15,7 +15,7 @@ AGG_SUM, AGG_SQUARE, AGG_MEAN, AGG_RMS = 0, 1, 2, 3
 FIT_DEGENERATE = 1
 MATCH_NCC, MATCH_SSD = 0, 1
 INT64_MAX = (1 << 63) - 1
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class SelectResult(C.Structure):
@@ -29,6 +29,56 @@ class SelectResult(C.Structure):
         ("n_flagged", C.c_int32),
         ("best_cnt", C.c_int32),
     ]
+
+
+class ScoreOptions(C.Structure):
+    """struct sfm_score_options (32 bytes): launch options of the two-tier scoring kernels — they change how a call is
+    launched, never its counts or decisions (include/sfm_hip.h)."""
+
+    _fields_ = [
+        ("kernel", C.c_int32),         # SCORE_KERNEL_AUTO / _FILTERED / _MATRIX
+        ("hyps_per_wave", C.c_int32),  # VALU-filter kernel: 0 = by launch size, 1 / 2 / 4
+        ("split", C.c_int32),          # ranges of the points: -1 = by launch size, 0 = none, k
+        ("order", C.c_int32),          # heaviest-first order: -1 = by launch size, 0 / 1
+        ("one_sided", C.c_int32),      # VALU filter: -1 / 1 one-sided (default), 0 two-sided
+        ("xcd_map", C.c_int32),        # batches: -1 / 1 XCD-aware block map (default), 0 plain grid
+        ("block_sync", C.c_int32),     # small pass: -1 = by size, k = barrier every k iterations, 0 never
+        ("reserved", C.c_int32),
+    ]
+
+    def __init__(self, kernel=0, hyps_per_wave=0, split=-1, order=-1, one_sided=-1, xcd_map=-1, block_sync=-1):
+        if isinstance(kernel, str):
+            kernel = {"auto": SCORE_KERNEL_AUTO, "filtered": SCORE_KERNEL_FILTERED, "matrix": SCORE_KERNEL_MATRIX}[kernel]
+        super().__init__(int(kernel), int(hyps_per_wave), int(split), int(order), int(one_sided), int(xcd_map),
+                         int(block_sync), 0)
+
+
+SCORE_KERNEL_AUTO, SCORE_KERNEL_FILTERED, SCORE_KERNEL_MATRIX = 0, 1, 2
+
+
+def score_options_from_env(environ=None) -> "ScoreOptions":
+    """The SFM_SCORE_* variables as a ScoreOptions (unset / unparsable = the library's default for that field).  The
+    package calls this ONCE, when the library is loaded, and hands the result to sfm_score_set_default_options: the
+    library itself never reads the environment."""
+    env = os.environ if environ is None else environ
+
+    def number(name, default):
+        try:
+            return int(env[name])
+        except (KeyError, ValueError):
+            return default
+
+    matrix = number("SFM_SCORE_MATRIX", -1)
+    hpw = number("SFM_SCORE_HPW", 0)
+    return ScoreOptions(
+        kernel=SCORE_KERNEL_AUTO if matrix < 0 else (SCORE_KERNEL_MATRIX if matrix > 0 else SCORE_KERNEL_FILTERED),
+        hyps_per_wave=hpw if hpw in (1, 2, 4) else 0,
+        split=max(-1, number("SFM_SCORE_SPLIT", -1)),
+        order=min(1, max(-1, number("SFM_SCORE_ORDER", -1))),
+        one_sided=min(1, max(-1, number("SFM_SCORE_ONE_SIDED", -1))),
+        xcd_map=min(1, max(-1, number("SFM_SCORE_XCD", -1))),
+        block_sync=max(-1, number("SFM_SCORE_SYNC", -1)),
+    )
 
 
 _P = C.c_void_p
@@ -49,6 +99,11 @@ SIGNATURES = {
     "sfm_fit_stage": [C.c_int, _P, _P, _P],
     "sfm_hartley_normalize": [_P, _I64, _P, _P],
     "sfm_score_sed": [_P, _I64, _P, _P, _I64, _I64, _D, _P, _P, _P, _P, _I64, _P],
+    "sfm_score_sed_ex": [_P, _I64, _P, _P, _I64, _I64, _D, _P, _P, _P, _P, _I64, _P, _P],
+    "sfm_score_set_default_options": [_P],
+    "sfm_score_get_default_options": [_P],
+    "sfm_score_kernel_choice_ex": [_I64, _I64, _I64, _P],
+    "sfm_debug_matrix_filter": [_P, _I64, _P, _I64, _D, _P, _I64, _P, _P, _P, _P],
     "sfm_score_set_timing_events": [_P, _P],
     "sfm_ransac_pass_small": [_U64, _P, C.c_int, _I64, _P, _I64, _I64, _D, _D, C.c_int, _I64, _P, _P, _P, _P, _P, _P,
                               _P, _P, _P, _I64, _P],
@@ -114,6 +169,10 @@ def load() -> C.CDLL:
     if lib.sfm_abi_version() != ABI_VERSION:
         raise NativeLibraryError(
             f"libsfm_hip.so ABI {lib.sfm_abi_version()} != expected {ABI_VERSION}; rebuild it")
+    # the SFM_SCORE_* variables, translated once per process (the library does not read the environment)
+    options = score_options_from_env()
+    if lib.sfm_score_set_default_options(C.byref(options)) != SFM_OK:
+        raise NativeLibraryError("SFM_SCORE_* environment: " + lib.sfm_last_error().decode("utf-8", "replace"))
     _lib = lib
     return lib
 

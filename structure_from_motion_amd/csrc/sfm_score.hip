@@ -42,6 +42,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <atomic>
 
 #include "sfm_common.h"
 #include "sfm_math.h"
@@ -910,9 +911,8 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
     if (units > 1) {
         // Range split: lane k publishes this range's partial of hypothesis k and counts itself in; the range that arrives
         // last adds the partials in range order — a fixed order, so the sums are the same from run to run — and writes
-        // the hypothesis' totals.  Hand-off between waves of different CUs without L1 invalidates: write-through
-        // (sc1) stores, drained, then the agent-scope counter; the reader's loads bypass L1 the same way
-        // (MI355X_MICROARCH.md, inter-workgroup visibility, "valid forms").  score_split_reset_kernel zeroed the counters.
+        // the hypothesis' totals (sfmws::split_arrive_and_fold: the partials are agent-scope atomic accesses, the arrival an
+        // ACQ_REL read-modify-write at agent scope).  score_split_reset_kernel zeroed the counters.
         bool owner = false;
         int my_h = 0;
 #pragma unroll
@@ -920,32 +920,10 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
             owner |= (lane == k) && slot_valid[k];
             my_h = (lane == k) ? hyp[k] : my_h;
         }
-        if (owner) {
-            const int64_t hp = split_padded(h_count);
-            int32_t* arrivals = reinterpret_cast<int32_t*>(split);
-            int32_t* part_c = arrivals + hp;
-            double* part_a1 = reinterpret_cast<double*>(part_c + kSplitMaxUnits * hp);
-            double* part_a2 = part_a1 + kSplitMaxUnits * hp;
-            __hip_atomic_store(part_c + unit * hp + my_h, mine_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(part_a1 + unit * hp + my_h, mine_a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(part_a2 + unit * hp + my_h, mine_a2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const int arrived = __hip_atomic_fetch_add(arrivals + my_h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (arrived == units - 1) {
-                int ck = 0;
-                double s1k = 0.0, s2k = 0.0;
-                for (int uu = 0; uu < units; ++uu) {
-                    const int pc = __hip_atomic_load(part_c + uu * hp + my_h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const double p1 = __hip_atomic_load(part_a1 + uu * hp + my_h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const double p2 = __hip_atomic_load(part_a2 + uu * hp + my_h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ck += pc;
-                    s1k = (uu == 0) ? p1 : s1k + p1;
-                    s2k = (uu == 0) ? p2 : s2k + p2;
-                }
-                cnt[my_h] = ck;
-                s1[my_h] = s1k;
-                s2[my_h] = s2k;
-            }
+        if (owner && sfmws::split_arrive_and_fold(split, h_count, units, unit, my_h, mine_c, mine_a1, mine_a2)) {
+            cnt[my_h] = mine_c;
+            s1[my_h] = mine_a1;
+            s2[my_h] = mine_a2;
         }
     }
 #if SFM_WAVE_STAMPS
@@ -982,6 +960,7 @@ struct FilteredLaunch {
     bool one_sided;
     double a_scale;
     int units, chunks_per_unit;   // range split (single pair): 1, 0 = off
+    bool xcd_map = true;          // batches: all blocks of a pair on one XCD (options.xcd_map)
 };
 
 template <int HPW>
@@ -1008,8 +987,7 @@ int launch_filtered(const FilteredLaunch& a) {
         order_arg = a.order;
     }
     const int64_t flat_blocks = (int64_t)grid.x * ((a.batch + 7) / 8 * 8);
-    static const bool xcd_env = getenv("SFM_SCORE_XCD") ? atoi(getenv("SFM_SCORE_XCD")) != 0 : true;
-    const bool remap = xcd_env && a.batch > 1 && flat_blocks <= 0x7FFFFFFF;  // see the kernel's block -> (pair, block) map
+    const bool remap = a.xcd_map && a.batch > 1 && flat_blocks <= 0x7FFFFFFF;  // see the kernel's block -> (pair, block) map
     const int blocks_per_pair = remap ? (int)grid.x : 0;
     dim3 flat = remap ? dim3((unsigned)flat_blocks) : grid;
     unsigned char* split = nullptr;
@@ -1032,11 +1010,27 @@ int launch_filtered(const FilteredLaunch& a) {
     return check_launch("score_sed_filtered_kernel");
 }
 
-// The size rule between the two filtered kernels of sfm_score_sed (and SFM_SCORE_MATRIX=1 / 0, which forces the matrix-pipe
-// kernel on where it applies / off).
-bool use_matrix_kernel(int64_t n, int64_t h_count, int64_t batch) {
-    const char* matrix_choice = getenv("SFM_SCORE_MATRIX");   // (read per call: the tests switch it)
-    const int matrix_env = matrix_choice ? atoi(matrix_choice) : -1;
+// Launch options (sfm_score_options, include/sfm_hip.h).  The library never reads the process environment: a call carries its
+// options (sfm_score_sed_ex) or takes the process-wide defaults, which the embedding application sets once
+// (sfm_score_set_default_options — the Python package translates the SFM_SCORE_* variables at import).  A default set is an
+// immutable heap copy behind an atomic pointer, so a call on another thread sees either the old set or the new one, whole.
+constexpr sfm_score_options kBuiltinOptions = SFM_SCORE_OPTIONS_DEFAULT;
+std::atomic<const sfm_score_options*> g_default_options{&kBuiltinOptions};
+
+sfm_score_options resolve_options(const sfm_score_options* given) {
+    return given ? *given : *g_default_options.load(std::memory_order_acquire);
+}
+bool valid_options(const sfm_score_options& o) {
+    return (o.kernel == SFM_SCORE_KERNEL_AUTO || o.kernel == SFM_SCORE_KERNEL_FILTERED || o.kernel == SFM_SCORE_KERNEL_MATRIX) &&
+           (o.hyps_per_wave == 0 || o.hyps_per_wave == 1 || o.hyps_per_wave == 2 || o.hyps_per_wave == 4) && o.split >= -1 &&
+           o.order >= -1 && o.order <= 1 && o.one_sided >= -1 && o.one_sided <= 1 && o.xcd_map >= -1 && o.xcd_map <= 1 &&
+           o.block_sync >= -1 && o.reserved == 0;
+}
+
+// The size rule between the two filtered kernels of sfm_score_sed (options.kernel forces the matrix-pipe kernel on where it
+// applies / off).
+bool use_matrix_kernel(int64_t n, int64_t h_count, int64_t batch, const sfm_score_options& opt) {
+    const int matrix_env = opt.kernel == SFM_SCORE_KERNEL_MATRIX ? 1 : opt.kernel == SFM_SCORE_KERNEL_FILTERED ? 0 : -1;
     // By itself when the launch is large enough to fill the chip with its waves of 32 hypotheses over ranges of the points: at
     // least 8192 points, 4096 hypotheses and 5 x 10^8 evaluations (same box, VALU vs matrix kernel: 50 000 x 100 000 2.49 vs 1.49
     // ms, x 125 000 2.97 vs 1.91, x 20 000 0.60 vs 0.43, 20 000 x 40 000 0.46 vs 0.31; but 16 000 x 16 000 0.16 vs 0.25, 8192 x
@@ -1063,7 +1057,7 @@ int launch_matrix(const FilteredLaunch& a) {
     static_assert(kBlocks * 2 * 16 == 96, "sfm_score_ws.h sizes the tables: 3 blocks");
     const uint4* hyp_table = reinterpret_cast<const uint4*>(a.ws + ws_matrix_hyp_offset(a.n, a.h_count, a.batch));
     hipLaunchKernelGGL(matrix_hypothesis_kernel, dim3(grid_for(2 * (int64_t)a.h_count, 256), pairs), dim3(256), 0, a.st, a.ws, a.E,
-                       a.h_count, a.a_scale, const_cast<uint4*>(hyp_table));
+                       a.h_count, a.a_scale, const_cast<uint4*>(hyp_table), (float*)nullptr);
     const int64_t waves = (a.h_count + kHyps - 1) / kHyps;
     const unsigned blocks = grid_for(waves, 256 / kWave);
     // batches: flat grid of 8-pair groups (the kernel's block -> (pair, block) map), `units` range blocks per block of a pair; a
@@ -1120,9 +1114,9 @@ int launch_small_score(const SmallPass& p) {
     // hypotheses per wave: at most 32768 hypotheses are a few generations of waves at best, where two per wave (7
     // waves per SIMD) beat four (5 per SIMD; measured at 20 000 and 30 000 hypotheses: 80 vs 85 and 186 vs 198 us per
     // pass) and one per wave wins as long as two would leave the chip short of waves (profiles/r02/small_pass_hpw.log)
+    const sfm_score_options opt = resolve_options(nullptr);   // a small pass runs with the process-wide defaults
     int hpw = (p.h_count + 1) / 2 >= 5120 ? 2 : 1;
-    const int hpw_env = getenv("SFM_SCORE_HPW") ? atoi(getenv("SFM_SCORE_HPW")) : 0;
-    if (hpw_env == 1 || hpw_env == 2 || hpw_env == 4) hpw = hpw_env;
+    if (opt.hyps_per_wave != 0) hpw = opt.hyps_per_wave;
     const int64_t waves = (p.h_count + hpw - 1) / hpw;
     const int64_t blocks = (waves + 256 / kWave - 1) / (256 / kWave);
     SFM_REQUIRE_GRID("sfm_ransac_pass_small", blocks, 1, 256);
@@ -1130,9 +1124,8 @@ int launch_small_score(const SmallPass& p) {
     const dim3 grid((unsigned)blocks);
     // block barrier every `sync_every` iterations (three 128-point steps each) of the one-hypothesis-per-wave loop (0 = never): see the kernel
     // measured (profiles/r03/small_pass/block_barrier.log): every 1..4 iterations alike, -2 % at 5000 x 10000, -5 % at 7000..8000
-    // points (L1 -> L2 requests -41 %), nothing below ~4000 points; SFM_SCORE_SYNC overrides
-    static const int sync_env = getenv("SFM_SCORE_SYNC") ? atoi(getenv("SFM_SCORE_SYNC")) : -1;
-    const int sync_every = sync_env >= 0 ? sync_env : (hpw == 1 && p.n >= 4096 ? 2 : 0);
+    // points (L1 -> L2 requests -41 %), nothing below ~4000 points; options.block_sync overrides
+    const int sync_every = opt.block_sync >= 0 ? opt.block_sync : (hpw == 1 && p.n >= 4096 ? 2 : 0);
     if (g_event_before) (void)hipEventRecord(g_event_before, p.stream);
 #define SFM_LAUNCH_FUSED(H)                                                                                          \
     hipLaunchKernelGGL((score_sed_filtered_kernel<H, true, true>), grid, dim3(256), 0, p.stream, (const Corr*)p.corr, \
@@ -1173,9 +1166,58 @@ int64_t sfm_score_workspace_bytes(int64_t n, int64_t h_count, int64_t batch) {
     return workspace_bytes_for(n, h_count, batch);
 }
 
-int sfm_score_kernel_choice(int64_t n, int64_t h_count, int64_t batch) {
+int sfm_score_kernel_choice_ex(int64_t n, int64_t h_count, int64_t batch, const sfm_score_options* options) {
     if (n < 0 || h_count < 0 || batch < 0) return -1;
-    return use_matrix_kernel(n, h_count, batch) ? SFM_SCORE_KERNEL_MATRIX : SFM_SCORE_KERNEL_FILTERED;
+    const sfm_score_options opt = resolve_options(options);
+    if (!valid_options(opt)) return -1;
+    return use_matrix_kernel(n, h_count, batch, opt) ? SFM_SCORE_KERNEL_MATRIX : SFM_SCORE_KERNEL_FILTERED;
+}
+
+int sfm_score_kernel_choice(int64_t n, int64_t h_count, int64_t batch) {
+    return sfm_score_kernel_choice_ex(n, h_count, batch, nullptr);
+}
+
+int sfm_score_set_default_options(const sfm_score_options* options) {
+    if (options && !valid_options(*options)) return fail(SFM_EINVAL, "sfm_score_set_default_options: a field is out of range");
+    // (earlier sets stay allocated: a call that loaded the pointer just before may still be reading one; they are 32 bytes each
+    // and set once per process in practice)
+    const sfm_score_options* next = options ? new sfm_score_options(*options) : &kBuiltinOptions;
+    g_default_options.store(next, std::memory_order_release);
+    return SFM_OK;
+}
+
+int sfm_score_get_default_options(sfm_score_options* out) {
+    if (!out) return fail(SFM_EINVAL, "sfm_score_get_default_options: null pointer");
+    *out = resolve_options(nullptr);
+    return SFM_OK;
+}
+
+int sfm_debug_matrix_filter(const double* corr, int64_t n, const double* E, int64_t h_count, double thr, void* workspace,
+                            int64_t workspace_bytes, float* r_out, float* d_out, float* bound_out, void* stream) {
+    if (n < 8 || h_count < 1 || n > matrixscore::kMaxPoints || h_count > 0x3FFFFFFF)
+        return fail(SFM_EINVAL, "sfm_debug_matrix_filter: 8 <= n <= 65536 points and at least one hypothesis");
+    if (!corr || !E || !workspace || !r_out || !d_out || !bound_out) return fail(SFM_EINVAL, "sfm_debug_matrix_filter: null pointer");
+    if (workspace_bytes < workspace_bytes_for(n, h_count, 1) || (reinterpret_cast<uintptr_t>(workspace) & 15u) != 0)
+        return fail(SFM_EINVAL, "sfm_debug_matrix_filter: workspace of sfm_score_workspace_bytes(n, h_count, 1) bytes, 16-byte aligned");
+    using namespace matrixscore;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned char* ws = static_cast<unsigned char*>(workspace);
+    const int steps = (int)steps_of(n);
+    const int64_t tiles = (h_count + kHyps - 1) / kHyps;
+    if (!sfmhost::grid_fits(steps, 1, 64) || tiles > 65535) return fail(SFM_EINVAL, "sfm_debug_matrix_filter: too many tiles");
+    // exactly what sfm_score_sed does in front of the matrix-pipe kernel: maxima + fp32 points, then the two operand tables
+    const double a_scale = scale_for(thr);
+    hipLaunchKernelGGL(score_reset_kernel, dim3(1), dim3(256), 0, st, ws, reinterpret_cast<int32_t*>(ws + ws_buckets_offset(n, 1)));
+    hipLaunchKernelGGL(score_prepare_kernel, dim3(n <= 8192 ? 1u : grid_stride(n, 256, 64), 1), dim3(256), 0, st, (const Corr*)corr,
+                       n, a_scale, ws);
+    uint4* table = reinterpret_cast<uint4*>(ws + ws_matrix_offset(n, h_count, 1));
+    uint4* hyp_table = reinterpret_cast<uint4*>(ws + ws_matrix_hyp_offset(n, h_count, 1));
+    hipLaunchKernelGGL(matrix_prepare_kernel, dim3((unsigned)steps, 1), dim3(64), 0, st, (const Corr*)corr, (int)n, a_scale, ws, table);
+    hipLaunchKernelGGL(matrix_hypothesis_kernel, dim3(grid_for(2 * h_count, 256), 1), dim3(256), 0, st, ws, E, (int)h_count, a_scale,
+                       hyp_table, bound_out);
+    hipLaunchKernelGGL(matrix_filter_dump_kernel, dim3((unsigned)steps, (unsigned)tiles), dim3(64), 0, st, hyp_table, table, steps,
+                       (int)h_count, r_out, d_out);
+    return check_launch("matrix_filter_dump_kernel");
 }
 
 int sfm_score_set_timing_events(void* before, void* after) {
@@ -1187,6 +1229,14 @@ int sfm_score_set_timing_events(void* before, void* after) {
 int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t* S, int64_t h_count,
                   int64_t batch, double thr, int32_t* cnt, double* s1, double* s2, void* workspace,
                   int64_t workspace_bytes, void* stream) {
+    return sfm_score_sed_ex(corr, n, E, S, h_count, batch, thr, cnt, s1, s2, workspace, workspace_bytes, stream, nullptr);
+}
+
+int sfm_score_sed_ex(const double* corr, int64_t n, const double* E, const int32_t* S, int64_t h_count,
+                     int64_t batch, double thr, int32_t* cnt, double* s1, double* s2, void* workspace,
+                     int64_t workspace_bytes, void* stream, const sfm_score_options* options) {
+    const sfm_score_options opt = resolve_options(options);
+    if (!valid_options(opt)) return fail(SFM_EINVAL, "sfm_score_sed_ex: an option is out of range");
     if (h_count < 0 || batch < 0 || n < 0) return fail(SFM_EINVAL, "sfm_score_sed: negative size");
     if (n > 0x7FFFFFFF || h_count > 0x3FFFFFFF) return fail(SFM_EINVAL, "sfm_score_sed: size too large");
     if (h_count == 0 || batch == 0) return SFM_OK;
@@ -1208,11 +1258,10 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
     if ((reinterpret_cast<uintptr_t>(workspace) & 15u) != 0)
         return fail(SFM_EINVAL, "sfm_score_sed: workspace must be 16-byte aligned");
     // hypotheses per wave: 4 amortises the point loads best, but a launch with fewer waves than the chip holds
-    // (5120) leaves SIMDs idle — then fewer hypotheses per wave = more waves wins (SFM_SCORE_HPW overrides)
-    const int hpw_env = getenv("SFM_SCORE_HPW") ? atoi(getenv("SFM_SCORE_HPW")) : 0;
+    // (5120) leaves SIMDs idle — then fewer hypotheses per wave = more waves wins (options.hyps_per_wave overrides)
     int hpw = kHypPerWave;
-    if (hpw_env == 1 || hpw_env == 2 || hpw_env == 4) {
-        hpw = hpw_env;
+    if (opt.hyps_per_wave != 0) {
+        hpw = opt.hyps_per_wave;
     } else {
         while (hpw > 1 && (h_count + hpw - 1) / hpw * batch < 5120) hpw /= 2;
     }
@@ -1222,22 +1271,22 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
     unsigned char* ws = static_cast<unsigned char*>(workspace);
     int32_t* buckets = reinterpret_cast<int32_t*>(ws + ws_buckets_offset(n, batch));
     int32_t* order = reinterpret_cast<int32_t*>(ws + ws_order_offset(n, batch));
-    // longest-first processing order (cost pre-pass + counting sort); SFM_SCORE_ORDER=0 keeps index order
+    // longest-first processing order (cost pre-pass + counting sort); options.order = 0 keeps index order
     // It pays only when the launch has few generations of waves (a long wave starting late then idles the chip at
     // the end): 256 CUs x 20 resident waves = 5120 per generation; beyond ~12 generations the tail is negligible
     // and the pre-pass would cost more than it saves.
-    const int order_env = getenv("SFM_SCORE_ORDER") ? atoi(getenv("SFM_SCORE_ORDER")) : -1;
+    const int order_env = opt.order;
     // ... and its fixed cost (~25 us) needs enough points per hypothesis to be won back (measured break-even ~8k).
     const bool use_order = order_env >= 0 ? order_env != 0 : (waves * batch <= 12 * 5120 && n >= 8192);
-    // tier 1 on the matrix pipe (sfm_score_matrix.h): SFM_SCORE_MATRIX=1 / 0 forces it on (where it applies) / off
-    const bool matrix = use_matrix_kernel(n, h_count, batch);
+    // tier 1 on the matrix pipe (sfm_score_matrix.h): options.kernel forces it on (where it applies) / off
+    const bool matrix = use_matrix_kernel(n, h_count, batch, opt);
     // Small point sets are prepared by one block per pair, which stores the maxima itself; the zeroing kernel is then
     // only needed for the class counters of the ordering pre-pass (a small pass is a chain of ~4 us launches).
     const unsigned prepare_blocks = n <= 8192 ? 1u : grid_stride(n, 256, 64);
     if (use_order || matrix || prepare_blocks > 1)
         hipLaunchKernelGGL(score_reset_kernel, dim3((unsigned)batch), dim3(256), 0, st, ws, buckets);
-    // SFM_SCORE_ONE_SIDED=0 switches tier 1 back to the two-sided test (ablation)
-    static const bool one_sided = getenv("SFM_SCORE_ONE_SIDED") ? atoi(getenv("SFM_SCORE_ONE_SIDED")) != 0 : true;
+    // options.one_sided = 0 switches tier 1 of the VALU filter back to the two-sided test (ablation)
+    const bool one_sided = opt.one_sided != 0;
     const double a_scale = matrix ? matrixscore::scale_for(thr) : (one_sided ? one_sided_scale(thr) : 1.0);
     hipLaunchKernelGGL(score_prepare_kernel, dim3(prepare_blocks, (unsigned)batch), dim3(256), 0, st,
                        (const Corr*)corr, n, a_scale, ws);
@@ -1247,10 +1296,9 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
     // that its last generation — a whole wave duration of draining chip — is half as long: 2.233-2.240 ms against
     // 2.279-2.297 ms at 50 000 x 100 000 (4.9 generations), 2.803 vs 2.831 at 125 000 hypotheses (6.1).  Four ranges
     // give the gain back (2.286 ms), launches of one or two generations lose (20 000 x 40 000: 0.480 vs 0.458 ms with
-    // four ranges), more generations have no tail to speak of (profiles/r03/README.md).  SFM_SCORE_SPLIT=0 switches it
-    // off, =k forces k ranges.
-    const char* split_choice = getenv("SFM_SCORE_SPLIT");   // (read per call: the tests switch it)
-    const int split_env = split_choice ? atoi(split_choice) : -1;
+    // four ranges), more generations have no tail to speak of (profiles/r03/README.md).  options.split = 0 switches it
+    // off, = k forces k ranges.
+    const int split_env = opt.split;
     int units = 1, chunks_per_unit = 0;
     if (batch == 1 && split_env != 0) {
         const int64_t launch_waves = (h_count + hpw - 1) / hpw;
@@ -1290,7 +1338,7 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
         return launch_matrix(margs);
     }
     const FilteredLaunch args{(const Corr*)corr, ws, (int)n, E, S, (int)h_count, thr, use_order, cnt, s1, s2,
-                              buckets, order, batch, st, one_sided, a_scale, units, chunks_per_unit};
+                              buckets, order, batch, st, one_sided, a_scale, units, chunks_per_unit, opt.xcd_map != 0};
     switch (hpw) {
         case 1: return launch_filtered<1>(args);
         case 2: return launch_filtered<2>(args);

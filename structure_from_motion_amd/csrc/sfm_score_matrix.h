@@ -27,12 +27,23 @@
 // hypothesis: the largest entry in [2^10, 2^11)); the dB chain (bf16: fp32's range) carries s_p^2 and s_h^2, so the compare
 // r''^2 > dB'' is the unscaled one.
 //
-// Bound (in scaled units).  x = hi + mid + res, |res| <= 2^-22 |x| (fp16 subnormals are not flushed by the matrix unit —
-// tools/micro/mfma_bf16_filter.hip probes it — and a flush would cost < 2^-23 relative anyway).  Dropped products per term:
-// mid*mid, res*x, x*res <= 3.1 * 2^-22 |m_t E_t|.  Accumulation: every product of two fp16 is exact in fp32; the matrix unit
-// truncates each aligned addend at the unit of the largest one (probe: <= 3.9 * 2^-23 sum |products| observed), bounded here by
-// one ulp of the largest term per addend: 17 * 2^-23 sum |products| per instruction, 34 * 2^-23 for the chain of two.  Together
-//   |r''_mfma - r''| <= delta'' = 5.2e-6 sum_t |E_t| s_h M_t s_p        (M_t: data-set maximum of |m_t|).
+// Bound (in scaled units).  x = hi + mid + res with hi = fp16(x), mid = fp16(x - hi), |x - hi| <= 2^-11 |x|.  A normal mid is
+// rounded relatively, |res| <= 2^-11 |x - hi| <= 2^-22 |x|; a mid below 2^-14 lies on fp16's SUBNORMAL grid of 2^-24 and is
+// rounded absolutely, |res| <= 2^-25 — which is within 2^-22 |x| only for |x| >= 2^-3.  Smaller entries exist: they are the small
+// terms of a pair whose large terms set the power-of-two scale (pixel-unit coordinates spread the nine products over 2^20), and
+// below 2^-14 hi is subnormal too.  So in general
+//   |res| <= max(2^-22 |x|, 2^-25),     |mid| <= 2^-11 |x| + 2^-24
+// (fp16 subnormals are not flushed by the matrix unit — tools/micro/mfma_bf16_filter.hip probes it).  Dropped products per term
+// (x = m_t s_p, y = E_t s_h): mid_x mid_y + res_x y + (hi_x + mid_x) res_y
+//   <= 3.1 * 2^-22 |x y|  +  (2^-25 + 2^-35) (|x| + |y|)  +  2^-48.
+// Accumulation: every product of two fp16 (subnormal or not) is exact in fp32; the matrix unit truncates each aligned addend
+// at the unit of the largest one (probe: <= 3.9 * 2^-23 sum |products| observed), bounded here by one ulp of the largest term per
+// addend: 17 * 2^-23 sum |products| per instruction, 34 * 2^-23 for the chain of two.  Together
+//   |r''_mfma - r''| <= delta'' = 5.2e-6 sum_t |E_t| s_h M_t s_p  +  1.01 * 2^-25 sum_t (M_t s_p + |E_t| s_h)
+// (M_t: data-set maximum of |m_t|).  The second, absolute term was missing until round 4 (round 3's advisor: with coordinates
+// of +-10 000 an emulation of the split saw |error| up to 33 delta'' and true inliers rejected); with it the same emulation stays
+// below 0.6 delta''.  On K-normalised coordinates it adds ~1e-3 to a delta'' of ~20.  tests/test_gpu_parity.py measures the
+// margin per (point, hypothesis) through sfm_debug_matrix_filter.
 // dS: bf16 has 8 significant bits, |bf(x) - x| <= 2^-8 |x|, so |bf(q) bf(g) - q g| <= (2^-7 + 2^-16) |q g|, accumulation 17 * 2^-23:
 // eps = 0.008 times sum |g_k| Q_k (Q_k: data-set maximum of |q_k|) rides with the slack, rounded up, so the accumulated value is an
 // upper bound of the exact (dA + dB) / 4.  (Per-point absolute terms |q_k| eps |g_k| in twelve more slots are tighter — 3.77 instead
@@ -214,7 +225,8 @@ __global__ __launch_bounds__(64) void matrix_prepare_kernel(const Corr* __restri
 // fragments of tier 1 — the scaled fp16 hi / mid split of E for the two r' blocks and the bf16 dB form with its absolute terms
 // and the slack.  One thread per (hypothesis, half).
 __global__ __launch_bounds__(256) void matrix_hypothesis_kernel(const unsigned char* __restrict__ ws, const double* __restrict__ E,
-                                                                int h_count, double a_scale, uint4* __restrict__ hyp_table) {
+                                                                int h_count, double a_scale, uint4* __restrict__ hyp_table,
+                                                                float* __restrict__ bound_out) {
     const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (item >= 2 * (int64_t)h_count) return;
     const int64_t pair = blockIdx.y;
@@ -242,12 +254,15 @@ __global__ __launch_bounds__(256) void matrix_hypothesis_kernel(const unsigned c
     {
         float eh[9], em[9];
         float weighted = 0.f;   // sum_t |E_t| s_h M_t s_p
+        float absolute = 0.f;   // sum_t (M_t s_p + |E_t| s_h): the subnormal part of the fp16 split (header)
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
             split2(e[j] * (double)sh, eh[j], em[j]);
-            weighted += fabsf((float)e[j]) * (1.0f + 1e-6f) * sh * (M[j] * sp);
+            const float ej = fabsf((float)e[j]) * (1.0f + 1e-6f) * sh;
+            weighted += ej * (M[j] * sp);
+            absolute += ej + M[j] * sp;
         }
-        const float delta = 5.2e-6f * weighted * up + poison;
+        const float delta = (5.2e-6f * weighted + 3.0101e-8f * absolute) * up + poison;   // 3.0101e-8 >= 1.01 * 2^-25
         const float slack = (delta * delta) * (float)((1.0 + kKappa) / kKappa) * up + poison;   // in scaled units
         // (dA + dB) / 4 as quadratic forms of b = (xb, yb, 1) and a = (xa, ya, 1): lb = E^T b (columns of E), la = E a (rows)
         const double g[12] = {0.25 * (e[0] * e[0] + e[1] * e[1]), 0.5 * (e[0] * e[3] + e[1] * e[4]), 0.25 * (e[3] * e[3] + e[4] * e[4]),
@@ -283,12 +298,51 @@ __global__ __launch_bounds__(256) void matrix_hypothesis_kernel(const unsigned c
             else if (s == 12) x = armed ? bf_up((slack / (sp * sp) + rounding) * up) : INFINITY;   // the point side carries s_p^2 in this slot
             B2[j] = (__bf16)x;
         }
+        if (bound_out != nullptr && half == 0) {   // diagnostic (sfm_debug_matrix_filter): what the bound of this hypothesis is made of
+            float* b = bound_out + (pair * (int64_t)h_count + h) * 8;
+            b[0] = delta;
+            b[1] = slack;
+            b[2] = sh;
+            b[3] = armed ? 1.0f : 0.0f;
+            b[4] = sp;
+            b[5] = rounding;
+            b[6] = armed ? bf_up((slack / (sp * sp) + rounding) * up) : INFINITY;
+            b[7] = 0.0f;
+        }
     }
 
     uint4* out = hyp_table + item * kBlocks;
     out[0] = __builtin_bit_cast(uint4, B0);
     out[1] = __builtin_bit_cast(uint4, B1);
     out[2] = __builtin_bit_cast(uint4, B2);
+}
+
+// Diagnostic (sfm_debug_matrix_filter; tests/test_gpu_parity.py measures the bound's margin with it): tier 1 of ONE 32 x 32 tile
+// per wave — the three MFMAs of the scoring kernel on the same operand tables, in the same order — with the raw accumulators
+// written out: r_out / d_out [h_count][32 steps] = r'' and the upper bound of dS'' / 4 (slack included) of every (hypothesis, point).
+__global__ __launch_bounds__(64) void matrix_filter_dump_kernel(const uint4* __restrict__ hyp_table, const uint4* __restrict__ table,
+                                                                int steps, int h_count, float* __restrict__ r_out,
+                                                                float* __restrict__ d_out) {
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const int col = lane & 31, half = lane >> 5;
+    const int h = min((int)blockIdx.y * kHyps + col, h_count - 1);
+    const uint4* __restrict__ operands = hyp_table + ((int64_t)h * 2 + half) * kBlocks;
+    const f16x8 B0 = __builtin_bit_cast(f16x8, operands[0]);
+    const f16x8 B1 = __builtin_bit_cast(f16x8, operands[1]);
+    const bf16x8 B2 = __builtin_bit_cast(bf16x8, operands[2]);
+    const uint4* __restrict__ src = table + (size_t)t * kBlocks * 64 + lane;
+    const uint4 A0 = src[0], A1 = src[64], A2 = src[128];
+    float16v r = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, d = r;
+    r = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A0), B0, r, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A2), B2, d, 0, 0, 0);
+    r = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A1), B1, r, 0, 0, 0);
+    if ((int)blockIdx.y * kHyps + col >= h_count) return;
+    const size_t row0 = (size_t)h * ((size_t)steps * kTile) + (size_t)t * kTile + 4 * half;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        r_out[row0 + (j & 3) + 8 * (j >> 2)] = r[j];
+        d_out[row0 + (j & 3) + 8 * (j >> 2)] = d[j];
+    }
 }
 
 // One wave: 32 hypotheses (entries [32 wave, 32 wave + 32) of the processing order) over the steps of one range of the points.
@@ -506,28 +560,10 @@ __global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
         return;
     }
     // range split: publish this range's partial, count in; the range that arrives last adds the partials in range order
-    // (see score_sed_filtered_kernel for the hand-off form)
-    const int64_t hp = sfmws::split_padded(h_count);
-    int32_t* arrivals = reinterpret_cast<int32_t*>(split);
-    int32_t* part_c = arrivals + hp;
-    double* part_a1 = reinterpret_cast<double*>(part_c + sfmws::kSplitMaxUnits * hp);
-    double* part_a2 = part_a1 + sfmws::kSplitMaxUnits * hp;
-    __hip_atomic_store(part_c + unit * hp + h, ck, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(part_a1 + unit * hp + h, s1k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(part_a2 + unit * hp + h, s2k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int arrived = __hip_atomic_fetch_add(arrivals + h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (arrived == units - 1) {
-        int total = 0;
-        double t1 = 0.0, t2 = 0.0;
-        for (int uu = 0; uu < units; ++uu) {
-            const int pc = __hip_atomic_load(part_c + uu * hp + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const double p1 = __hip_atomic_load(part_a1 + uu * hp + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const double p2 = __hip_atomic_load(part_a2 + uu * hp + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            total += pc;
-            t1 = (uu == 0) ? p1 : t1 + p1;
-            t2 = (uu == 0) ? p2 : t2 + p2;
-        }
+    // (sfmws::split_arrive_and_fold: an ACQ_REL arrival at agent scope)
+    int total = ck;
+    double t1 = s1k, t2 = s2k;
+    if (sfmws::split_arrive_and_fold(split, h_count, units, unit, h, total, t1, t2)) {
         cnt[h] = total;
         s1[h] = t1;
         s2[h] = t2;

@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from . import _native, ops
-from ._native import SelectResult, check
+from ._native import ScoreOptions, SelectResult, check  # noqa: F401  (ScoreOptions: re-exported for callers and tests)
 
 F64 = torch.float64
 SELECT_BYTES = C.sizeof(SelectResult)
@@ -191,13 +191,31 @@ def score_workspace(n: int, h_count: int, batch: int, device) -> torch.Tensor:
 
 
 def score_sed(corr: torch.Tensor, E: torch.Tensor, S: torch.Tensor, thr: float, cnt=None, s1=None,
-              s2=None, workspace: Optional[torch.Tensor] = None, exact_only: bool = False):
+              s2=None, workspace: Optional[torch.Tensor] = None, exact_only: bool = False,
+              options: Optional[ScoreOptions] = None):
     """Per-hypothesis (extra-inlier count, sum sed, sum sed^2).  Uses the two-tier kernel (fp32 pre-filter
-    + exact fp64) unless ``exact_only``; both give identical counts / decisions."""
+    + exact fp64) unless ``exact_only``; both give identical counts / decisions.  ``options`` (launch options of the
+    two-tier kernels: which filter kernel, ranges, order ...; ``sfm_score_sed_ex``) default to the process-wide set, which
+    the SFM_SCORE_* variables initialised when the library was loaded."""
     op = ops.load()
     B, N, _ = corr.shape
     H = E.shape[1]
     exact = exact_only or os.environ.get("SFM_SCORE_KERNEL", "filtered") == "exact"
+    if options is not None and not exact:
+        if cnt is None:
+            cnt = torch.empty((B, H), dtype=torch.int32, device=corr.device)
+        if s1 is None:
+            s1 = torch.empty((B, H), dtype=F64, device=corr.device)
+        if s2 is None:
+            s2 = torch.empty((B, H), dtype=F64, device=corr.device)
+        if workspace is None:
+            workspace = score_workspace(N, H, B, corr.device)
+        assert S.dtype == torch.int32 and corr.dtype == F64 and E.dtype == F64
+        with torch.cuda.device(corr.device):
+            check(_native.load().sfm_score_sed_ex(_ptr(corr), N, _ptr(E), _ptr(S), H, B, float(thr), _ptr(cnt), _ptr(s1),
+                                                  _ptr(s2), _ptr(workspace), workspace.numel(), _stream(), C.byref(options)),
+                  "sfm_score_sed_ex")
+        return cnt, s1, s2
     if cnt is None and s1 is None and s2 is None and (exact or workspace is None):
         return op.score_sed(corr, E, S, float(thr), exact)
     if cnt is None:

@@ -954,21 +954,28 @@ def test_graph_replay_equals_eager(dev, n, h):
 # ------------------------------------------------------------------------------------------------------
 # two-tier scoring kernel (fp32 pre-filter + exact fp64) against the all-fp64 kernel
 # ------------------------------------------------------------------------------------------------------
-def _score_both(dev, corr, E, S, thr):
+def _score_both(dev, corr, E, S, thr, options=None):
+    """(all-fp64 kernel, two-tier kernel launched with `options` — sfm_score_sed_ex; None = the library's own rules)."""
     n, h = corr.shape[0], E.shape[0]
     args = (dev.to_device(corr).reshape(1, n, 4), dev.to_device(E.reshape(1, h, 9)),
             dev.to_device(S, torch.int32).reshape(1, h, 8), thr)
     exact = [t.cpu().numpy()[0] for t in dev.score_sed(*args, exact_only=True)]
-    filt = [t.cpu().numpy()[0] for t in dev.score_sed(*args)]
+    filt = [t.cpu().numpy()[0] for t in dev.score_sed(*args, options=options)]
     return exact, filt
 
 
+def _options(**fields):
+    from structure_from_motion_amd._native import ScoreOptions
+
+    return ScoreOptions(**fields)
+
+
 @pytest.fixture(params=["filtered", "matrix"])
-def score_kernel(request, monkeypatch):
+def score_kernel(request):
     """Both two-tier scoring kernels: the VALU filter (score_sed_filtered_kernel) and the matrix-pipe one
-    (score_sed_matrix_kernel, csrc/sfm_score_matrix.h), whatever the library's size rule would pick."""
-    monkeypatch.setenv("SFM_SCORE_MATRIX", "1" if request.param == "matrix" else "0")
-    return request.param
+    (score_sed_matrix_kernel, csrc/sfm_score_matrix.h), whatever the library's size rule would pick — as launch options
+    of the call (sfm_score_options.kernel), not through the process environment."""
+    return _options(kernel=request.param)
 
 
 def _assert_same_scores(exact, filt):
@@ -986,7 +993,7 @@ def test_filtered_score_equals_exact(dev, score_kernel, n, h, thr):
     _, _, _, corr = scene(n)
     S = orc.philox_sample_table(13, 0, h, n)
     E, _, _ = orc.fit_hypotheses(corr, S)
-    exact, filt = _score_both(dev, corr, E, S, thr)
+    exact, filt = _score_both(dev, corr, E, S, thr, score_kernel)
     _assert_same_scores(exact, filt)
     if thr == 1.5e-6:
         cnt_o, s1_o, s2_o = orc.score_hypotheses(corr, E, S, thr)
@@ -995,24 +1002,21 @@ def test_filtered_score_equals_exact(dev, score_kernel, n, h, thr):
 
 
 @pytest.mark.parametrize("hpw", [1, 2, 4, "matrix"])
-def test_filtered_score_every_loop_remainder(dev, monkeypatch, hpw):
-    """Every hypotheses-per-wave variant of the two-tier kernel (forced with SFM_SCORE_HPW: small launches would always
+def test_filtered_score_every_loop_remainder(dev, hpw):
+    """Every hypotheses-per-wave variant of the two-tier kernel (forced with options.hyps_per_wave: small launches would always
     pick one per wave) over point counts that hit each exit of the staged point-load loop — 0, 1, 2, ... full steps of
     128 (the loop is unrolled over 2 or 3 stages), with 0, 1 or 2 tail chunks, full and partial — and hypothesis counts
     that leave slots of the last wave empty.  Counts equal to the all-fp64 kernel's, sums to summation order; a high
     threshold so that the exact tier runs every few steps, a low one so that it almost never does."""
-    if hpw == "matrix":   # the matrix-pipe kernel: steps of 32 points, the last one masked; 32 hypothesis slots per wave
-        monkeypatch.setenv("SFM_SCORE_MATRIX", "1")
-    else:
-        monkeypatch.setenv("SFM_SCORE_MATRIX", "0")
-        monkeypatch.setenv("SFM_SCORE_HPW", str(hpw))
+    # "matrix": the matrix-pipe kernel — steps of 32 points, the last one masked; 32 hypothesis slots per wave
+    options = _options(kernel="matrix") if hpw == "matrix" else _options(kernel="filtered", hyps_per_wave=hpw)
     for n in (8, 31, 32, 33, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 320, 383, 384, 385, 449, 512, 640, 767, 1000):
         _, _, _, corr = scene(n, seed=n)
         for h in (1, 3, 4, 5, 9):
             S = orc.philox_sample_table(n + h, 0, h, n)
             E, _, _ = orc.fit_hypotheses(corr, S)
             for thr in (1.5e-6, 1e-2):
-                exact, filt = _score_both(dev, corr, E, S, thr)
+                exact, filt = _score_both(dev, corr, E, S, thr, options)
                 _assert_same_scores(exact, filt)
 
 
@@ -1024,7 +1028,7 @@ def test_filtered_score_extreme_matrix_scales(dev, score_kernel, scale):
     _, _, _, corr = scene(n)
     S = orc.philox_sample_table(17, 0, h, n)
     E, _, _ = orc.fit_hypotheses(corr, S)
-    exact, filt = _score_both(dev, corr, E * scale, S, 1.5e-6)
+    exact, filt = _score_both(dev, corr, E * scale, S, 1.5e-6, score_kernel)
     _assert_same_scores(exact, filt)
 
 
@@ -1036,7 +1040,7 @@ def test_filtered_score_pixel_units_and_bad_matrices(dev, score_kernel):
     S = orc.philox_sample_table(19, 0, h, n)
     F, _, _ = orc.fit_hypotheses(corr, S)
     for thr in (1.0, 4.0, 1e-2):
-        _assert_same_scores(*_score_both(dev, corr, F, S, thr))
+        _assert_same_scores(*_score_both(dev, corr, F, S, thr, score_kernel))
     bad = F.copy()
     bad[3] = np.nan
     bad[4, 1, 1] = np.nan
@@ -1044,12 +1048,12 @@ def test_filtered_score_pixel_units_and_bad_matrices(dev, score_kernel):
     bad[6] = 0.0
     bad[7, 0, 0] = np.inf
     bad[8] = 1e-200
-    _assert_same_scores(*_score_both(dev, corr, bad, S, 1.0))
+    _assert_same_scores(*_score_both(dev, corr, bad, S, 1.0, score_kernel))
     corr_nan = corr.copy()
     corr_nan[17, 2] = np.nan
     corr_nan[99] = np.inf
     corr_nan[500] = 0.0
-    _assert_same_scores(*_score_both(dev, corr_nan, F, S, 1.0))
+    _assert_same_scores(*_score_both(dev, corr_nan, F, S, 1.0, score_kernel))
 
 
 def test_filtered_score_threshold_ties(dev, score_kernel):
@@ -1063,7 +1067,7 @@ def test_filtered_score_threshold_ties(dev, score_kernel):
     for _ in range(12):
         k, i = rng.integers(0, h), rng.integers(0, n)
         for thr in (sed[k, i], np.nextafter(sed[k, i], 0.0), np.nextafter(sed[k, i], np.inf)):
-            exact, filt = _score_both(dev, corr, E, S, float(thr))
+            exact, filt = _score_both(dev, corr, E, S, float(thr), score_kernel)
             _assert_same_scores(exact, filt)
             cnt_o, _, _ = orc.score_hypotheses(corr, E, S, float(thr))
             np.testing.assert_array_equal(filt[0], cnt_o)
@@ -1077,81 +1081,243 @@ def test_filtered_score_full_size_equals_exact(dev, score_kernel):
     S = dev.sample_philox(5, 0, h, n)
     E, _ = dev.fit_eight_point(corr_d, S)
     exact = dev.score_sed(corr_d, E, S, 1.5e-6, exact_only=True)
-    filt = dev.score_sed(corr_d, E, S, 1.5e-6)
+    filt = dev.score_sed(corr_d, E, S, 1.5e-6, options=score_kernel)
     assert torch.equal(exact[0], filt[0])
     torch.testing.assert_close(filt[1], exact[1], rtol=1e-13, atol=0, equal_nan=True)
     torch.testing.assert_close(filt[2], exact[2], rtol=1e-13, atol=0, equal_nan=True)
 
 
-@pytest.mark.parametrize("split", ["0", "2", "3", "4"])
-@pytest.mark.parametrize("order", ["0", "1"])
-def test_matrix_score_ranges_and_order(dev, monkeypatch, split, order):
+# ---- the matrix-pipe filter's error bound, measured per (point, hypothesis) -------------------------------------------
+def _matrix_filter_dump(dev, corr, E, thr):
+    """sfm_debug_matrix_filter: the raw tier-1 accumulators r'' [h, n] and d'' [h, n] (upper bound of (dA + dB) / 4 plus the
+    slack, scaled) as the three 16-bit matrix instructions produced them, and the per-hypothesis bound record [h, 8]."""
+    import ctypes
+
+    from structure_from_motion_amd import _native
+
+    n, h = corr.shape[0], E.shape[0]
+    n_pad = (n + 31) // 32 * 32
+    corr_d = dev.to_device(corr)
+    E_d = dev.to_device(E.reshape(h, 9))
+    ws = dev.score_workspace(n, h, 1, corr_d.device)
+    r = torch.full((h, n_pad), float("nan"), dtype=torch.float32, device=corr_d.device)
+    d = torch.full((h, n_pad), float("nan"), dtype=torch.float32, device=corr_d.device)
+    bound = torch.zeros((h, 8), dtype=torch.float32, device=corr_d.device)
+    lib = _native.load()
+    _native.check(lib.sfm_debug_matrix_filter(corr_d.data_ptr(), n, E_d.data_ptr(), h, float(thr), ws.data_ptr(), ws.numel(),
+                                              r.data_ptr(), d.data_ptr(), bound.data_ptr(),
+                                              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                  "sfm_debug_matrix_filter")
+    torch.cuda.synchronize()
+    return r.cpu().numpy()[:, :n].astype(np.float64), d.cpu().numpy()[:, :n].astype(np.float64), bound.cpu().numpy().astype(np.float64)
+
+
+def _matrix_filter_margin(dev, corr, E, thr):
+    """What the bound of csrc/sfm_score_matrix.h promises, checked per evaluation against fp64 recomputation from the true
+    operands: (a) |r''_mfma - r''| <= delta'' — returns the worst ratio; (b) the accumulated denominator minus its slack is an
+    upper bound of the exact (dA + dB) / 4 (scaled) — returns the smallest margin in units of the rounding allowance; (c) no
+    pair with sed <= thr in fp64 is rejected.  Disarmed hypotheses (all-zero operands, infinite slack) reject nothing."""
+    r_mfma, d_mfma, bound = _matrix_filter_dump(dev, corr, E, thr)
+    delta, slack, sh, armed, sp, rounding = (bound[:, k] for k in range(6))
+    kappa = 1.0 / 32.0
+    T = thr * (1.0 + 1.0 / 1024.0) * (1.0 + 1e-5)
+    c = (1.0 - 1e-6) / np.sqrt(T * (1.0 + kappa))
+    xa, ya, xb, yb = (corr[:, k].astype(np.longdouble) for k in range(4))
+    one = np.ones_like(xa)
+    cl = np.longdouble(c)
+    m = np.stack([xb * (xa * cl), xb * (ya * cl), xb * cl, yb * (xa * cl), yb * (ya * cl), yb * cl, xa * cl, ya * cl, one * cl])  # [9, n]
+    Ef = E.reshape(len(E), 9).astype(np.longdouble)
+    on = armed > 0
+    assert on.any()
+    r_true = (Ef @ m).astype(np.longdouble) * (sp[:, None] * sh[:, None])
+    err = np.abs(r_mfma - r_true.astype(np.float64))[on]
+    ratio = float(np.max(err / delta[on, None]))
+    # (b) denominators
+    e = E.astype(np.longdouble)
+    la0 = e[:, 0, 0, None] * xa + e[:, 0, 1, None] * ya + e[:, 0, 2, None]
+    la1 = e[:, 1, 0, None] * xa + e[:, 1, 1, None] * ya + e[:, 1, 2, None]
+    lb0 = e[:, 0, 0, None] * xb + e[:, 1, 0, None] * yb + e[:, 2, 0, None]
+    lb1 = e[:, 0, 1, None] * xb + e[:, 1, 1, None] * yb + e[:, 2, 1, None]
+    quarter = ((la0 * la0 + la1 * la1 + lb0 * lb0 + lb1 * lb1) / 4).astype(np.float64) * (sp[:, None] * sh[:, None]) ** 2
+    allowance = (rounding * sp * sp)[:, None]   # what the constant slot adds for the bf16 roundings, scaled like d
+    margin = ((d_mfma - slack[:, None]) - quarter)[on] / allowance[on]
+    # (c) decisions: the kernel rejects iff fma(-r, r, d) < 0 (one rounding: the sign is that of d - r^2)
+    rejected = (d_mfma - r_mfma * r_mfma) < 0.0
+    sed = orc.sed_values(E, corr)
+    with np.errstate(invalid="ignore"):
+        inlier = sed <= thr
+    lost = int(np.count_nonzero(rejected & inlier))
+    assert not rejected[~on].any()
+    return ratio, float(np.min(margin)), lost, float(np.mean(rejected[on])), int(np.count_nonzero(inlier))
+
+
+def _epipolar_scene_wide(n, h, coord, thr, seed):
+    """Pixel-like coordinates up to +-coord, h fundamental matrices F = K^-T [t]x R K^-1 of random poses, and the points of
+    hypothesis i % h moved off their epipolar line until sed = (0.97 .. 1.03) thr: the advisor's failing case for the
+    fp16 split (small terms of a scaled pair land on fp16's subnormal grid)."""
+    rng = np.random.default_rng(seed)
+    f = coord * 1.2
+    K = np.array([[f, 0.0, 0.0], [0.0, f, 0.0], [0.0, 0.0, 1.0]])
+    Ki = np.linalg.inv(K)
+    F = np.empty((h, 3, 3))
+    for k in range(h):
+        w = rng.normal(size=3) * 0.15
+        th = np.linalg.norm(w)
+        W = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+        R = np.eye(3) + np.sin(th) / th * W + (1 - np.cos(th)) / th ** 2 * W @ W
+        t = rng.normal(size=3)
+        t /= np.linalg.norm(t)
+        tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+        Fk = Ki.T @ tx @ R @ Ki
+        F[k] = Fk / Fk[2, 2] if abs(Fk[2, 2]) > 1e-12 * np.abs(Fk).max() else Fk / np.abs(Fk).max()
+    a = rng.uniform(-coord, coord, (n, 2))
+    b = rng.uniform(-coord, coord, (n, 2))
+    for i in range(n):
+        Fk = F[i % h]
+        la = Fk @ np.array([a[i, 0], a[i, 1], 1.0])             # line of a in image b
+        nrm = np.hypot(la[0], la[1])
+        b0 = b[i] - (la[0] * b[i, 0] + la[1] * b[i, 1] + la[2]) / nrm ** 2 * la[:2]   # foot of b on the line
+        target = thr * rng.uniform(0.97, 1.03)
+        dist = 0.0
+        for _ in range(4):
+            bb = b0 + dist * la[:2] / nrm
+            lb = Fk.T @ np.array([bb[0], bb[1], 1.0])
+            dist = np.sqrt(target / (1.0 + nrm ** 2 / (lb[0] ** 2 + lb[1] ** 2)))
+        b[i] = b0 + dist * la[:2] / nrm * (1 if i % 2 else -1)
+    corr = np.ascontiguousarray(np.column_stack([a, b]))
+    return corr, F
+
+
+def test_matrix_filter_error_bound_margin(dev):
+    """not only the outcome of the matrix-pipe filter but the MARGIN of its error bound, per (point,
+    hypothesis), on (i) 10^6 pairs of the bench scene, (ii) pixel-unit coordinates, (iii) wide pixel coordinates with points
+    within 3 % of the threshold (round 3's advisor: the fp16 split's subnormal tail), (iv) crafted cancellation cases.  On
+    every set: |r''_mfma - r''| <= delta'' / 2, the accumulated denominator is an upper bound of the exact one, and no pair
+    with sed <= thr is rejected.  The worst ratios are printed (pytest -s) and recorded in DESIGN.md."""
+    report = []
+
+    def check(name, corr, E, thr, max_ratio=0.5):
+        ratio, margin, lost, rejected, inliers = _matrix_filter_margin(dev, corr, E, thr)
+        report.append(f"{name}: worst |error| / delta'' = {ratio:.3f}, least denominator margin = {margin:.3f} allowances, "
+                      f"{rejected:.3f} of the evaluations rejected, {inliers} true inliers, {lost} of them rejected")
+        assert lost == 0, report[-1]
+        assert ratio <= max_ratio, report[-1]
+        assert margin >= 0.0, report[-1]
+
+    # (i) the bench scene: 1000 points x 1024 fitted hypotheses
+    n, h = 1000, 1024
+    _, _, _, corr = scene(n)
+    S = orc.philox_sample_table(5, 0, h, n)
+    E, _, _ = orc.fit_hypotheses(corr, S)
+    check("bench scene 1000 x 1024, thr 1.5e-6", corr, E, 1.5e-6)
+    check("bench scene 1000 x 1024, thr 1e-3", corr, E, 1e-3)
+    # (ii) pixel units
+    pa, pb, K, _ = scene(3000)
+    pix = orc.pack_correspondences(pa, pb)
+    Sp = orc.philox_sample_table(19, 0, 256, 3000)
+    F, _, _ = orc.fit_hypotheses(pix, Sp)
+    for thr in (1.0, 1e-2, 100.0):
+        check(f"pixel units 3000 x 256, thr {thr:g}", pix, F, thr)
+    # (iii) wide coordinates, points within 3 % of the threshold
+    for coord in (1000.0, 4000.0, 10000.0, 30000.0):
+        for thr in (1e-2, 1.0, 100.0):
+            cw, Fw = _epipolar_scene_wide(4096, 64, coord, thr, seed=int(coord) + int(thr * 100))
+            check(f"coordinates +-{coord:g}, 4096 x 64, thr {thr:g}", cw, Fw, thr)
+    # (iv) crafted: products of alternating sign at the top of the fp16 range; one large + many small addends; mantissas of
+    # all ones (worst case of the hi / mid split); entries 2^-20 .. 1 apart (the subnormal tail)
+    rng = np.random.default_rng(77)
+    n, h = 512, 256
+    ones = 2.0 - 2.0 ** -52
+    pts = np.empty((n, 4))
+    pts[:, :] = rng.choice([1.0, -1.0, ones / 2, -ones / 2, 1.0 - 2.0 ** -12, 1.0 + 2.0 ** -11], size=(n, 4))
+    pts[n // 2:] *= 2.0 ** rng.integers(-10, 1, size=(n - n // 2, 4))
+    Ec = np.empty((h, 3, 3))
+    sign = np.where(np.arange(9) % 2 == 0, 1.0, -1.0).reshape(3, 3)
+    Ec[: h // 4] = sign * (1.0 - 2.0 ** -11 - 2.0 ** -22) * (1.0 + 2.0 ** -30 * rng.integers(0, 8, size=(h // 4, 3, 3)))
+    Ec[h // 4: h // 2] = sign * 2.0 ** rng.integers(-20, 1, size=(h // 4, 3, 3)).astype(np.float64) * ones / 2
+    Ec[h // 2: 3 * h // 4] = rng.choice([1.0, -1.0], size=(h // 4, 3, 3)) * 2.0 ** -12 * rng.uniform(0.5, 1.0, size=(h // 4, 3, 3))
+    Ec[h // 2: 3 * h // 4, 0, 0] = 1.0                                   # one large + eight small
+    Ec[3 * h // 4:] = rng.normal(size=(h - 3 * h // 4, 3, 3)) * 10.0 ** rng.integers(-6, 1, size=(h - 3 * h // 4, 3, 3))
+    for thr in (1e-4, 1.0):
+        check(f"crafted cancellation 512 x 256, thr {thr:g}", pts, Ec, thr)
+    print("\n" + "\n".join(report))
+
+
+@pytest.mark.parametrize("coord", [4000.0, 10000.0, 30000.0])
+@pytest.mark.parametrize("thr", [1e-2, 1.0, 100.0])
+def test_matrix_score_wide_coordinates_near_threshold(dev, coord, thr):
+    """Un-normalised coordinates of +-4000 .. 30 000 with ~94 points per hypothesis placed within 3 % of the threshold: the
+    matrix-pipe kernel's counts equal the all-fp64 kernel's (round 3's advisor found the fp16 split's absolute rounding on
+    the subnormal grid missing from the bound: at +-10 000 an emulation lost 4 % of such inliers)."""
+    corr, F = _epipolar_scene_wide(6016, 64, coord, thr, seed=int(coord) + 7)
+    S = orc.philox_sample_table(3, 0, 64, 6016)
+    exact, filt = _score_both(dev, corr, F, S, thr, _options(kernel="matrix"))
+    _assert_same_scores(exact, filt)
+    assert exact[0].sum() > 1000    # the near-threshold points are there: about half of 6016 lie below the threshold
+
+
+@pytest.mark.parametrize("split", [0, 2, 3, 4])
+@pytest.mark.parametrize("order", [0, 1])
+def test_matrix_score_ranges_and_order(dev, split, order):
     """The matrix-pipe kernel with its points cut into 1..4 ranges (partials published per range, added in range order by the
     range that arrives last) and with / without the heaviest-first order: counts equal to the all-fp64 kernel's, the sums to
     summation order — and the same bits when the launch is repeated (a lane's queue is first-in first-out, so the order in
     which a hypothesis' errors are added does not depend on the hypotheses it shares a wave with)."""
-    monkeypatch.setenv("SFM_SCORE_MATRIX", "1")
-    monkeypatch.setenv("SFM_SCORE_SPLIT", split)
-    monkeypatch.setenv("SFM_SCORE_ORDER", order)
+    options = _options(kernel="matrix", split=split, order=order)
     n, h = 9000, 2500
     _, _, _, corr = scene(n)
     S = orc.philox_sample_table(31, 0, h, n)
     E, _, _ = orc.fit_hypotheses(corr, S)
     for thr in (1.5e-6, 1e-3):
-        exact, filt = _score_both(dev, corr, E, S, thr)
+        exact, filt = _score_both(dev, corr, E, S, thr, options)
         _assert_same_scores(exact, filt)
-        _, again = _score_both(dev, corr, E, S, thr)
+        _, again = _score_both(dev, corr, E, S, thr, options)
         for a, b in zip(filt, again):
             np.testing.assert_array_equal(a.view(np.int64) if a.dtype == np.float64 else a,
                                           b.view(np.int64) if b.dtype == np.float64 else b)
 
 
 @pytest.mark.parametrize("batch,n,h", [(5, 700, 70), (9, 300, 33), (17, 2100, 40), (3, 4099, 300)])
-def test_matrix_score_batches(dev, monkeypatch, batch, n, h):
+def test_matrix_score_batches(dev, batch, n, h):
     """The matrix-pipe kernel on a batch of pairs (blocks of a pair share one L2: groups of eight pairs, the last one
     padded; per-pair maxima, operand tables, cost order): every pair's counts equal the all-fp64 kernel's."""
-    monkeypatch.setenv("SFM_SCORE_MATRIX", "1")
     corr = np.stack([scene(n, seed=40 + b)[3] for b in range(batch)])
     S = np.stack([orc.philox_sample_table(50 + b, 0, h, n) for b in range(batch)])
     E = np.stack([orc.fit_hypotheses(corr[b], S[b])[0] for b in range(batch)])
     args = (dev.to_device(corr), dev.to_device(E.reshape(batch, h, 9)), dev.to_device(S, torch.int32))
     for thr in (1.5e-6, 1e-3):
         exact = [t.cpu().numpy() for t in dev.score_sed(*args, thr, exact_only=True)]
-        filt = [t.cpu().numpy() for t in dev.score_sed(*args, thr)]
+        filt = [t.cpu().numpy() for t in dev.score_sed(*args, thr, options=_options(kernel="matrix"))]
         for b in range(batch):
             _assert_same_scores([x[b] for x in exact], [x[b] for x in filt])
 
 
-def test_matrix_kernel_is_not_used_beyond_65536_points(dev, monkeypatch):
+def test_matrix_kernel_is_not_used_beyond_65536_points(dev):
     """Queue entries keep the step in 16 bits: a pair of more than 65 536 points runs the VALU-filter kernel even when the matrix
-    one is asked for — same bits as with SFM_SCORE_MATRIX=0, counts equal to the all-fp64 kernel's."""
+    one is asked for — same bits as with the VALU-filter kernel asked for, counts equal to the all-fp64 kernel's."""
     n, h = 66_000, 96
     _, _, _, corr = scene(n)
     S = orc.philox_sample_table(3, 0, h, n)
     E, _, _ = orc.fit_hypotheses(corr, S)
-    monkeypatch.setenv("SFM_SCORE_MATRIX", "1")
-    exact, asked = _score_both(dev, corr, E, S, 1.5e-6)
-    monkeypatch.setenv("SFM_SCORE_MATRIX", "0")
-    _, valu = _score_both(dev, corr, E, S, 1.5e-6)
+    exact, asked = _score_both(dev, corr, E, S, 1.5e-6, _options(kernel="matrix"))
+    _, valu = _score_both(dev, corr, E, S, 1.5e-6, _options(kernel="filtered"))
     _assert_same_scores(exact, asked)
     for a, b in zip(asked, valu):
         np.testing.assert_array_equal(a.view(np.int64) if a.dtype == np.float64 else a, b.view(np.int64) if b.dtype == np.float64 else b)
 
 
-def test_score_kernel_size_rule_picks_the_matrix_kernel(dev, monkeypatch):
-    """Left to itself (no SFM_SCORE_MATRIX) a single-pair launch of at least 8192 points, 4096 hypotheses and 5 x 10^8
-    evaluations runs the matrix-pipe kernel: same counts as the all-fp64 kernel, and as the VALU-filter kernel forced with
-    SFM_SCORE_MATRIX=0."""
-    monkeypatch.delenv("SFM_SCORE_MATRIX", raising=False)
+def test_score_kernel_size_rule_picks_the_matrix_kernel(dev):
+    """Left to itself (options.kernel = auto) a single-pair launch of at least 8192 points, 4096 hypotheses and 5 x 10^8
+    evaluations runs the matrix-pipe kernel: same counts as the all-fp64 kernel, and as the VALU-filter kernel forced by
+    its option."""
     n, h = 8200, 62_000
     _, _, _, corr = scene(n)
     corr_d = dev.to_device(corr).reshape(1, n, 4)
     S = dev.sample_philox(7, 0, h, n)
     E, _ = dev.fit_eight_point(corr_d, S)
     exact = dev.score_sed(corr_d, E, S, 1.5e-6, exact_only=True)
-    default = dev.score_sed(corr_d, E, S, 1.5e-6)
-    monkeypatch.setenv("SFM_SCORE_MATRIX", "0")
-    valu = dev.score_sed(corr_d, E, S, 1.5e-6)
+    default = dev.score_sed(corr_d, E, S, 1.5e-6, options=_options())
+    valu = dev.score_sed(corr_d, E, S, 1.5e-6, options=_options(kernel="filtered"))
     assert torch.equal(exact[0], default[0]) and torch.equal(exact[0], valu[0])
     torch.testing.assert_close(default[1], exact[1], rtol=1e-13, atol=0, equal_nan=True)
     torch.testing.assert_close(default[2], exact[2], rtol=1e-13, atol=0, equal_nan=True)
@@ -1405,51 +1571,40 @@ def test_filtered_score_randomized_sweep(dev, score_kernel):
         if trial % 7 == 0:
             corr[:, :] *= 50.0  # far outside the normalised range (larger coordinate maxima)
         thr = float(10.0 ** rng.uniform(-12, 2)) if trial % 11 else 0.0
-        exact, filt = _score_both(dev, corr, E, S, thr)
+        exact, filt = _score_both(dev, corr, E, S, thr, score_kernel)
         _assert_same_scores(exact, filt)
         total_checked += n * h
     assert total_checked > 5e6
 
 
-def test_two_sided_filter_variant_in_a_fresh_process():
-    """SFM_SCORE_ONE_SIDED=0 (read once per process) selects the two-sided tier-1 test everywhere: same counts as the
-    all-fp64 kernel, checked in a child process so that the switch is actually taken."""
-    import os
-    import subprocess
-    import sys
+def test_two_sided_filter_variant(dev):
+    """options.one_sided = 0 selects the two-sided tier-1 test of the VALU filter everywhere: same counts as the all-fp64
+    kernel (an option of the call since round 4; SFM_SCORE_ONE_SIDED=0 sets it as the process default)."""
+    from structure_from_motion_amd import synthetic
 
-    code = (
-        "import numpy as np, torch, sys\n"
-        "sys.path.insert(0, %r)\n"
-        "from structure_from_motion_amd import device as dev, synthetic\n"
-        "n, h = 9000, 700\n"
-        "pa, pb, K, *_ = synthetic.two_view_scene(n, seed=6)\n"
-        "corr = dev.normalize_correspondences(dev.to_device(pa), dev.to_device(pb), K).reshape(1, n, 4)\n"
-        "S = dev.sample_philox(5, 0, h, n)\n"
-        "E, _ = dev.fit_eight_point(corr, S)\n"
-        "for thr in (1.5e-6, 1e-9, 0.0, 3e-4):\n"
-        "    a = dev.score_sed(corr, E, S, thr, exact_only=True)\n"
-        "    b = dev.score_sed(corr, E, S, thr)\n"
-        "    assert torch.equal(a[0], b[0]), thr\n"
-        "    assert torch.allclose(a[1], b[1], rtol=1e-12, atol=0, equal_nan=True)\n"
-        "print('two-sided ok')\n"
-    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SFM_SCORE_ONE_SIDED="0")
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0 and "two-sided ok" in out.stdout, out.stderr[-2000:]
+    n, h = 9000, 700
+    pa, pb, K, *_ = synthetic.two_view_scene(n, seed=6)
+    corr = dev.normalize_correspondences(dev.to_device(pa), dev.to_device(pb), K).reshape(1, n, 4)
+    S = dev.sample_philox(5, 0, h, n)
+    E, _ = dev.fit_eight_point(corr, S)
+    for thr in (1.5e-6, 1e-9, 0.0, 3e-4):
+        a = dev.score_sed(corr, E, S, thr, exact_only=True)
+        b = dev.score_sed(corr, E, S, thr, options=_options(kernel="filtered", one_sided=0))
+        assert torch.equal(a[0], b[0]), thr
+        assert torch.allclose(a[1], b[1], rtol=1e-12, atol=0, equal_nan=True)
 
 
-@pytest.mark.parametrize("order", ["1", "0"])
-def test_score_hypothesis_ordering_does_not_change_results(dev, monkeypatch, order):
+@pytest.mark.parametrize("order", [1, 0])
+def test_score_hypothesis_ordering_does_not_change_results(dev, order):
     """The longest-first processing order (forced on / off) only affects speed: identical outputs on odd sizes,
     tiny hypothesis counts and batches."""
-    monkeypatch.setenv("SFM_SCORE_ORDER", order)
+    options = _options(order=order)
     rng = np.random.default_rng(3)
     for n, h in [(64, 1), (100, 3), (999, 5), (2000, 4), (4099, 130), (300, 257)]:
         _, _, _, corr = scene(n)
         S = orc.philox_sample_table(31, 0, h, n)
         E, _, _ = orc.fit_hypotheses(corr, S)
-        exact, filt = _score_both(dev, corr, E, S, 1.5e-6)
+        exact, filt = _score_both(dev, corr, E, S, 1.5e-6, options)
         _assert_same_scores(exact, filt)
         cnt_o, _, s2_o = orc.score_hypotheses(corr, E, S, 1.5e-6)
         np.testing.assert_array_equal(filt[0], cnt_o)
@@ -1459,7 +1614,7 @@ def test_score_hypothesis_ordering_does_not_change_results(dev, monkeypatch, ord
     S_all = np.stack([orc.philox_sample_table(70 + b, 0, h, n) for b in range(B)])
     E_all = np.stack([orc.fit_hypotheses(corr_all[b], S_all[b])[0] for b in range(B)])
     cnt, s1, s2 = dev.score_sed(dev.to_device(corr_all), dev.to_device(E_all.reshape(B, h, 9)),
-                                dev.to_device(S_all, torch.int32), 1.5e-6)
+                                dev.to_device(S_all, torch.int32), 1.5e-6, options=options)
     for b in range(B):
         cnt_o, s1_o, s2_o = orc.score_hypotheses(corr_all[b], E_all[b], S_all[b], 1.5e-6)
         np.testing.assert_array_equal(cnt.cpu().numpy()[b], cnt_o)

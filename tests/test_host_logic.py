@@ -47,21 +47,68 @@ def test_score_workspace_holds_every_region(native_lib):
     assert size(-1, 5, 1) == -1 and size(5, -1, 1) == -1 and size(5, 5, -1) == -1
 
 
-def test_score_kernel_choice_rule(native_lib, monkeypatch):
-    """sfm_score_kernel_choice: 2 = the matrix-pipe kernel — single pairs from 8192 points x 4096 hypotheses x 5e8 evaluations,
+def test_score_kernel_choice_rule(native_lib):
+    """sfm_score_kernel_choice_ex: 2 = the matrix-pipe kernel — single pairs from 8192 points x 4096 hypotheses x 5e8 evaluations,
     batches from 8192 x 1024 per pair with 6144 waves and 5e8 evaluations over the batch, never beyond 65 536 points;
-    SFM_SCORE_MATRIX=1 / 0 forces it on (where it applies) / off."""
-    choice = native_lib.sfm_score_kernel_choice
-    monkeypatch.delenv("SFM_SCORE_MATRIX", raising=False)
+    options.kernel forces it on (where it applies) / off."""
+    from structure_from_motion_amd import _native
+
+    auto, valu, matrix = (C.byref(_native.ScoreOptions(kernel=k)) for k in ("auto", "filtered", "matrix"))
+
+    def choice(n, h, b, options=auto):
+        return native_lib.sfm_score_kernel_choice_ex(n, h, b, options)
+
     assert choice(50_000, 100_000, 1) == 2 and choice(50_000, 125_000, 1) == 2 and choice(50_000, 10_000, 1) == 2
     assert choice(5_000, 10_000, 1) == 1 and choice(16_000, 16_000, 1) == 1 and choice(8_191, 1_000_000, 1) == 1
     assert choice(70_000, 100_000, 1) == 1
     assert choice(10_000, 2_000, 256) == 2 and choice(10_000, 2_000, 16) == 1 and choice(4_000, 2_000, 256) == 1
-    monkeypatch.setenv("SFM_SCORE_MATRIX", "0")
-    assert choice(50_000, 100_000, 1) == 1
-    monkeypatch.setenv("SFM_SCORE_MATRIX", "1")
-    assert choice(300, 64, 1) == 2 and choice(70_000, 100_000, 1) == 1
+    assert choice(50_000, 100_000, 1, valu) == 1
+    assert choice(300, 64, 1, matrix) == 2 and choice(70_000, 100_000, 1, matrix) == 1
     assert choice(-1, 5, 1) == -1
+    bad = _native.ScoreOptions(kernel=7)
+    assert choice(300, 64, 1, C.byref(bad)) == -1
+
+
+def test_score_options_are_set_by_the_caller_not_read_from_the_environment(native_lib, monkeypatch):
+    """The library never calls getenv for its launch options: the package translates SFM_SCORE_* once into
+    a ScoreOptions (`_native.score_options_from_env`) and hands it over with sfm_score_set_default_options; calls that pass
+    NULL options use that set, calls that pass options ignore it; changing the environment afterwards changes nothing."""
+    from structure_from_motion_amd import _native
+
+    from_env = _native.score_options_from_env
+    fields = [f[0] for f in _native.ScoreOptions._fields_]
+
+    def values(o):
+        return [getattr(o, f) for f in fields]
+
+    assert values(from_env({})) == [0, 0, -1, -1, -1, -1, -1, 0] == values(_native.ScoreOptions())
+    env = {"SFM_SCORE_MATRIX": "1", "SFM_SCORE_HPW": "2", "SFM_SCORE_SPLIT": "3", "SFM_SCORE_ORDER": "0",
+           "SFM_SCORE_ONE_SIDED": "0", "SFM_SCORE_XCD": "0", "SFM_SCORE_SYNC": "4"}
+    assert values(from_env(env)) == [2, 2, 3, 0, 0, 0, 4, 0]
+    assert values(from_env({"SFM_SCORE_MATRIX": "0", "SFM_SCORE_HPW": "3", "SFM_SCORE_SPLIT": "x"})) == [1, 0, -1, -1, -1, -1, -1, 0]
+    assert C.sizeof(_native.ScoreOptions) == 32
+    before = _native.ScoreOptions()
+    assert native_lib.sfm_score_get_default_options(C.byref(before)) == 0
+    try:
+        monkeypatch.setenv("SFM_SCORE_MATRIX", "0")                      # ignored: the library does not look
+        if before.kernel == 0:
+            assert native_lib.sfm_score_kernel_choice(50_000, 100_000, 1) == 2
+        forced = _native.ScoreOptions(kernel="filtered")
+        assert native_lib.sfm_score_set_default_options(C.byref(forced)) == 0
+        assert native_lib.sfm_score_kernel_choice(50_000, 100_000, 1) == 1
+        assert native_lib.sfm_score_kernel_choice_ex(50_000, 100_000, 1, C.byref(_native.ScoreOptions())) == 2   # per call wins
+        bad = _native.ScoreOptions(split=-5)
+        assert native_lib.sfm_score_set_default_options(C.byref(bad)) == -1
+        assert native_lib.sfm_score_kernel_choice(50_000, 100_000, 1) == 1   # a refused set leaves the old one in place
+        assert native_lib.sfm_score_set_default_options(None) == 0           # NULL: the built-in defaults
+        now = _native.ScoreOptions(kernel=2)
+        native_lib.sfm_score_get_default_options(C.byref(now))
+        assert values(now) == [0, 0, -1, -1, -1, -1, -1, 0]
+    finally:
+        native_lib.sfm_score_set_default_options(C.byref(before))
+    # no getenv left in the scoring translation unit
+    src = open(os.path.join(REPO, "structure_from_motion_amd", "csrc", "sfm_score.hip")).read()
+    assert "getenv" not in src
 
 
 def test_argument_validation_without_gpu(native_lib):

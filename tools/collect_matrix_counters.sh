@@ -11,13 +11,20 @@ cd /tmp
 run() {
     local name=$1; shift
     echo "== $name: $*"
-    # (each pass under its own limit: a counter group the profiler cannot schedule ended in a silent hang once)
+    # Round 3's "silent hang" was the pass `ta2` (gpurun_out/r03m/ta2.log): FOUR counters of the TA block in one pass —
+    # the block has two counter registers per instance on gfx950 — made rocprofiler_create_counter_config fail with
+    # "error code 38: Request exceeds the capabilities of the hardware to collect"; rocprofv3 aborted (signal 6) before the
+    # program ran and then sat in its own finalisation.  No kernel was involved and the GPU was never touched by that pass.
+    # Hence: at most two TA counters (and at most eight SQ counters) per pass below; the limit stays as a guard only.
     timeout -k 10 240 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -o p -- python3 "$REPO/tools/ab_matrix_score.py" > "$OUT/$name.log" 2>&1 || echo "   (pass failed or timed out: see $OUT/$name.log)"
 }
 run sq SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES SQ_BUSY_CYCLES
 run wait SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES
 run tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum
 run ta TA_TA_BUSY_sum TA_BUSY_avr
+run ta_stall TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum
+run ta_waves TA_BUFFER_WAVEFRONTS_sum TA_FLAT_READ_WAVEFRONTS_sum
+run lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS
 run grbm GRBM_GUI_ACTIVE
 cd "$REPO"
 python3 - "$OUT" <<'PY'
