@@ -40,6 +40,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); ~6290 measur
 SIMDS, CLOCK_GHZ = 1024, 2.4   # 256 CUs x 4 SIMD-32; max clock (MI355X_MICROARCH.md chip table)
 CYC_VALU, CYC_F64 = 2.0, 4.0   # spec issue cycles per wave64 instruction: v_fma_f32 2 (SIMD-32); fp64 at half rate
 CYC_MFMA = 8.0                 # vector-issue cycles a 32x32x16 16-bit MFMA holds (MI355X_MICROARCH.md cycle constants); it runs 32 on the matrix pipe
+FP64_PER_EVAL = 59             # fp64 wave-instructions of one exact SED evaluation (sfm::sed_value as compiled: 21 mul, 17 add, 2 IEEE
+                               # divisions of 10, 1 compare — counted in the disassembly of the exact tier; -ffp-contract=off)
 THR, MIN_EXTRA = 1.5e-6, 10    # reference apps/config/config.yaml:6-9 (RMS aggregation)
 C4_TOTAL = 1_000_000           # BASELINE.json configs[3]
 COUNTERS = os.path.join(REPO, "profiles", "score_traffic.json")
@@ -120,10 +122,28 @@ def cpu_baseline(corr: np.ndarray, seed: int, target_seconds: float):
             elapsed = time.perf_counter() - t0
             if elapsed >= target_seconds or done >= 4_000_000:
                 break
+    # (i) of BASELINE.md section 3: the same port in ONE process on one thread, ~2 s of work
+    t0 = time.perf_counter()
+    done1, chunk1 = 0, 1_000
+    while True:
+        S = orc.philox_sample_table(seed, done1, chunk1, n)
+        E, _, _ = orc.fit_hypotheses(corr, S)
+        E = np.ascontiguousarray(E.reshape(chunk1, 9))
+        cnt, s1, s2 = np.zeros(chunk1, dtype=np.int32), np.zeros(chunk1), np.zeros(chunk1)
+        lib.sfm_oracle_score(corr.ctypes.data, n, E.ctypes.data, S.ctypes.data, chunk1, THR, cnt.ctypes.data,
+                             s1.ctypes.data, s2.ctypes.data, 1)
+        orc.select_best(orc.aggregate(cnt, s1, s2, orc.RMS), cnt, MIN_EXTRA)
+        done1 += chunk1
+        elapsed1 = time.perf_counter() - t0
+        if elapsed1 >= 2.0:
+            break
+    single = {"value": n * done1 / elapsed1, "cores": 1,
+              "sample": f"{done1} hypotheses x {n} matches in {elapsed1:.1f} s: one process, one thread (numpy fit, C scoring loop)"}
     return {
         "value": n * done / elapsed,
         "unit": "correspondence-evals/s",
         "cores": used,
+        "single_thread": single,
         "kind": "port",
         "score_leg_value": n * done / legs["score"] if legs["score"] > 0 else None,
         "seconds": {k: round(v, 3) for k, v in legs.items()},
@@ -155,7 +175,22 @@ def load_counters(n, h):
     return rec, rec.get("source_sha") != build.score_source_sha()
 
 
-def roofline(n, h, kernel_ms, call_ms, variant):
+def fp64_floor(exact_evals, kernel_ms):
+    """The part of the scoring kernel no filter can remove: every true inlier (and every sample point) must go through the
+    fp64 routine.  exact_evals x FP64_PER_EVAL wave-instructions / 64 lanes at the spec fp64 rate (4 cycles per wave64
+    instruction) on 1024 SIMDs at 2.4 GHz — a floor in ms, and the share of the measured kernel time it explains."""
+    if not exact_evals or not kernel_ms:
+        return None
+    cycles = float(exact_evals) / 64.0 * FP64_PER_EVAL * CYC_F64
+    floor_ms = cycles / SIMDS / (CLOCK_GHZ * 1e9) * 1e3
+    return {"exact_evaluations": int(exact_evals), "fp64_insts_per_evaluation": FP64_PER_EVAL, "cycles_per_inst": CYC_F64,
+            "floor_ms": floor_ms, "frac_of_kernel": floor_ms / kernel_ms,
+            "note": "true inliers + sample points of this run (sum of cnt + 8 per hypothesis) x fp64 wave-instructions per "
+                    "evaluation x 4 cycles / (64 lanes x 1024 SIMDs x 2.4 GHz): what the kernel would take if it did nothing "
+                    "but the unavoidable fp64 evaluations at full lane utilisation"}
+
+
+def roofline(n, h, kernel_ms, call_ms, variant, exact_evals=None):
     evals = float(n) * float(h)
     if not kernel_ms or kernel_ms <= 0:   # nothing was timed (--steps 0)
         return {"bound": "valu-issue", "kernel_ms": None, "achieved": None, "peak": SIMDS * CLOCK_GHZ, "frac": None,
@@ -176,9 +211,12 @@ def roofline(n, h, kernel_ms, call_ms, variant):
                                     "correspondence set is L2-resident: not a bound for this kernel"},
         "hbm_physical": None,
         "counters_stale": stale,
-        "note": "frac = (VALU wave-instructions per launch x spec issue cycles: 2 per wave64 instruction, 4 per fp64 "
+        "fp64_floor": fp64_floor(exact_evals, kernel_ms),
+        "note": "frac = issue-slot utilisation of the EXECUTED instruction stream (not a bound: a fatter kernel scores "
+                "higher): (VALU wave-instructions per launch x spec issue cycles: 2 per wave64 instruction, 4 per fp64 "
                 "one, 8 of vector issue per 16-bit MFMA) / (1024 SIMDs x 2.4 GHz x kernel time by HIP events around the "
-                "kernel); counters from profiles/score_traffic.json (rocprofv3 --pmc, separate passes)",
+                "kernel); counters from profiles/score_traffic.json (rocprofv3 --pmc, separate passes).  fp64_floor is the "
+                "bound: the irreducible fp64 work of this run's true inliers",
     }
     if rec is None or variant != "filtered":
         return out
@@ -248,6 +286,19 @@ def api_timings(device_mod):
                     max_iterations=h)
                 times.append((time.perf_counter() - t0) * 1e3)
             out[name] = {"ms": min(times[1:]), "first_call_ms": times[0], "inliers": len(pairs)}
+        # the DEFAULT call at C3: exact random.shuffle replay — O(H x N) Mersenne-Twister draws on the host, like the
+        # reference's own sampling (ransac.py:62); one call, no warm-up repeat (it takes seconds)
+        os.environ["SFM_SAMPLER"] = "pyshuffle"
+        random.seed(5)
+        t0 = time.perf_counter()
+        E, pairs = estimate_essential_mat_with_ransac(
+            K, features_a=fa, features_b=fb, matches=matches, sed_inlier_threshold=THR,
+            error_aggregation_method=ErrorAggregationMethod.RMS, min_num_extra_inliers=MIN_EXTRA, max_iterations=h)
+        ms = (time.perf_counter() - t0) * 1e3
+        out["c3_50000x100000_pyshuffle"] = {"ms": ms, "calls": 1, "inliers": len(pairs),
+                                            "ns_per_element_and_iteration": ms * 1e6 / (float(n) * float(h)),
+                                            "note": "default sampler: the reference's cumulative random.shuffle stream, "
+                                                    "replayed bit-exactly on the host (csrc/pyshuffle.cpp)"}
     finally:
         for k, v in saved.items():
             if v is None:
@@ -273,6 +324,49 @@ def other_configs(torch, device, distributed, synthetic, agg):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / reps
 
+    def scoring_kernel_ms(fn):
+        """One more invocation of `fn` with its scoring kernel bracketed by HIP events recorded inside the library,
+        immediately around that kernel on its launch stream (sfm_score_set_timing_events)."""
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        b.record()
+        torch.cuda.synchronize()
+        times = []
+        for rep in range(3):
+            device.score_timing_events(a, b)
+            fn(rep)
+            device.score_timing_events(None, None)
+            torch.cuda.synchronize()
+            times.append(a.elapsed_time(b))
+        return float(np.median(times))
+
+    def config_roofline(name, n, h, batch, kernel_ms, exact_evals):
+        """Roofline block of one of the other configurations: the fp64 floor from the run's own inlier count, and — when
+        profiles/<name>_counters.json (tools/collect_config_counters.sh) holds the kernel's PMC record — the issue-slot
+        utilisation and HBM traffic priced like the headline's."""
+        block = {"kernel_ms": kernel_ms, "fp64_floor": fp64_floor(exact_evals, kernel_ms),
+                 "hbm_algorithmic_frac": (float(n) * h * batch * BYTES_PER_EVAL / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                          if kernel_ms else None)}
+        try:
+            rec = json.load(open(os.path.join(REPO, "profiles", name + "_counters.json")))
+        except (OSError, ValueError):
+            return block
+        c = rec.get("counters", {})
+        if rec.get("matches") != n or rec.get("hypotheses") != h or rec.get("batch", 1) != batch or "SQ_INSTS_VALU" not in c:
+            return block
+        from structure_from_motion_amd import build
+
+        f64 = sum(c.get(k, 0.0) for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64",
+                                          "SQ_INSTS_VALU_TRANS_F64"))
+        cycles = (c["SQ_INSTS_VALU"] - f64) * CYC_VALU + f64 * CYC_F64 + c.get("SQ_INSTS_MFMA", 0.0) * CYC_MFMA
+        block.update({"bound": "valu-issue", "frac": cycles / SIMDS / (CLOCK_GHZ * 1e9) / (kernel_ms * 1e-3) if kernel_ms else None,
+                      "valu_insts_per_launch": c["SQ_INSTS_VALU"], "fp64_insts": f64, "mfma_insts": c.get("SQ_INSTS_MFMA"),
+                      "traffic": ((2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 if "FETCH_SIZE" in c and "WRITE_SIZE" in c else None),
+                      "counters_stale": rec.get("source_sha") != build.score_source_sha(),
+                      "counters_from": {k: rec.get(k) for k in ("git", "source_sha", "collected", "kernel")}})
+        return block
+
+    lib = _native_lib()
     out = {}
     # C2: median over 10 groups of 20 passes
     n, h = 5_000, 10_000
@@ -283,8 +377,12 @@ def other_configs(torch, device, distributed, synthetic, agg):
     groups = [wall(lambda r, g=g: eng.step(1000 + 20 * g + r), 20) for g in range(10)]
     us = float(np.median(groups)) * 1e6
     res = eng.outcome()
+    k_ms = scoring_kernel_ms(lambda r: eng.step(2000 + r))
+    exact = int(eng.ws.cnt.sum().item()) + 8 * h
     out["c2_5000x10000"] = {"pass_us": us, "evals_per_s": n * h / us * 1e6, "passes": 200, "best_h": res.best_h,
-                            "inliers": int((res.mask != 0).sum())}
+                            "inliers": int((res.mask != 0).sum()),
+                            "kernel": "score_sed_filtered_kernel (fused small pass, one hypothesis per wave)",
+                            "roofline": config_roofline("c2", n, h, 1, k_ms, exact)}
     # C4 per-rank share
     n, total, world = 50_000, C4_TOTAL, 8
     pa, pb, K, *_ = synthetic.two_view_scene(n, seed=6)
@@ -292,8 +390,13 @@ def other_configs(torch, device, distributed, synthetic, agg):
     eng = distributed.ShardedRansac(corr, None, THR, MIN_EXTRA, agg, rank=0, world=world, total_hypotheses=total)
     wall(lambda r: eng.step_local(50 + r), 3)
     sec = wall(lambda r: eng.step_local(1000 + r), 10)
+    k_ms = scoring_kernel_ms(lambda r: eng.step_local(2000 + r))
+    exact = int(eng.ws.cnt.sum().item()) + 8 * eng.h
     out["c4_shard_125000x50000"] = {"ms": sec * 1e3, "evals_per_s": n * eng.h / sec,
-                                    "note": "rank 0 of 8: local pass over its 125 000 hypotheses of the 1 M stream"}
+                                    "note": "rank 0 of 8: local pass over its 125 000 hypotheses of the 1 M stream",
+                                    "kernel": ("score_sed_matrix_kernel" if lib.sfm_score_kernel_choice(n, eng.h, 1) == 2
+                                               else "score_sed_filtered_kernel"),
+                                    "roofline": config_roofline("c4", n, eng.h, 1, k_ms, exact)}
     del eng
     # C5
     B, n, h = 256, 10_000, 2_000
@@ -305,11 +408,22 @@ def other_configs(torch, device, distributed, synthetic, agg):
     wall(run, 2)
     sec = wall(run, 5)
     ok = sum(r.status == batched.OK for r in pipe.results())
+    k_ms = scoring_kernel_ms(lambda r: run(100 + r))
+    exact = int(pipe.ws.cnt.sum().item()) + 8 * h * B
     out["c5_256x10000x2000"] = {"batch_ms": sec * 1e3, "evals_per_s": B * n * h / sec, "pairs_per_s": B / sec,
-                                "pairs_ok": ok, "note": "E estimation + pose vote + triangulation, one enqueue"}
+                                "pairs_ok": ok, "note": "E estimation + pose vote + triangulation, one enqueue",
+                                "kernel": ("score_sed_matrix_kernel" if lib.sfm_score_kernel_choice(n, h, B) == 2
+                                           else "score_sed_filtered_kernel"),
+                                "roofline": config_roofline("c5", n, h, B, k_ms, exact)}
     del pipe
     torch.cuda.empty_cache()
     return out
+
+
+def _native_lib():
+    from structure_from_motion_amd import _native
+
+    return _native.load()
 
 
 def self_launch(args) -> int:
@@ -432,14 +546,12 @@ def main():
         # the same pass with each scoring kernel, 3 steps each: the all-fp64 kernel (every evaluation in fp64) and
         # the default two-tier kernel (conservative fp32 reject filter + the same fp64 routine for the survivors)
         variants = {}
-        # and the two-tier kernel with tier 1 on the matrix pipe (the default from 65 536 hypotheses on)
-        saved_matrix = os.environ.get("SFM_SCORE_MATRIX")
-        for name, env, matrix in (("exact_f64", "exact", None), ("filtered", "filtered", "0"), ("matrix", "filtered", "1")):
+        # and the two-tier kernel with tier 1 on the matrix pipe (the default of this workload); the kernel is chosen through
+        # the library's process-wide launch options (sfm_score_set_default_options), which are put back afterwards
+        saved_options = device.default_score_options()
+        for name, env, kernel in (("exact_f64", "exact", None), ("filtered", "filtered", "filtered"), ("matrix", "filtered", "matrix")):
             os.environ["SFM_SCORE_KERNEL"] = env
-            if matrix is None:
-                os.environ.pop("SFM_SCORE_MATRIX", None)
-            else:
-                os.environ["SFM_SCORE_MATRIX"] = matrix
+            device.set_default_score_options(saved_options if kernel is None else device.ScoreOptions(kernel=kernel))
             engine.step(args.seed + 77)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -450,10 +562,7 @@ def main():
             variants[name] = {"ms_per_step": wall * 1e3, "value": float(n) * h / wall,
                               "kernel_ms": float(np.mean([a.elapsed_time(b) for a, b in kernel_ev[:3]]))}
         os.environ.pop("SFM_SCORE_KERNEL", None)
-        if saved_matrix is None:
-            os.environ.pop("SFM_SCORE_MATRIX", None)
-        else:
-            os.environ["SFM_SCORE_MATRIX"] = saved_matrix
+        device.set_default_score_options(saved_options)
 
     variant = os.environ.get("SFM_SCORE_KERNEL", "filtered")
     if args.graph:
@@ -481,6 +590,7 @@ def main():
         elapsed = float(tt.cpu()[0])
 
     out = engine.outcome()
+    exact_evals = int(engine.ws.cnt.sum().item()) + 8 * h   # true inliers + sample points of the last step: all must be scored in fp64
     if not args.graph:
         ev = kernel_ev[:args.steps]
         kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else None
@@ -517,7 +627,7 @@ def main():
                 "launch": "hip-graph" if args.graph else "eager",
                 "library": {"abi": _native.ABI_VERSION, "score_source_sha": build.score_source_sha()},
             },
-            "roofline": roofline(n, h, kernel_ms, call_ms, variant),
+            "roofline": roofline(n, h, kernel_ms, call_ms, variant, exact_evals),
             "result": {"best_h": out.best_h, "error": out.error,
                        "inliers": int((out.mask != 0).sum()) if out.mask is not None else 0,
                        "n_flagged": out.n_flagged},

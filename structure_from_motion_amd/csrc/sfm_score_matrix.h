@@ -61,6 +61,9 @@
 #ifndef SFM_MATRIX_POPS
 #define SFM_MATRIX_POPS 2    // points a lane pops per round of the exact tier
 #endif
+#ifndef SFM_MATRIX_ABLATE
+#define SFM_MATRIX_ABLATE 0  // measurement builds only (WRONG results; tools/r04/ablate.sh): bit 0 no operand refills, bit 1 one matrix
+#endif                       // instruction instead of three, bit 2 one sign test instead of sixteen, bit 3 no queue push
 #ifndef SFM_MATRIX_STATS
 #define SFM_MATRIX_STATS 0   // diagnostic build: rounds of the exact tier, points popped, push-loop iterations (sfm_debug_matrix_stats)
 #endif
@@ -79,14 +82,15 @@ constexpr int kTile = 32;        // points per step
 constexpr int kHyps = 32;        // hypotheses per wave
 constexpr int kBlocks = 3;       // K16 operand blocks per step: r' slots 0..15 and 16..31 (fp16), denominator slots 0..15 (bf16)
 constexpr int kCap = 32;         // entries per lane queue (a power of two: the queue is a ring); an entry is one step's survivors
-constexpr int kHigh = kCap - 4;  // a step pushes at most one entry per lane: rounds start when a queue holds this many ...
+constexpr int kHigh = kCap - 4;  // a step pushes at most one entry per lane: rounds start when a queue holds this many (checked once per group of steps) ...
 constexpr int kLow = 8;          // ... and stop when every queue is down to this
 constexpr double kKappa = 1.0 / 32.0;
 constexpr int kPops = SFM_MATRIX_POPS;
 #ifndef SFM_MATRIX_AHEAD
 #define SFM_MATRIX_AHEAD 1
 #endif
-constexpr int kAhead = SFM_MATRIX_AHEAD;   // steps of operand loads in flight
+static_assert(SFM_MATRIX_AHEAD >= 1 && kHigh + SFM_MATRIX_AHEAD <= kCap, "a group of kAhead + 1 steps must fit behind kHigh - 1 entries");
+constexpr int kAhead = SFM_MATRIX_AHEAD;   // steps of operand loads in flight behind the one being processed (register stages: kAhead + 1)
 #ifndef SFM_MATRIX_ESTIMATE_STEPS
 #define SFM_MATRIX_ESTIMATE_STEPS 128
 #endif
@@ -461,54 +465,94 @@ __global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
     const int steps_total = (int)steps_of(n);
     const int step_begin = units > 1 ? unit * steps_per_unit : 0;
     const int step_end = units > 1 || ESTIMATE ? min(step_begin + steps_per_unit, steps_total) : steps_total;
+    // rows of the LAST step that exist when the point count is no multiple of 32 (bit 15 - j: register j), computed once: inside
+    // the loop the sixteen comparisons cost 25 VGPRs of hoisted row offsets and bit constants — the registers a second step of
+    // operand loads in flight needs
+    unsigned tail_keep = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        tail_keep |= ((steps_total - 1) * kTile + (j & 3) + 8 * (j >> 2) + 4 * half < n) ? (1u << (15 - j)) : 0u;
     unsigned survivors = 0;   // ESTIMATE
     if (step_begin < step_end) {
         const uint4* __restrict__ src = table + lane;
-        // operand loads run kAhead steps ahead of the step being processed (register stages shifted down once per step)
-        uint4 A[kAhead + 1][kBlocks];
+        // Operand loads run kStages steps ahead of the step being processed.  The stages ROTATE — the step loop is unrolled
+        // kStages times and stage s is refilled (with the operands of step t + kStages) right behind the three matrix
+        // instructions that consumed it — so no register is ever copied: rounds 3's form shifted the stages down once per
+        // step, and a copy out of a register a load is still writing makes the wave wait for ALL its loads (s_waitcnt
+        // vmcnt(0) at the top of every step), i.e. the loop ran one memory latency per step whatever the depth — tier 1 of a
+        // light wave took ~450 cycles per step and SIMD against ~220 of issue for that reason.
+        constexpr int kStages = kAhead + 1;
+        uint4 A[kStages][kBlocks];
+        // (the first fill in stage order, oldest first, like every refill: the wait in front of stage 0 at the loop's head is ONE
+        // instruction for the entry and the back edge — entered with stage 0's loads as the youngest it would be vmcnt(0) forever)
 #pragma unroll
-        for (int a = 0; a < kAhead; ++a)
+        for (int a = 0; a < kStages; ++a) {
 #pragma unroll
             for (int b = 0; b < kBlocks; ++b) A[a][b] = src[((size_t)min(step_begin + a, step_end - 1) * kBlocks + b) * 64];
-        for (int t = step_begin; t < step_end; ++t) {
-            const uint4* nxt = src + (size_t)min(t + kAhead, step_end - 1) * kBlocks * 64;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        int t0 = step_begin;
+        while (t0 < step_end) {
+         bool queue_full = false;
+         do {   // the hot loop: groups of kStages steps until a queue is full (or the range ends)
 #pragma unroll
-            for (int b = 0; b < kBlocks; ++b) A[kAhead][b] = nxt[b * 64];
+          for (int stage = 0; stage < kStages; ++stage) {
+            const int t = t0 + stage;   // (steps past the range's end — at most kStages - 1 per wave — run on the last step's operands and keep nothing)
             float16v r = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, d = r;
-            r = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[0][0]), B0, r, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[0][2]), B2, d, 0, 0, 0);
-            r = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[0][1]), B1, r, 0, 0, 0);
+            r = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[stage][0]), B0, r, 0, 0, 0);
+#if !(SFM_MATRIX_ABLATE & 2)
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[stage][2]), B2, d, 0, 0, 0);
+            r = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[stage][1]), B1, r, 0, 0, 0);
+#endif
             // rejected bits, register 0 ending up in bit 15: the sign of dB - r^2 (one rounding: the sign is exact, and zero
             // — equality — keeps the point) shifted in with an alignbit.  A NaN with its sign set counts as rejected, which is
             // what the exact tier would decide for it (sed = NaN is not <= thr).
             unsigned rejected = 0;
 #pragma unroll
-            for (int j = 0; j < 16; ++j)
+            for (int j = 0; j < ((SFM_MATRIX_ABLATE & 4) ? 1 : 16); ++j)
                 rejected = __builtin_amdgcn_alignbit(rejected, __float_as_uint(__builtin_fmaf(-r[j], r[j], d[j])), 31);
             unsigned keep = ~rejected & 0xffffu;   // bit 15 - j: row (j & 3) + 8 (j >> 2) + 4 half of this step
-            if ((t + 1) * kTile > n) {   // wave-uniform: the last step of a point count that is no multiple of 32
-                unsigned in_range = 0;
+            {
+                // refill this stage.  The loads must stay BEHIND the three matrix instructions that read the stage: hoisted
+                // above the second r' instruction (where instruction selection likes to put them) the load of block 1 needs a
+                // copy of the old block 1, and a copy waits for the loads.  The empty asm makes the address depend on `keep`.
+                // (the OFFSET goes through the asm, not the pointer: a pointer coming out of an asm has lost its address space and
+                // the loads become flat_load, which the compiler can only wait for with vmcnt(0))
+                unsigned offset = (unsigned)min(t + kStages, step_end - 1) * (kBlocks * 64);
+                asm volatile("" : "+v"(offset), "+v"(keep));
+                const uint4* nxt = src + offset;
+#if !(SFM_MATRIX_ABLATE & 1)
 #pragma unroll
-                for (int j = 0; j < 16; ++j)
-                    in_range |= (t * kTile + (j & 3) + 8 * (j >> 2) + 4 * half < n) ? (1u << (15 - j)) : 0u;
-                keep &= in_range;
+                for (int b = 0; b < kBlocks; ++b) A[stage][b] = nxt[b * 64];
+#endif
             }
+            if (t == steps_total - 1) keep &= tail_keep;   // (wave-uniform) the last step of a point count that is no multiple of 32
+            if (t >= step_end) keep = 0u;
             if (ESTIMATE) {
                 survivors += (unsigned)__builtin_popcount(keep);
             } else {
+#if SFM_MATRIX_ABLATE & 8
+                survivors += (unsigned)__builtin_popcount(keep);
+#else
                 if (keep != 0u) {   // push: one entry with this step's survivors
                     my_queue[(tail & (kCap - 1)) * kWave] = ((unsigned)t << 16) | keep;
                     ++tail;
                 }
-                if (__builtin_amdgcn_ballot_w64((int)(tail - head) >= kHigh) != 0ull) {
-                    __builtin_amdgcn_wave_barrier();
-                    do round(); while (__builtin_amdgcn_ballot_w64((int)(tail - head) > kLow) != 0ull);
-                }
+#endif
             }
-#pragma unroll
-            for (int a = 0; a < kAhead; ++a)
-#pragma unroll
-                for (int b = 0; b < kBlocks; ++b) A[a][b] = A[a + 1][b];
+          }
+          t0 += kStages;
+          queue_full = !ESTIMATE && __builtin_amdgcn_ballot_w64((int)(tail - head) >= kHigh) != 0ull;
+         } while (t0 < step_end && !queue_full);
+         // Rounds of the exact tier are looked at once per group of kStages steps, not between its stages, and run OUTSIDE the
+         // hot loop: that loop is then straight-line code whose operand loads the compiler can count (s_waitcnt
+         // vmcnt(3 (kStages - 1)) in front of a stage: the younger stages stay in flight) — with the gathers of a round
+         // between two stages it falls back to vmcnt(0) at the top of every group.  A group pushes at most kStages entries per
+         // lane: kHigh + kStages - 1 <= kCap.  (When rounds happen does not change any sum: a lane's queue is first-in first-out.)
+         if (queue_full) {
+             __builtin_amdgcn_wave_barrier();
+             do round(); while (__builtin_amdgcn_ballot_w64((int)(tail - head) > kLow) != 0ull);
+         }
         }
     }
     if (ESTIMATE) {   // survivors per 1024 points of this hypothesis (both lanes) in sixteenths, at least 1 when there was any
@@ -524,6 +568,9 @@ __global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
     }
     __builtin_amdgcn_wave_barrier();
     while (__builtin_amdgcn_ballot_w64(tail != head || cur != 0u) != 0ull) round();
+#if SFM_MATRIX_ABLATE & 8
+    c += (int)survivors;
+#endif
 #if SFM_MATRIX_STATS
     if (lane == 0) {
         atomicAdd(&g_matrix_stats[0], (unsigned long long)stat_rounds);

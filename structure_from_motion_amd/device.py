@@ -232,6 +232,20 @@ def score_sed(corr: torch.Tensor, E: torch.Tensor, S: torch.Tensor, thr: float, 
     return cnt, s1, s2
 
 
+def default_score_options() -> ScoreOptions:
+    """The process-wide launch options of the scoring kernels (what calls without ``options`` use)."""
+    out = ScoreOptions()
+    check(_native.load().sfm_score_get_default_options(C.byref(out)), "sfm_score_get_default_options")
+    return out
+
+
+def set_default_score_options(options: Optional[ScoreOptions]) -> None:
+    """Replace the process-wide launch options (``None`` = the library's built-in defaults).  The package sets them once
+    from the SFM_SCORE_* variables when the library is loaded; bench.py switches kernels with this for its variants."""
+    check(_native.load().sfm_score_set_default_options(None if options is None else C.byref(options)),
+          "sfm_score_set_default_options")
+
+
 def score_timing_events(before: Optional[torch.cuda.Event], after: Optional[torch.cuda.Event]) -> None:
     """Have the following ``score_sed`` calls record ``before`` / ``after`` immediately around the scoring kernel
     (``sfm_score_set_timing_events``); ``(None, None)`` switches it off.  The events must have been recorded once

@@ -44,15 +44,20 @@ def _distributed(group) -> bool:
     return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
 
 
-def gather_records(record: torch.Tensor, out: Optional[torch.Tensor] = None, group=None) -> torch.Tensor:
+def gather_records(record: torch.Tensor, out: Optional[torch.Tensor] = None, group=None,
+                   force_collective: bool = False) -> torch.Tensor:
     """The ONE collective of a sharded pass.  record: int64 [batch, 5] view of this rank's sfm_select_result
     records -> int64 [world, batch, 5], identical on every rank.  With the "nccl" backend (RCCL) the device tensor
     is gathered in place over xGMI; with "gloo" (CPU tests, or a rehearsal with several ranks sharing one GPU)
-    device tensors are staged through the host."""
-    world = dist.get_world_size(group) if _distributed(group) else 1
+    device tensors are staged through the host.  A world of one copies without a collective unless
+    ``force_collective`` (an initialised process group of one rank: the call RCCL sees at N > 1, executable on one GPU)."""
+    initialised = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if initialised else 1
     if out is None:
         out = torch.empty((world,) + tuple(record.shape), dtype=record.dtype, device=record.device)
-    if world == 1:
+    if force_collective and not initialised:
+        raise RuntimeError("gather_records(force_collective=True) needs an initialised process group")
+    if world == 1 and not force_collective:
         out[0].copy_(record)
         return out
     if record.is_cuda and dist.get_backend(group) == "gloo":
@@ -125,7 +130,7 @@ class ShardedRansac:
 
     def __init__(self, corr: torch.Tensor, hypotheses_per_rank: Optional[int], thr: float, min_extra: float,
                  aggregation: int, rank: int = 0, world: int = 1, group=None,
-                 total_hypotheses: Optional[int] = None):
+                 total_hypotheses: Optional[int] = None, force_exchange: bool = False):
         from . import device
 
         self.device_api = device
@@ -139,9 +144,14 @@ class ShardedRansac:
             self.total = hypotheses_per_rank * world
         self.thr, self.min_extra, self.aggregation = thr, min_extra, aggregation
         self.rank, self.world, self.group = rank, world, group
+        # force_exchange: a world of ONE still runs the multi-rank path — global indices from the selection kernel, the
+        # all-gather as a real collective on the device tensor, the fold, the winner re-derived from (seed, h*) — so that the
+        # code RCCL sees at N > 1 can be executed and checked on one GPU (tests/test_gpu_api.py)
+        self.exchange = world > 1 or force_exchange
+        self.force_exchange = force_exchange
         dev = corr.device
         self.ws = device.RansacWorkspace(1, self.n, self.h, dev)  # h == 0 (more ranks than hypotheses) is a valid empty shard
-        if world == 1:  # the local record is the global one: views, no copies, no exchange
+        if not self.exchange:  # the local record is the global one: views, no copies, no exchange
             self.global_record = self.ws.result
             self.global_best = self.ws.result[:, 1]
         else:
@@ -161,7 +171,7 @@ class ShardedRansac:
         """sample -> fit -> score -> select on this rank's shard (+ mask when the winner is local).
         ``seed=None`` reads the seed from ``self.seed_dev`` (the form a HIP graph can replay)."""
         source = (self.seed_dev if seed is None else seed, self.h_begin, 1)  # sampled inside the fit kernel
-        if self.world == 1:
+        if not self.exchange:
             # single GPU: the winner is local — mask straight from the shard's own E / S
             self.ws.run(self.corr, self.thr, self.min_extra, self.aggregation, h_offset=0, with_mask=True,
                         philox=source)
@@ -196,8 +206,9 @@ class ShardedRansac:
 
     def step(self, seed: int) -> None:
         self.step_local(seed)
-        if self.world > 1:
-            gather_records(self.ws.result, self.gathered, self.group)   # the one collective: 40 B per rank
+        if self.exchange:
+            # the one collective: 40 B per rank
+            gather_records(self.ws.result, self.gathered, self.group, force_collective=self.force_exchange)
             self.finish(seed)
 
     def step_local(self, seed: int) -> None:
@@ -240,7 +251,7 @@ class ShardedRansac:
         best = int(rec.best_h)
         if best < 0:
             return ShardedOutcome(-1, float("inf"), None, None, None, n_flagged, first)
-        if self.world == 1:
+        if not self.exchange:
             E = self.ws.E[0, best].cpu().numpy().reshape(3, 3)
             sample = self.ws.S[0, best].cpu().numpy().astype(np.int64)
         else:

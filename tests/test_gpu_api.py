@@ -591,3 +591,57 @@ def test_bench_two_rank_rehearsal(tmp_path):
     # 3000 x 4000 per rank runs as the lean small pass: its scoring launch is bracketed by the events all the same,
     # and there is no separate scoring call to time
     assert line2["roofline"]["kernel_ms"] > 0 and line2["roofline"]["score_call_ms"] is None
+
+
+def test_rccl_exchange_on_one_rank(tmp_path):
+    """The multi-GPU path under the REAL backend, as far as one GPU allows: a child process — started
+    before anything in it touches the GPU — with WORLD_SIZE=1 initialises the "nccl" (= RCCL) process group exactly as
+    bench.py does (`device_id=cuda:0`, HSA_ENABLE_IPC_MODE_LEGACY=0) and runs `ShardedRansac(..., force_exchange=True)`:
+    the selection kernel writes global indices, `dist.all_gather_into_tensor` runs as an RCCL collective on the int64 DEVICE
+    tensor, the records are folded and the winner re-derived from (seed, h*).  Winner, error, E, sample and mask equal the
+    single-GPU engine's bit for bit, over three seeds and with a hypothesis offset.  It cannot measure scaling; it makes sure
+    the first 8-GPU run is not the first time RCCL sees this code."""
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    code = (
+        "import os, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import numpy as np, torch\n"
+        "import torch.distributed as dist\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', device_id=torch.device('cuda', 0))\n"
+        "assert dist.get_backend() == 'nccl' and dist.get_world_size() == 1\n"
+        "from structure_from_motion_amd import device, distributed, synthetic\n"
+        "from structure_from_motion_amd._native import AGG_RMS\n"
+        "n, h = 3000, 6000\n"
+        "pa, pb, K, *_ = synthetic.two_view_scene(n, seed=6)\n"
+        "corr = device.normalize_correspondences(device.to_device(pa), device.to_device(pb), K)\n"
+        "plain = distributed.ShardedRansac(corr, None, 1.5e-6, 10, AGG_RMS, 0, 1, total_hypotheses=h)\n"
+        "forced = distributed.ShardedRansac(corr, None, 1.5e-6, 10, AGG_RMS, 0, 1, total_hypotheses=h, force_exchange=True)\n"
+        "assert forced.gathered.is_cuda and forced.gathered.dtype == torch.int64 and forced.gathered.shape == (1, 1, 5)\n"
+        "for seed in (5, 6, 2**63 + 11):\n"
+        "    plain.step(seed); a = plain.outcome()\n"
+        "    forced.gathered.fill_(-7)\n"
+        "    forced.step(seed); b = forced.outcome()\n"
+        "    assert torch.equal(forced.gathered[0], forced.ws.result), 'the collective did not deliver the record'\n"
+        "    assert a.best_h == b.best_h >= 0 and a.error == b.error, (a.best_h, b.best_h)\n"
+        "    assert np.array_equal(a.E, b.E) and np.array_equal(a.sample, b.sample) and np.array_equal(a.mask, b.mask)\n"
+        "# a rank that does not own hypothesis 0: global indices through the same exchange\n"
+        "late = distributed.ShardedRansac(corr, h, 1.5e-6, 10, AGG_RMS, rank=3, world=1, force_exchange=True)\n"
+        "late.step(5); c = late.outcome()\n"
+        "assert 3 * h <= c.best_h < 4 * h, c.best_h\n"
+        "dist.barrier()\n"
+        "dist.destroy_process_group()\n"
+        "print('rccl one-rank exchange ok', a.best_h, c.best_h)\n"
+    ) % repo
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=repo)
+    assert out.returncode == 0 and "rccl one-rank exchange ok" in out.stdout, (out.stdout[-500:], out.stderr[-3000:])

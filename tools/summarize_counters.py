@@ -69,10 +69,13 @@ def main():
         counters["profiled_kernel_ms"] = sum(sq_span) / len(sq_span) * 1e-6
     from structure_from_motion_amd import _native, build
 
-    try:
-        git = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=REPO, capture_output=True, text=True).stdout.strip()
-    except OSError:
-        git = ""
+    # the GPU box gets a snapshot without .git: the caller passes the revision (gpurun -- 'SFM_GIT_SHA=$(git rev-parse ...) ...')
+    git = os.environ.get("SFM_GIT_SHA", "")
+    if not git:
+        try:
+            git = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=REPO, capture_output=True, text=True).stdout.strip()
+        except OSError:
+            git = ""
     rec = {
         "kernel": kernel[:120],
         "kernel_short": short,
