@@ -1047,6 +1047,19 @@ bool use_matrix_kernel(int64_t n, int64_t h_count, int64_t batch, const sfm_scor
     return matrix_fits && (matrix_env > 0 || (matrix_env < 0 && matrix_pays));
 }
 
+// compute units of the current device (256 on MI355X): the grid of the persistent-wave launch
+int compute_units() {
+    static std::atomic<int> cached[64];
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 64) return 256;
+    int cus = cached[device].load(std::memory_order_relaxed);
+    if (cus == 0) {
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+        cached[device].store(cus, std::memory_order_relaxed);
+    }
+    return cus;
+}
+
 // Scoring launch with tier 1 on the matrix pipe (sfm_score_matrix.h): one pair, workspace prepared with that kernel's scale.
 int launch_matrix(const FilteredLaunch& a) {
     using namespace matrixscore;
@@ -1056,8 +1069,13 @@ int launch_matrix(const FilteredLaunch& a) {
                        const_cast<uint4*>(table));
     static_assert(kBlocks * 2 * 16 == 96, "sfm_score_ws.h sizes the tables: 3 blocks");
     const uint4* hyp_table = reinterpret_cast<const uint4*>(a.ws + ws_matrix_hyp_offset(a.n, a.h_count, a.batch));
+    unsigned char* fix = a.ws + ws_matrix_fix_offset(a.n, a.h_count, a.batch);   // the sample corrections, per pair
     hipLaunchKernelGGL(matrix_hypothesis_kernel, dim3(grid_for(2 * (int64_t)a.h_count, 256), pairs), dim3(256), 0, a.st, a.ws, a.E,
-                       a.h_count, a.a_scale, const_cast<uint4*>(hyp_table), (float*)nullptr);
+                       a.h_count, a.a_scale, const_cast<uint4*>(hyp_table), (float*)nullptr, a.corr, a.n, a.S, a.thr, fix);
+    // a single pair: persistent waves — as many blocks as the chip holds at once, every wave takes (group of 32 hypotheses,
+    // range) items from a per-XCD counter (see the kernel); the counters were zeroed with the class counters
+    const bool persistent = a.batch == 1;
+    const unsigned resident_blocks = (unsigned)compute_units() * SFM_MATRIX_OCC;
     const int64_t waves = (a.h_count + kHyps - 1) / kHyps;
     const unsigned blocks = grid_for(waves, 256 / kWave);
     // batches: flat grid of 8-pair groups (the kernel's block -> (pair, block) map), `units` range blocks per block of a pair; a
@@ -1074,8 +1092,8 @@ int launch_matrix(const FilteredLaunch& a) {
             hipLaunchKernelGGL(score_split_reset_kernel, dim3(grid_stride(a.h_count, 256, 1024)), dim3(256), 0, a.st, a.cnt,
                                (int64_t)a.h_count);
         hipLaunchKernelGGL(score_sed_matrix_kernel<true>, dim3(flat * (unsigned)e_units), dim3(256), 0, a.st, a.corr, hyp_table, table,
-                           a.n, a.E, a.S, a.h_count, a.thr, (const int32_t*)nullptr, a.cnt, a.s1, a.s2, e_units, e_steps / e_units,
-                           (unsigned char*)nullptr, (int)a.batch, blocks_per_pair);
+                           a.n, a.E, a.h_count, a.thr, (const int32_t*)nullptr, a.cnt, a.s1, a.s2, e_units, e_steps / e_units,
+                           (unsigned char*)nullptr, (const unsigned char*)nullptr, (int)a.batch, blocks_per_pair, (int32_t*)nullptr);
         const dim3 per_hyp(grid_for(a.h_count, 256), pairs);
         hipLaunchKernelGGL(score_class_count_kernel, per_hyp, dim3(256), 0, a.st, a.cnt, a.h_count, a.buckets);
         hipLaunchKernelGGL(score_class_scan_kernel, dim3(pairs), dim3(256), 0, a.st, a.buckets, a.batch);
@@ -1084,17 +1102,18 @@ int launch_matrix(const FilteredLaunch& a) {
         if (rc != SFM_OK) return rc;
         order_arg = a.order;
     }
-    unsigned char* split = nullptr;
-    if (a.units > 1) {
-        split = a.ws + (a.batch > 1 ? ws_batch_split_offset(a.n, a.h_count, a.batch) : ws_split_offset(a.n, a.h_count));
-        hipLaunchKernelGGL(score_split_reset_kernel, dim3(grid_stride(a.h_count, 256, 1024), pairs), dim3(256), 0, a.st,
-                           reinterpret_cast<int32_t*>(split), (int64_t)a.h_count, split_bytes(a.h_count) / 4);
-    }
+    unsigned char* split = nullptr;   // partials of the ranges: [range][hypothesis], folded by matrix_fold_kernel behind the launch
+    if (a.units > 1) split = a.ws + (a.batch > 1 ? ws_batch_split_offset(a.n, a.h_count, a.batch) : ws_split_offset(a.n, a.h_count));
     if (g_event_before) (void)hipEventRecord(g_event_before, a.st);
-    hipLaunchKernelGGL(score_sed_matrix_kernel<false>, dim3(flat * (unsigned)a.units), dim3(256), 0, a.st, a.corr, hyp_table, table, a.n,
-                       a.E, a.S, a.h_count, a.thr, order_arg, a.cnt, a.s1, a.s2, a.units, a.chunks_per_unit, split,
-                       (int)a.batch, blocks_per_pair * a.units);
+    const int64_t item_blocks = (int64_t)flat * a.units;
+    const unsigned grid_blocks = persistent ? (unsigned)std::min<int64_t>(item_blocks, resident_blocks) : (unsigned)item_blocks;
+    hipLaunchKernelGGL(score_sed_matrix_kernel<false>, dim3(grid_blocks), dim3(256), 0, a.st, a.corr, hyp_table, table, a.n,
+                       a.E, a.h_count, a.thr, order_arg, a.cnt, a.s1, a.s2, a.units, a.chunks_per_unit, split, fix,
+                       (int)a.batch, blocks_per_pair * a.units, persistent ? a.buckets + kTicketWords : (int32_t*)nullptr);
     if (g_event_after) (void)hipEventRecord(g_event_after, a.st);
+    if (a.units > 1)
+        hipLaunchKernelGGL(matrix_fold_kernel, dim3(grid_stride(a.h_count, 256, 1024), pairs), dim3(256), 0, a.st, split, fix, a.units,
+                           a.h_count, a.cnt, a.s1, a.s2);
     return check_launch("score_sed_matrix_kernel");
 }
 
@@ -1150,6 +1169,12 @@ extern "C" int sfm_debug_matrix_stats(unsigned long long* out, int reset) {   //
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(matrixscore::g_matrix_stats), 32) != hipSuccess) return -2;
     if (reset && hipMemcpyToSymbol(HIP_SYMBOL(matrixscore::g_matrix_stats), zero, 32) != hipSuccess) return -2;
     return 0;
+}
+#endif
+
+#if SFM_MATRIX_STAMPS
+extern "C" int sfm_debug_read_matrix_stamps(unsigned long long* out, int64_t waves) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(matrixscore::g_matrix_stamps), 64 * (size_t)waves) == hipSuccess ? 0 : -2;
 }
 #endif
 
@@ -1214,7 +1239,7 @@ int sfm_debug_matrix_filter(const double* corr, int64_t n, const double* E, int6
     uint4* hyp_table = reinterpret_cast<uint4*>(ws + ws_matrix_hyp_offset(n, h_count, 1));
     hipLaunchKernelGGL(matrix_prepare_kernel, dim3((unsigned)steps, 1), dim3(64), 0, st, (const Corr*)corr, (int)n, a_scale, ws, table);
     hipLaunchKernelGGL(matrix_hypothesis_kernel, dim3(grid_for(2 * h_count, 256), 1), dim3(256), 0, st, ws, E, (int)h_count, a_scale,
-                       hyp_table, bound_out);
+                       hyp_table, bound_out, (const Corr*)corr, (int)n, (const int32_t*)nullptr, thr, (unsigned char*)nullptr);
     hipLaunchKernelGGL(matrix_filter_dump_kernel, dim3((unsigned)steps, (unsigned)tiles), dim3(64), 0, st, hyp_table, table, steps,
                        (int)h_count, r_out, d_out);
     return check_launch("matrix_filter_dump_kernel");

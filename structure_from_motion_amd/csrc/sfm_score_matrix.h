@@ -63,7 +63,10 @@
 #endif
 #ifndef SFM_MATRIX_ABLATE
 #define SFM_MATRIX_ABLATE 0  // measurement builds only (WRONG results; tools/r04/ablate.sh): bit 0 no operand refills, bit 1 one matrix
-#endif                       // instruction instead of three, bit 2 one sign test instead of sixteen, bit 3 no queue push
+#endif                       // instruction instead of three, bit 2 one sign test instead of sixteen, bit 3 no queue push, bit 4 no fp16 subnormal operands
+#ifndef SFM_MATRIX_E_IN_REGISTERS
+#define SFM_MATRIX_E_IN_REGISTERS 0   // 1: rounds 3's form — E held in 18 VGPRs through the tier-1 loop (A/B)
+#endif
 #ifndef SFM_MATRIX_STATS
 #define SFM_MATRIX_STATS 0   // diagnostic build: rounds of the exact tier, points popped, push-loop iterations (sfm_debug_matrix_stats)
 #endif
@@ -73,6 +76,19 @@ namespace matrixscore {
 #if SFM_MATRIX_STATS
 __device__ unsigned long long g_matrix_stats[4];
 #endif
+#ifndef SFM_MATRIX_STAMPS
+#define SFM_MATRIX_STAMPS 0   // diagnostic build (tools/r04/matrix_timeline.py): s_memrealtime stamps of every wave's phases
+#endif
+#if SFM_MATRIX_STAMPS
+__device__ unsigned long long g_matrix_stamps[8 * 65536];   // begin, operands in, loop done, drained, samples fixed, handed off, hw id, wave
+#define SFM_STAMP(k)                                                                     \
+    do {                                                                                 \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                      \
+        stamp[k] = __builtin_amdgcn_s_memrealtime();                                     \
+    } while (0)
+#else
+#define SFM_STAMP(k) do {} while (0)
+#endif
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -81,7 +97,10 @@ typedef float float16v __attribute__((ext_vector_type(16)));
 constexpr int kTile = 32;        // points per step
 constexpr int kHyps = 32;        // hypotheses per wave
 constexpr int kBlocks = 3;       // K16 operand blocks per step: r' slots 0..15 and 16..31 (fp16), denominator slots 0..15 (bf16)
-constexpr int kCap = 32;         // entries per lane queue (a power of two: the queue is a ring); an entry is one step's survivors
+#ifndef SFM_MATRIX_CAP
+#define SFM_MATRIX_CAP 32
+#endif
+constexpr int kCap = SFM_MATRIX_CAP;   // entries per lane queue (a power of two: the queue is a ring); an entry is one step's survivors
 constexpr int kHigh = kCap - 4;  // a step pushes at most one entry per lane: rounds start when a queue holds this many (checked once per group of steps) ...
 constexpr int kLow = 8;          // ... and stop when every queue is down to this
 constexpr double kKappa = 1.0 / 32.0;
@@ -125,6 +144,10 @@ SFM_DEVICE float bf_up(float x) {   // smallest bf16 >= x for x >= 0 (NaN stays 
 SFM_DEVICE void split2(double x, float& hi, float& mid) {
     hi = (float)(_Float16)(float)x;
     mid = (float)(_Float16)(float)(x - (double)hi);
+#if SFM_MATRIX_ABLATE & 16   // measurement build: no fp16 subnormals among the operands (are they slow on the matrix pipe?)
+    if (fabsf(mid) < 6.2e-5f) mid = 0.0f;
+    if (fabsf(hi) < 6.2e-5f) hi = 0.0f;
+#endif
     if (!(fabs(x) < 1e300)) mid = hi;   // inf / NaN: keep the poison in both parts (inf - inf would be NaN anyway)
 }
 // power of two s with s * x in [2^(top-1), 2^top) (x > 0 finite), else 1
@@ -228,11 +251,19 @@ __global__ __launch_bounds__(64) void matrix_prepare_kernel(const Corr* __restri
 // Operand table of the hypotheses: for hypothesis h and half (0: slots 0..7, 1: slots 8..15 of each block) the three B
 // fragments of tier 1 — the scaled fp16 hi / mid split of E for the two r' blocks and the bf16 dB form with its absolute terms
 // and the slack.  One thread per (hypothesis, half).
+//
+// The same threads compute the hypothesis' SAMPLE CORRECTION (fix != nullptr): the eight sample points are never counted and
+// always summed (ransac.py:70-79), while the scoring scan treats them like any other point — so for each sample point with
+// sed <= thr the count drops by one, and the others add their sed / sed^2 to the sums.  Four samples per thread (their gathers in
+// flight together), the two threads of a hypothesis added first half + second half: fix = [h_pad] int32 | [h_pad] f64 | [h_pad] f64.
 __global__ __launch_bounds__(256) void matrix_hypothesis_kernel(const unsigned char* __restrict__ ws, const double* __restrict__ E,
                                                                 int h_count, double a_scale, uint4* __restrict__ hyp_table,
-                                                                float* __restrict__ bound_out) {
-    const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (item >= 2 * (int64_t)h_count) return;
+                                                                float* __restrict__ bound_out, const Corr* __restrict__ pts, int n,
+                                                                const int32_t* __restrict__ S, double thr,
+                                                                unsigned char* __restrict__ fix) {
+    const int64_t item_raw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = item_raw < 2 * (int64_t)h_count;
+    const int64_t item = live ? item_raw : 2 * (int64_t)h_count - 1;   // (the tail threads shadow the last one: the pair sums below are wave operations)
     const int64_t pair = blockIdx.y;
     ws += 16 * pair;                                   // this pair's maxima
     E += pair * (int64_t)h_count * 9;
@@ -242,6 +273,33 @@ __global__ __launch_bounds__(256) void matrix_hypothesis_kernel(const unsigned c
     double e[9];
 #pragma unroll
     for (int j = 0; j < 9; ++j) e[j] = E[(int64_t)h * 9 + j];
+    if (fix != nullptr) {
+        pts += pair * (int64_t)n;
+        S += pair * (int64_t)h_count * 8;
+        fix += pair * sfmws::matrix_fix_bytes(h_count);
+        const int4 sample = *reinterpret_cast<const int4*>(S + h * 8 + 4 * half);
+        const Corr p[4] = {pts[sample.x], pts[sample.y], pts[sample.z], pts[sample.w]};
+        int dc = 0;
+        double d1 = 0.0, d2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double sed = sfm::sed_value(e, p[k].xa, p[k].ya, p[k].xb, p[k].yb);
+            const bool counted = sed <= thr;            // the scan counted it and summed it
+            dc += counted ? -1 : 0;
+            const double extra = counted ? 0.0 : sed;   // NaN / inf propagate: such a model never wins
+            d1 += extra;
+            d2 += extra * extra;
+        }
+        const int dc_other = __shfl_xor(dc, 1, 64);
+        const double d1_other = __shfl_xor(d1, 1, 64), d2_other = __shfl_xor(d2, 1, 64);
+        if (live && half == 0) {
+            const int64_t hp = sfmws::split_padded(h_count);
+            reinterpret_cast<int32_t*>(fix)[h] = dc + dc_other;
+            reinterpret_cast<double*>(fix + 4 * hp)[h] = d1 + d1_other;
+            reinterpret_cast<double*>(fix + 4 * hp)[hp + h] = d2 + d2_other;
+        }
+    }
+    if (!live) return;
     constexpr float up = 1.0f + 1e-5f;
     float M[9];
     const DataScale data = data_scale(reinterpret_cast<const uint32_t*>(ws), (float)a_scale * (1.0f + 1e-6f), M);
@@ -349,51 +407,61 @@ __global__ __launch_bounds__(64) void matrix_filter_dump_kernel(const uint4* __r
     }
 }
 
-// One wave: 32 hypotheses (entries [32 wave, 32 wave + 32) of the processing order) over the steps of one range of the points.
+// One work item: 32 hypotheses (entries [32 wave, 32 wave + 32) of the processing order) over the steps of one range of the
+// points, done by one wave.
 // ESTIMATE: the cost pre-pass of this kernel — tier 1 alone over the first `units` x `steps_per_unit` steps (a single pair: in
 // `units` ranges by different waves, a pre-pass of 3125 waves over 128 steps each is latency-bound: 59 us, 4 x 32 steps: see
 // profiles/r03), cnt[h] = the survivors per 1024 points in sixteenths (what the counting sort's classes are defined on).  With 1024 points the estimate is 52 +- 7 for a typical hypothesis
 // and the 32 hypotheses a wave runs in lock step differ by that noise (lane utilisation 0.77); tier 1 on the matrix pipe makes
 // 4096 points as cheap as 1024 were on the VALU.
+struct MatrixPair {   // the arrays of one image pair
+    const Corr* __restrict__ pts;
+    const uint4* __restrict__ hyp_table;
+    const uint4* __restrict__ table;
+    const double* __restrict__ E;
+    const int32_t* __restrict__ order;
+    int32_t* __restrict__ cnt;
+    double* __restrict__ s1;
+    double* __restrict__ s2;
+    unsigned char* __restrict__ split;
+    const unsigned char* __restrict__ fix;   // sample corrections of matrix_hypothesis_kernel: [h] int32 | [h] double | [h] double
+};
+
+// One wave-uniform ticket from an agent-scope counter, in straight-line assembly with the exec mask set by hand: written as
+// `if (lane == 0) t = atomicAdd(..); t = readfirstlane(t)` inside a loop the compiler may thread the inactive lanes past the
+// atomic into the next iteration, where readfirstlane then reads one of THEM (round 3, profiles/r03/README.md).
+SFM_DEVICE int take_ticket(int32_t* counter) {
+    int ticket, returned;
+    unsigned long long saved;
+    const int one = 1;
+    asm volatile(
+        "s_mov_b64 %[saved], exec\n\t"
+        "s_mov_b64 exec, 1\n\t"
+        "global_atomic_add %[returned], %[address], %[one], off sc0\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "v_readfirstlane_b32 %[ticket], %[returned]\n\t"
+        "s_mov_b64 exec, %[saved]"
+        : [ticket] "=s"(ticket), [returned] "=&v"(returned), [saved] "=&s"(saved)
+        : [address] "v"(counter), [one] "v"(one)
+        : "memory");
+    return ticket;
+}
+
 template <bool ESTIMATE>
-__global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
-    const Corr* __restrict__ pts, const uint4* __restrict__ hyp_table, const uint4* __restrict__ table, int n,
-    const double* __restrict__ E, const int32_t* __restrict__ S, int h_count, double thr,
-    const int32_t* __restrict__ order, int32_t* __restrict__ cnt, double* __restrict__ s1, double* __restrict__ s2, int units,
-    int steps_per_unit, unsigned char* __restrict__ split, int batch, int blocks_per_pair) {
-    __shared__ uint32_t queues[ESTIMATE ? 1 : 256 / kWave][ESTIMATE ? 1 : kCap][kWave];
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
-    int block_of_range = blockIdx.x, unit = 0;
-    if (batch > 1) {
-        // XCD-aware block -> (pair, block of the pair) map, as in score_sed_filtered_kernel: workgroups are dealt round-robin
-        // over the 8 XCDs by linear id, so all blocks of a pair get ids of one residue class mod 8 and the pair's operand
-        // table (96 bytes per point) and fp64 points stay in ONE L2 — and the pair's points are cut into ranges until its waves
-        // fill an XCD by themselves: with eight small pairs resident per XCD their tables (1.3 MB each at 10 000 points) thrash
-        // the 4 MB L2 (C5 without ranges: 4.6 ms against 3.2 with the VALU kernel, whose points take 16 bytes each).
-        const int label = blockIdx.x & 7, j = blockIdx.x >> 3;
-        const int64_t pair = (int64_t)(j / blocks_per_pair) * 8 + label;
-        block_of_range = j % blocks_per_pair;
-        if (pair >= batch) return;   // padding of the last group of eight
-        if (units > 1) {
-            unit = block_of_range % units;
-            block_of_range /= units;
-            split += pair * sfmws::split_bytes(h_count);
-        }
-        pts += pair * (int64_t)n;
-        table += pair * steps_of(n) * kBlocks * 64;
-        hyp_table += pair * (int64_t)h_count * 2 * kBlocks;
-        E += pair * (int64_t)h_count * 9;
-        S += pair * (int64_t)h_count * 8;
-        if (order != nullptr) order += pair * (int64_t)h_count;
-        cnt += pair * (int64_t)h_count;
-        s1 += pair * (int64_t)h_count;
-        s2 += pair * (int64_t)h_count;
-    } else if (units > 1) {   // `units` consecutive blocks take the same hypotheses over one range of the points each
-        unit = block_of_range % units;
-        block_of_range /= units;
-    }
-    const int wave = block_of_range * (256 / kWave) + wave_in_block;
+SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr, int units, int steps_per_unit, int wave, int unit,
+                            uint32_t* const my_queue, int lane, unsigned item_id) {
+    const Corr* __restrict__ pts = a.pts;
+    const uint4* __restrict__ hyp_table = a.hyp_table;
+    const uint4* __restrict__ table = a.table;
+    const double* __restrict__ E = a.E;
+    const int32_t* __restrict__ order = a.order;
+    int32_t* __restrict__ cnt = a.cnt;
+    double* __restrict__ s1 = a.s1;
+    double* __restrict__ s2 = a.s2;
+#if SFM_MATRIX_STAMPS
+    unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0};
+    stamp[0] = __builtin_amdgcn_s_memrealtime();
+#endif
     const int h0 = wave * kHyps;
     if (h0 >= h_count) return;   // (no block-level synchronisation in this kernel)
     const int col = lane & 31, half = lane >> 5;
@@ -403,13 +471,24 @@ __global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
 
     // ---- this lane's hypothesis: exact entries for the exact tier; the B operands of tier 1 come from the table
     // matrix_hypothesis_kernel wrote once per launch (a hypothesis is scored by up to 16 range waves and the cost pre-pass)
+    // (the exact entries are loaded where the exact tier starts — in front of a burst of rounds, and of the final drain — not
+    // kept in 18 VGPRs through the tier-1 loop, which never reads them: the loop's occupancy is what they would cost)
     double e[9];
+    auto load_e = [&]() __attribute__((always_inline)) {
+        int64_t first = (int64_t)h * 9;
+        asm volatile("" : "+v"(first));   // (an address the compiler cannot prove loop-invariant: the loads stay where they are written)
 #pragma unroll
-    for (int j = 0; j < 9; ++j) e[j] = E[(int64_t)h * 9 + j];
+        for (int j = 0; j < 9; ++j) e[j] = E[first + j];
+    };
+#if !SFM_MATRIX_E_IN_REGISTERS
+    if (ESTIMATE)
+#endif
+        load_e();
     const uint4* __restrict__ operands = hyp_table + ((int64_t)h * 2 + half) * kBlocks;
     const f16x8 B0 = __builtin_bit_cast(f16x8, operands[0]);
     const f16x8 B1 = __builtin_bit_cast(f16x8, operands[1]);
     const bf16x8 B2 = __builtin_bit_cast(bf16x8, operands[2]);
+    SFM_STAMP(1);
 
     // The lane's queue is a ring of entries (step << 16 | the step's 16 survivor bits), pushed at `tail`, popped at `head`; the
     // entry being consumed lives in registers (`cur` = its remaining bits, `cur_base` = index of its row 0).  Points of a
@@ -421,7 +500,7 @@ __global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
     unsigned head = 0, tail = 0, cur = 0;
     int cur_base = 0;
     double a1 = 0.0, a2 = 0.0;
-    uint32_t* const my_queue = &queues[ESTIMATE ? 0 : wave_in_block][0][lane];   // slot k at my_queue[k * kWave]
+    // (my_queue: this lane's column of the wave's queue block in LDS — slot k at my_queue[k * kWave])
 #if SFM_MATRIX_STATS
     unsigned stat_rounds = 0, stat_pops = 0, stat_push_iterations = 0;
 #endif
@@ -550,6 +629,9 @@ __global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
          // between two stages it falls back to vmcnt(0) at the top of every group.  A group pushes at most kStages entries per
          // lane: kHigh + kStages - 1 <= kCap.  (When rounds happen does not change any sum: a lane's queue is first-in first-out.)
          if (queue_full) {
+#if !SFM_MATRIX_E_IN_REGISTERS
+             load_e();
+#endif
              __builtin_amdgcn_wave_barrier();
              do round(); while (__builtin_amdgcn_ballot_w64((int)(tail - head) > kLow) != 0ull);
          }
@@ -566,8 +648,13 @@ __global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
         }
         return;
     }
+    SFM_STAMP(2);
+#if !SFM_MATRIX_E_IN_REGISTERS
+    load_e();
+#endif
     __builtin_amdgcn_wave_barrier();
     while (__builtin_amdgcn_ballot_w64(tail != head || cur != 0u) != 0ull) round();
+    SFM_STAMP(3);
 #if SFM_MATRIX_ABLATE & 8
     c += (int)survivors;
 #endif
@@ -579,42 +666,162 @@ __global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
     atomicAdd(&g_matrix_stats[1], (unsigned long long)stat_pops);
 #endif
 
-    // the eight sample points are never counted and always summed (ransac.py:70-79): the scan treated them like any other
-    // point; the first lane of each hypothesis (in the wave of its first range) re-scores them exactly and patches its totals
-    if ((units <= 1 || unit == 0) && half == 0) {
-        const int32_t* sample = S + (int64_t)h * 8;
-        for (int k = 0; k < 8; ++k) {
-            const Corr p = pts[sample[k]];
-            const double sed = sfm::sed_value(e, p.xa, p.ya, p.xb, p.yb);
-            const bool counted = sed <= thr;   // already in (c, a1, a2)
-            c += counted ? -1 : 0;
-            const double extra = counted ? 0.0 : sed;   // NaN / inf propagate: such a model never wins
-            a1 += extra;
-            a2 += extra * extra;
-        }
-    }
+    // (The eight sample points — never counted, always summed: ransac.py:70-79 — were scanned like any other point; their
+    // correction is a constant of the hypothesis, computed by matrix_hypothesis_kernel and added where the totals are written.
+    // Until round 4 the wave of range 0 re-scored them here: eight dependent gather + fp64 evaluations, 20 us in a kernel whose
+    // throughput is slots / wave lifetime, and — consecutive blocks being the ranges of one group, dealt round-robin over the
+    // XCDs — all of them on XCD 0, which finished a quarter of the launch after the other seven.)
+    SFM_STAMP(4);
     // the two lanes of a hypothesis: first half + second half
     const int c_other = __shfl_xor(c, 32, 64);
     const double a1_other = __shfl_xor(a1, 32, 64), a2_other = __shfl_xor(a2, 32, 64);
     const int ck = c + c_other;
     const double s1k = half == 0 ? a1 + a1_other : a1_other + a1;
     const double s2k = half == 0 ? a2 + a2_other : a2_other + a2;
-    if (half != 0 || !valid) return;
-    if (units <= 1) {
-        cnt[h] = ck;
-        s1[h] = s1k;
-        s2[h] = s2k;
+    if (half == 0 && valid) {
+        const int64_t hp = sfmws::split_padded(h_count);
+        if (units <= 1) {   // the totals, with the correction for the sample points behind them
+            const int32_t* fix_c = reinterpret_cast<const int32_t*>(a.fix);
+            const double* fix_a1 = reinterpret_cast<const double*>(a.fix + 4 * hp);
+            cnt[h] = ck + fix_c[h];
+            s1[h] = s1k + fix_a1[h];
+            s2[h] = s2k + fix_a1[hp + h];
+        } else {
+            // Range split: this range's partial goes to [range][hypothesis] with PLAIN stores; matrix_fold_kernel, launched
+            // behind this kernel, adds the ranges in range order (a fixed order: identical sums from run to run).  Until round 4
+            // the ranges met on a per-hypothesis arrival counter — three write-through stores, an agent-scope read-modify-write
+            // and, in the last arriver, 3 x ranges agent-scope loads per (hypothesis, range): 800 000 device-scope atomics and
+            // 2.4 M write-through stores per launch, which the memory side of eight non-coherent L2s serves at ~1.5 M / ms — with
+            // the step loop stubbed out the launch still took 0.6 ms, two thirds of every wave's life spent in that hand-off
+            // (profiles/r04/README.md); a kernel boundary orders the same data for nothing.
+            int32_t* part_c = reinterpret_cast<int32_t*>(a.split) + hp;
+            double* part_a1 = reinterpret_cast<double*>(part_c + sfmws::kSplitMaxUnits * hp);
+            double* part_a2 = part_a1 + sfmws::kSplitMaxUnits * hp;
+            part_c[unit * hp + h] = ck;
+            part_a1[unit * hp + h] = s1k;
+            part_a2[unit * hp + h] = s2k;
+        }
+    }
+#if SFM_MATRIX_STAMPS
+    SFM_STAMP(5);
+    const unsigned wave_id = item_id;
+    if (lane == 0 && wave_id < 65536u) {
+        unsigned hw_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        unsigned xcc_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+#pragma unroll
+        for (int k = 0; k < 6; ++k) g_matrix_stamps[8 * wave_id + k] = stamp[k];
+        g_matrix_stamps[8 * wave_id + 6] = ((unsigned long long)xcc_id << 32) | hw_id;
+        g_matrix_stamps[8 * wave_id + 7] = ((unsigned long long)unit << 32) | (unsigned)h0;
+    }
+#endif
+}
+
+// Totals of a range-split launch: partials [range][hypothesis] added in range order, then the sample correction.
+__global__ __launch_bounds__(256) void matrix_fold_kernel(const unsigned char* __restrict__ split, const unsigned char* __restrict__ fix,
+                                                          int units, int h_count, int32_t* __restrict__ cnt,
+                                                          double* __restrict__ s1, double* __restrict__ s2) {
+    const int64_t pair = blockIdx.y;
+    const int64_t hp = sfmws::split_padded(h_count);
+    split += pair * sfmws::split_bytes(h_count);
+    fix += pair * sfmws::matrix_fix_bytes(h_count);
+    cnt += pair * (int64_t)h_count;
+    s1 += pair * (int64_t)h_count;
+    s2 += pair * (int64_t)h_count;
+    const int32_t* part_c = reinterpret_cast<const int32_t*>(split) + hp;
+    const double* part_a1 = reinterpret_cast<const double*>(part_c + sfmws::kSplitMaxUnits * hp);
+    const double* part_a2 = part_a1 + sfmws::kSplitMaxUnits * hp;
+    const int32_t* fix_c = reinterpret_cast<const int32_t*>(fix);
+    const double* fix_a1 = reinterpret_cast<const double*>(fix + 4 * hp);
+    for (int64_t h = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; h < h_count; h += (int64_t)gridDim.x * blockDim.x) {
+        int total = part_c[h];
+        double t1 = part_a1[h], t2 = part_a2[h];
+        for (int u = 1; u < units; ++u) {
+            total += part_c[u * hp + h];
+            t1 += part_a1[u * hp + h];
+            t2 += part_a2[u * hp + h];
+        }
+        cnt[h] = total + fix_c[h];
+        s1[h] = t1 + fix_a1[h];
+        s2[h] = t2 + fix_a1[hp + h];
+    }
+}
+
+// The launch.  tickets == nullptr: one item per wave, placed by block index (batches of pairs with their XCD-aware block map).
+// tickets != nullptr (a single pair): PERSISTENT waves — the grid is what the chip holds at once (CUs x SFM_MATRIX_OCC blocks),
+// and every wave takes items from a counter until they run out.  Why: the hardware's workgroup dispatcher does not keep this
+// kernel's slots full.  With one block per 4 items (round 3) the stamps of every wave (tools/r04/matrix_timeline.py,
+// profiles/r04) showed, per XCD, ONE shader engine at its 128 waves and the other three at 30-45 for most of the launch while
+// thousands of blocks were waiting — blocks are handed to the engines in turn, and the turn waits for the full one — 2600 of
+// 4096 slots occupied on average, the launch ending when the slowest XCD did.  Waves that fetch their own work do not depend on
+// any of that: a slot is busy until the items are gone, and the items can be as fine as the balance wants.
+// Items of XCD x (tickets[16 x]): the ranges u = x (mod 8) of every group when the ranges are a multiple of eight — an XCD then
+// streams only its own eighth of the point operand table through its L2, as the block order of round 3 did; otherwise one
+// counter serves all.  The counters are zeroed by score_reset_kernel (they live behind the class counters).
+template <bool ESTIMATE>
+__global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
+    const Corr* __restrict__ pts, const uint4* __restrict__ hyp_table, const uint4* __restrict__ table, int n,
+    const double* __restrict__ E, int h_count, double thr, const int32_t* __restrict__ order, int32_t* __restrict__ cnt,
+    double* __restrict__ s1, double* __restrict__ s2, int units, int steps_per_unit, unsigned char* __restrict__ split,
+    const unsigned char* __restrict__ fix, int batch, int blocks_per_pair, int32_t* __restrict__ tickets) {
+    __shared__ uint32_t queues[ESTIMATE ? 1 : 256 / kWave][ESTIMATE ? 1 : kCap][kWave];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    uint32_t* const my_queue = &queues[ESTIMATE ? 0 : wave_in_block][0][lane];
+    MatrixPair a{pts, hyp_table, table, E, order, cnt, s1, s2, split, fix};
+    if (tickets != nullptr) {
+        const int waves32 = (h_count + kHyps - 1) / kHyps;
+        const bool by_xcc = units % 8 == 0;
+        unsigned xcc = 0;
+        if (by_xcc) {
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            xcc &= 7u;
+        }
+        const int mine = by_xcc ? units / 8 : units;   // ranges of a group that this wave's counter hands out
+        const int items = waves32 * mine;
+        for (;;) {
+            const int t = take_ticket(tickets + 16 * xcc);
+            if (t >= items) break;   // (every wave gets here: the counter only grows)
+            const int wave = t / mine;
+            const int unit = by_xcc ? (int)xcc + 8 * (t % mine) : t % mine;
+            matrix_item<ESTIMATE>(a, n, h_count, thr, units, steps_per_unit, wave, unit, my_queue, lane,
+                                  (unsigned)(wave * units + unit));
+        }
         return;
     }
-    // range split: publish this range's partial, count in; the range that arrives last adds the partials in range order
-    // (sfmws::split_arrive_and_fold: an ACQ_REL arrival at agent scope)
-    int total = ck;
-    double t1 = s1k, t2 = s2k;
-    if (sfmws::split_arrive_and_fold(split, h_count, units, unit, h, total, t1, t2)) {
-        cnt[h] = total;
-        s1[h] = t1;
-        s2[h] = t2;
+    int block_of_range = blockIdx.x, unit = 0;
+    if (batch > 1) {
+        // XCD-aware block -> (pair, block of the pair) map, as in score_sed_filtered_kernel: workgroups are dealt round-robin
+        // over the 8 XCDs by linear id, so all blocks of a pair get ids of one residue class mod 8 and the pair's operand
+        // table (96 bytes per point) and fp64 points stay in ONE L2 — and the pair's points are cut into ranges until its waves
+        // fill an XCD by themselves: with eight small pairs resident per XCD their tables (1.3 MB each at 10 000 points) thrash
+        // the 4 MB L2 (C5 without ranges: 4.6 ms against 3.2 with the VALU kernel, whose points take 16 bytes each).
+        const int label = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int64_t pair = (int64_t)(j / blocks_per_pair) * 8 + label;
+        block_of_range = j % blocks_per_pair;
+        if (pair >= batch) return;   // padding of the last group of eight
+        if (units > 1) {
+            unit = block_of_range % units;
+            block_of_range /= units;
+            a.split += pair * sfmws::split_bytes(h_count);
+        }
+        a.pts += pair * (int64_t)n;
+        a.table += pair * steps_of(n) * kBlocks * 64;
+        a.hyp_table += pair * (int64_t)h_count * 2 * kBlocks;
+        a.E += pair * (int64_t)h_count * 9;
+        if (a.order != nullptr) a.order += pair * (int64_t)h_count;
+        a.cnt += pair * (int64_t)h_count;
+        a.s1 += pair * (int64_t)h_count;
+        a.s2 += pair * (int64_t)h_count;
+        if (a.fix != nullptr) a.fix += pair * sfmws::matrix_fix_bytes(h_count);
+    } else if (units > 1) {   // `units` consecutive blocks take the same hypotheses over one range of the points each
+        unit = block_of_range % units;
+        block_of_range /= units;
     }
+    const int wave = block_of_range * (256 / kWave) + wave_in_block;
+    matrix_item<ESTIMATE>(a, n, h_count, thr, units, steps_per_unit, wave, unit, my_queue, lane,
+                          blockIdx.x * (256 / kWave) + wave_in_block);
 }
 
 }  // namespace matrixscore

@@ -117,9 +117,20 @@ __host__ __device__ inline int64_t ws_matrix_offset(int64_t n, int64_t h_count, 
 __host__ __device__ inline int64_t ws_matrix_hyp_offset(int64_t n, int64_t h_count, int64_t batch) {
     return ((ws_matrix_offset(n, h_count, batch) + batch * matrix_table_bytes(n) + 255) / 256) * 256;
 }
-__host__ __device__ inline int64_t workspace_bytes_for(int64_t n, int64_t h_count, int64_t batch) {
-    return ws_matrix_hyp_offset(n, h_count, batch) + batch * matrix_hyp_table_bytes(n, h_count);
+// ... and per pair the sample corrections of the hypotheses (matrix_hypothesis_kernel): [h_pad] int32 | [h_pad] f64 | [h_pad] f64
+__host__ __device__ inline int64_t matrix_fix_bytes(int64_t h_count) { return split_padded(h_count) * (4 + 8 + 8); }
+__host__ __device__ inline int64_t ws_matrix_fix_offset(int64_t n, int64_t h_count, int64_t batch) {
+    return ((ws_matrix_hyp_offset(n, h_count, batch) + batch * matrix_hyp_table_bytes(n, h_count) + 255) / 256) * 256;
 }
+__host__ __device__ inline int64_t workspace_bytes_for(int64_t n, int64_t h_count, int64_t batch) {
+    return ws_matrix_fix_offset(n, h_count, batch) + (n <= kMatrixMaxPoints ? batch * matrix_fix_bytes(h_count) : 0);
+}
+// Work counters of the matrix-pipe kernel's persistent waves (one per XCD, a 64-byte line each), in the words of the class-counter
+// block that no class uses (classes end at int 16 * 240 = 3840); score_reset_kernel zeroes them with the class counters.
+constexpr int kTicketWords = 3968;          // ints [3968, 3968 + 8 * 16): the scoring launch
+constexpr int kTicketWordsPrepass = 3848;   // ints [3848 + 8 x], x < 8: the cost pre-pass (eight 32-byte slots)
+static_assert(16 * (kClasses - 1) < kTicketWordsPrepass && kTicketWordsPrepass + 8 * 8 <= kTicketWords &&
+              kTicketWords + 8 * 16 <= kBuckets, "the work counters sit between the class counters and the end of the block");
 
 // fp32 record of one correspondence as tier 1 reads it; a_scale: 1 for the two-sided test, c ~ 1/sqrt(T) for the
 // one-sided one (reject_mask_one_sided in sfm_score.hip)

@@ -35,12 +35,14 @@ def gc_paused():
     / Match of the caller — at 50 000 matches that is most of a call's time (86 ms of 105 in building the pair list
     alone).  Nothing created here is cyclic; the collector's previous state is restored on exit.
 
-    On exit the objects created meanwhile (95 000 at 50 000 matches) would all sit in the youngest generation, and the
-    first allocation after ``gc.enable()`` would start a collection that walks every one of them (5-6 ms).  They are
-    moved to the oldest generation wholesale instead — ``gc.freeze(); gc.unfreeze()`` splices the generation lists
-    without visiting an object — where the next full collection finds them like any other long-lived object.  Skipped
-    when the process keeps a permanent generation of its own (``gc.get_freeze_count() != 0``: unfreezing would release
-    that too) and when only a few objects were created."""
+    On exit the objects created meanwhile (95 000 at 50 000 matches) all sit in the youngest generation, and the first
+    allocation after ``gc.enable()`` starts a collection that walks every one of them (5-6 ms at that size).  With
+    ``SFM_GC_SPLICE=1`` (opt-in since round 4) they are moved to the oldest generation wholesale instead —
+    ``gc.freeze(); gc.unfreeze()`` splices the generation lists without visiting an object.  That is a change of the
+    EMBEDDING application's collector state — every tracked object of the process is promoted, including the caller's own
+    young objects, and a ``gc.freeze()`` another thread takes between the check and the splice would be released by the
+    ``unfreeze`` — so a library call does not do it unasked.  Skipped in any case when the process keeps a permanent
+    generation of its own (``gc.get_freeze_count() != 0``) and when only a few objects were created."""
     was_enabled = gc.isenabled()
     gc.disable()
     before = gc.get_count()[0]
@@ -48,7 +50,8 @@ def gc_paused():
         yield
     finally:
         if was_enabled:
-            if gc.get_count()[0] - before > 20_000 and gc.get_freeze_count() == 0:
+            if (os.environ.get("SFM_GC_SPLICE", "0") == "1" and gc.get_count()[0] - before > 20_000
+                    and gc.get_freeze_count() == 0):
                 gc.freeze()
                 gc.unfreeze()
             gc.enable()

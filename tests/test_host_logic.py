@@ -638,10 +638,12 @@ def test_hostfast_helper_equals_the_python_paths(native_lib):
     assert _engine.pair_arrays([]).shape == (2, 0, 2) and _engine.copy_pairs(pairs, np.array([], dtype=np.int64)) == []
 
 
-def test_gc_paused_restores_the_collector_and_leaves_no_permanent_generation():
-    """_engine.gc_paused: the collector's state is restored, bulk objects created inside do not trigger a young
-    collection right after (they are spliced into the oldest generation), nothing stays frozen, cyclic garbage is still
-    collected afterwards, and a process that keeps a permanent generation of its own is left alone."""
+def test_gc_paused_restores_the_collector_and_leaves_no_permanent_generation(monkeypatch):
+    """_engine.gc_paused: the collector's state is restored; by default the embedding application's generations are left
+    alone (a library call must not promote the caller's young objects) and the new objects wait in the
+    youngest one; with SFM_GC_SPLICE=1 they are spliced into the oldest generation so that no young collection walks them
+    right after; nothing stays frozen either way, cyclic garbage is still collected afterwards, and a process that keeps a
+    permanent generation of its own is left alone."""
     import gc
     import weakref
 
@@ -649,6 +651,15 @@ def test_gc_paused_restores_the_collector_and_leaves_no_permanent_generation():
     from structure_from_motion_amd.epipolar import _engine
 
     assert gc.isenabled() and gc.get_freeze_count() == 0
+    monkeypatch.delenv("SFM_GC_SPLICE", raising=False)
+    calls = []
+    real_freeze = gc.freeze
+    monkeypatch.setattr(gc, "freeze", lambda: (calls.append(1), real_freeze())[1])
+    with _engine.gc_paused():
+        made = [(Feature(1.0, 2.0), Feature(3.0, 4.0)) for _ in range(15_000)]
+    assert gc.isenabled() and gc.get_freeze_count() == 0 and not calls    # default: the generations were not touched
+    del made
+    monkeypatch.setenv("SFM_GC_SPLICE", "1")
     with _engine.gc_paused():
         assert not gc.isenabled()
         with _engine.gc_paused():          # nested: the inner exit must not switch the collector back on
@@ -656,6 +667,8 @@ def test_gc_paused_restores_the_collector_and_leaves_no_permanent_generation():
         assert not gc.isenabled()
     assert gc.isenabled() and gc.get_freeze_count() == 0
     assert gc.get_count()[0] < 5_000      # the 45 000 new objects are not waiting in the youngest generation
+    assert len(calls) == 1
+    monkeypatch.setattr(gc, "freeze", real_freeze)
     del made
 
     class Node:

@@ -1,0 +1,149 @@
+// Microbenchmark (gfx950): what one tier-1 step of score_sed_matrix_kernel costs a SIMD, piece by piece, with no memory in the
+// loop: three 32x32x16 matrix instructions (r' chain of two + the denominator), the sixteen sign tests (v_fma_f32 +
+// v_alignbit_b32 each), and both together, at 1 / 2 / 4 waves per SIMD.  Cycles are shader cycles by s_memtime inside the
+// kernel (per wave: last stamp - first stamp, median over waves), so the clock the chip holds does not matter.
+// Build: hipcc --offload-arch=gfx950 -O3 tools/micro/matrix_step_rates.hip -o tools/micro/bin/matrix_step_rates
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <vector>
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+// MODE bit 0: matrix instructions, bit 1: sign tests (fma + alignbit), bit 2: fma only (no alignbit), bit 3: alignbit replaced
+// by v_lshl_or_b32 (is alignbit slow?), bit 4: packed fma (v_pk_fma_f32) for the tests
+// MODE bit 5: the three operands of the point side come from memory as in the kernel — 3 x 1 KiB per step and wave, two steps
+// ahead, every wave streaming `steps` steps of a table that stays in L2 (waves of one block read the same steps)
+template <int MODE>
+__global__ __launch_bounds__(256) void k(int iters, unsigned long long* stamps, unsigned* sink, const uint4* __restrict__ table = nullptr,
+                                         int steps = 1) {
+    extern __shared__ unsigned pad[];
+    f16x8 A0, A1, B0, B1;
+    bf16x8 A2, B2;
+    for (int j = 0; j < 8; ++j) {
+        A0[j] = (_Float16)(threadIdx.x * 0.001f + j); A1[j] = (_Float16)(j * 0.5f); B0[j] = (_Float16)(1.0f + j); B1[j] = (_Float16)(0.25f * j);
+        A2[j] = (__bf16)(0.1f * j); B2[j] = (__bf16)(2.0f + j);
+    }
+    float16v r = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, d = r;
+    for (int j = 0; j < 16; ++j) { r[j] = threadIdx.x + j; d[j] = 2.0f * j + 1.0f; }
+    unsigned total = 0;
+    uint4 S0[3], S1[3];
+    const uint4* src = table + (threadIdx.x & 63);
+    const int first = (int)((blockIdx.x & 7) * (unsigned)steps);   // an eighth of the table per residue class of the block id (XCD)
+    if (MODE & 32) {
+        for (int b = 0; b < 3; ++b) S0[b] = src[((size_t)first * 3 + b) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+        for (int b = 0; b < 3; ++b) S1[b] = src[((size_t)(first + 1) * 3 + b) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    int t = 0;   // step inside the range (wraps)
+    auto step = [&](uint4 (&stage)[3]) __attribute__((always_inline)) {
+        if (MODE & 32) {
+            A0 = __builtin_bit_cast(f16x8, stage[0]);
+            A1 = __builtin_bit_cast(f16x8, stage[1]);
+            A2 = __builtin_bit_cast(bf16x8, stage[2]);
+        }
+        if (MODE & 1) {
+            float16v z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            r = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, B0, z, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B2, z, 0, 0, 0);
+            r = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, B1, r, 0, 0, 0);
+        }
+        unsigned rejected = 0;
+        if (MODE & 2) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                rejected = __builtin_amdgcn_alignbit(rejected, __float_as_uint(__builtin_fmaf(-r[j], r[j], d[j])), 31);
+        }
+        if (MODE & 4) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) rejected += __float_as_uint(__builtin_fmaf(-r[j], r[j], d[j]));
+        }
+        if (MODE & 8) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) rejected = (rejected << 1) | (__float_as_uint(__builtin_fmaf(-r[j], r[j], d[j])) >> 31);
+        }
+        if (MODE & 16) {
+            typedef float float2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int j = 0; j < 16; j += 2) {
+                float2v rr = {r[j], r[j + 1]}, dd = {d[j], d[j + 1]}, out;
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(out) : "v"(rr), "v"(rr), "v"(dd));
+                rejected = __builtin_amdgcn_alignbit(rejected, __float_as_uint(out[0]), 31);
+                rejected = __builtin_amdgcn_alignbit(rejected, __float_as_uint(out[1]), 31);
+            }
+        }
+        if (MODE & 32) {   // refill this stage with the operands two steps on, behind its use
+            int next = t + 2;
+            next = next >= steps ? next - steps : next;
+            unsigned offset = (unsigned)(first + next) * 192u;
+            asm volatile("" : "+v"(offset), "+v"(rejected));
+#pragma unroll
+            for (int b = 0; b < 3; ++b) stage[b] = src[offset + b * 64];
+            t = t + 1 >= steps ? 0 : t + 1;
+        }
+        total += rejected;
+        if (!(MODE & 1)) {   // keep the test inputs changing so that nothing is hoisted
+#pragma unroll
+            for (int j = 0; j < 16; ++j) asm volatile("" : "+v"(r[j]), "+v"(d[j]));
+        } else if (!(MODE & 32)) {
+            asm volatile("" : "+v"(A0), "+v"(A1), "+v"(A2));
+        }
+    };
+    for (int i = 0; i < iters; i += 2) {
+        step(S0);
+        step(S1);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * 4 + threadIdx.x / 64] = t1 - t0;
+    if (total == 0x12345u) sink[threadIdx.x] = total + pad[0];
+}
+
+template <int MODE>
+int run(const char* name, int waves_per_simd, int iters, unsigned long long* stamps_dev, unsigned* sink, const uint4* table = nullptr,
+        int steps = 1) {
+    const int blocks = 256 * waves_per_simd;   // 4-wave blocks: one wave per SIMD each; LDS padding keeps `waves_per_simd` blocks per CU
+    const size_t lds = (size_t)(160 * 1024 / waves_per_simd) - 1024;
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), lds, 0, iters, stamps_dev, sink, table, steps);
+    CHECK(hipDeviceSynchronize());
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    hipEventRecord(a);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), lds, 0, iters, stamps_dev, sink, table, steps);
+    hipEventRecord(b); CHECK(hipEventSynchronize(b));
+    float ms; hipEventElapsedTime(&ms, a, b);
+    std::vector<unsigned long long> st(blocks * 4);
+    CHECK(hipMemcpy(st.data(), stamps_dev, st.size() * 8, hipMemcpyDeviceToHost));
+    std::sort(st.begin(), st.end());
+    const double per_wave = (double)st[st.size() / 2] / iters;
+    printf("%-34s %d waves/SIMD: %7.1f cycles per step and wave (median), %7.1f per step and SIMD; kernel %.3f ms -> %.2f GHz\n", name,
+           waves_per_simd, per_wave, per_wave / waves_per_simd, ms, (double)st[st.size() / 2] / (ms * 1e6));
+    return 0;
+}
+
+int main() {
+    unsigned long long* stamps; unsigned* sink;
+    CHECK(hipMalloc(&stamps, 8 * 4 * 256 * 8)); CHECK(hipMalloc(&sink, 4096));
+    const int it = 20000;
+    const int steps = 196;                                  // steps of one range (50 000 points in 8 ranges)
+    uint4* table;
+    CHECK(hipMalloc(&table, (size_t)8 * steps * 3 * 64 * 16 + 4096));   // 4.8 MB: the point operand table of the bench workload
+    CHECK(hipMemset(table, 0x3c, (size_t)8 * steps * 3 * 64 * 16 + 4096));
+    for (int w : {1, 2, 4}) {
+        if (run<32 + 3>("loads + matrix + 16 x (fma + abit)", w, it, stamps, sink, table, steps)) return 1;
+        if (run<32 + 2>("loads + 16 x (fma + alignbit)", w, it, stamps, sink, table, steps)) return 1;
+        if (run<32 + 4>("loads + 16 x fma (+ add)", w, it, stamps, sink, table, steps)) return 1;
+        if (run<1>("3 matrix instructions", w, it, stamps, sink)) return 1;
+        if (run<2>("16 x (fma + alignbit)", w, it, stamps, sink)) return 1;
+        if (run<4>("16 x fma (+ add)", w, it, stamps, sink)) return 1;
+        if (run<8>("16 x (fma + shift-or)", w, it, stamps, sink)) return 1;
+        if (run<16>("8 x pk_fma + 16 x alignbit", w, it, stamps, sink)) return 1;
+        if (run<3>("matrix + 16 x (fma + alignbit)", w, it, stamps, sink)) return 1;
+        if (run<17>("matrix + 8 pk_fma + 16 alignbit", w, it, stamps, sink)) return 1;
+    }
+    return 0;
+}
