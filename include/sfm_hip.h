@@ -137,7 +137,7 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
  * (summation order) and are bit-identical from run to run under one setting.  The library does not read the process
  * environment: a call carries its options (sfm_score_sed_ex; NULL = the process-wide defaults) and the embedding application
  * sets the defaults once (sfm_score_set_default_options; the Python package translates SFM_SCORE_MATRIX / _HPW / _SPLIT /
- * _ORDER / _ONE_SIDED / _XCD / _SYNC there when it is imported).  Safe to call from several threads: a default set is
+ * _ORDER / _ONE_SIDED / _XCD / _SYNC / _PERSISTENT there when it is imported).  Safe to call from several threads: a default set is
  * replaced as a whole. */
 #define SFM_SCORE_KERNEL_AUTO 0     /* the size rule described at sfm_score_sed */
 #define SFM_SCORE_KERNEL_FILTERED 1 /* fp32 VALU filter */
@@ -150,9 +150,11 @@ typedef struct sfm_score_options {
     int32_t one_sided;     /* VALU filter: -1 / 1 = one-sided test r^2 / dB (default), 0 = two-sided (ablation) */
     int32_t xcd_map;       /* batches: -1 / 1 = all blocks of a pair on one XCD (default), 0 = plain (block, pair) grid */
     int32_t block_sync;    /* sfm_ransac_pass_small: -1 = by size, k = block barrier every k loop iterations, 0 = never */
-    int32_t reserved;      /* 0 */
+    int32_t persistent;    /* matrix-pipe kernel, single pair: 1 = persistent waves taking (hypothesis group, range) items from
+                              per-XCD counters; -1 / 0 = one block per four items, placed by the hardware dispatcher (default:
+                              measured equal at 5e9 evaluations and faster below — the 4096 first tickets cost ~45 us) */
 } sfm_score_options;
-#define SFM_SCORE_OPTIONS_DEFAULT {SFM_SCORE_KERNEL_AUTO, 0, -1, -1, -1, -1, -1, 0}
+#define SFM_SCORE_OPTIONS_DEFAULT {SFM_SCORE_KERNEL_AUTO, 0, -1, -1, -1, -1, -1, -1}
 int sfm_score_sed_ex(const double* corr, int64_t n, const double* E, const int32_t* S, int64_t h_count,
                      int64_t batch, double thr, int32_t* cnt, double* s1, double* s2, void* workspace,
                      int64_t workspace_bytes, void* stream, const sfm_score_options* options);

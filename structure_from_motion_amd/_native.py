@@ -43,14 +43,14 @@ class ScoreOptions(C.Structure):
         ("one_sided", C.c_int32),      # VALU filter: -1 / 1 one-sided (default), 0 two-sided
         ("xcd_map", C.c_int32),        # batches: -1 / 1 XCD-aware block map (default), 0 plain grid
         ("block_sync", C.c_int32),     # small pass: -1 = by size, k = barrier every k iterations, 0 never
-        ("reserved", C.c_int32),
+        ("persistent", C.c_int32),     # matrix-pipe kernel, one pair: 1 persistent waves, -1 / 0 one block per 4 items (default)
     ]
 
-    def __init__(self, kernel=0, hyps_per_wave=0, split=-1, order=-1, one_sided=-1, xcd_map=-1, block_sync=-1):
+    def __init__(self, kernel=0, hyps_per_wave=0, split=-1, order=-1, one_sided=-1, xcd_map=-1, block_sync=-1, persistent=-1):
         if isinstance(kernel, str):
             kernel = {"auto": SCORE_KERNEL_AUTO, "filtered": SCORE_KERNEL_FILTERED, "matrix": SCORE_KERNEL_MATRIX}[kernel]
         super().__init__(int(kernel), int(hyps_per_wave), int(split), int(order), int(one_sided), int(xcd_map),
-                         int(block_sync), 0)
+                         int(block_sync), int(persistent))
 
 
 SCORE_KERNEL_AUTO, SCORE_KERNEL_FILTERED, SCORE_KERNEL_MATRIX = 0, 1, 2
@@ -78,6 +78,7 @@ def score_options_from_env(environ=None) -> "ScoreOptions":
         one_sided=min(1, max(-1, number("SFM_SCORE_ONE_SIDED", -1))),
         xcd_map=min(1, max(-1, number("SFM_SCORE_XCD", -1))),
         block_sync=max(-1, number("SFM_SCORE_SYNC", -1)),
+        persistent=min(1, max(-1, number("SFM_SCORE_PERSISTENT", -1))),
     )
 
 

@@ -909,10 +909,11 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
         }
     }
     if (units > 1) {
-        // Range split: lane k publishes this range's partial of hypothesis k and counts itself in; the range that arrives
-        // last adds the partials in range order — a fixed order, so the sums are the same from run to run — and writes
-        // the hypothesis' totals (sfmws::split_arrive_and_fold: the partials are agent-scope atomic accesses, the arrival an
-        // ACQ_REL read-modify-write at agent scope).  score_split_reset_kernel zeroed the counters.
+        // Range split: lane k stores this range's partial of hypothesis k at [range][hypothesis]; matrixscore::matrix_fold_kernel,
+        // launched behind this kernel, adds the partials in range order — a fixed order, so the sums are the same from run to
+        // run — and writes the hypothesis' totals.  (Until round 4 the ranges met on a per-hypothesis arrival counter: device-scope
+        // atomics are served by the memory side of the eight L2s at ~1.5 M per ms, and an ACQ_REL arrival at agent scope writes
+        // the XCD's L2 back and invalidates it: the kernel boundary orders the same data for nothing — see sfm_score_matrix.h.)
         bool owner = false;
         int my_h = 0;
 #pragma unroll
@@ -920,10 +921,14 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
             owner |= (lane == k) && slot_valid[k];
             my_h = (lane == k) ? hyp[k] : my_h;
         }
-        if (owner && sfmws::split_arrive_and_fold(split, h_count, units, unit, my_h, mine_c, mine_a1, mine_a2)) {
-            cnt[my_h] = mine_c;
-            s1[my_h] = mine_a1;
-            s2[my_h] = mine_a2;
+        if (owner) {
+            const int64_t hp = split_padded(h_count);
+            int32_t* part_c = reinterpret_cast<int32_t*>(split) + hp;
+            double* part_a1 = reinterpret_cast<double*>(part_c + kSplitMaxUnits * hp);
+            double* part_a2 = part_a1 + kSplitMaxUnits * hp;
+            part_c[unit * hp + my_h] = mine_c;
+            part_a1[unit * hp + my_h] = mine_a1;
+            part_a2[unit * hp + my_h] = mine_a2;
         }
     }
 #if SFM_WAVE_STAMPS
@@ -961,6 +966,7 @@ struct FilteredLaunch {
     double a_scale;
     int units, chunks_per_unit;   // range split (single pair): 1, 0 = off
     bool xcd_map = true;          // batches: all blocks of a pair on one XCD (options.xcd_map)
+    bool persistent = true;       // matrix-pipe kernel, single pair: persistent waves (options.persistent)
 };
 
 template <int HPW>
@@ -991,11 +997,9 @@ int launch_filtered(const FilteredLaunch& a) {
     const int blocks_per_pair = remap ? (int)grid.x : 0;
     dim3 flat = remap ? dim3((unsigned)flat_blocks) : grid;
     unsigned char* split = nullptr;
-    if (a.units > 1) {   // single pair: `units` consecutive blocks per group of waves, arrival counters re-armed first
+    if (a.units > 1) {   // single pair: `units` consecutive blocks per group of waves; their partials are folded behind the launch
         flat = dim3(grid.x * (unsigned)a.units);   // (sfm_score_sed checked that this grid fits one launch)
         split = a.ws + ws_split_offset(a.n, a.h_count);
-        hipLaunchKernelGGL(score_split_reset_kernel, dim3(grid_stride(a.h_count, 256, 1024)), dim3(256), 0, a.st,
-                           reinterpret_cast<int32_t*>(split), (int64_t)a.h_count);
     }
     if (g_event_before) (void)hipEventRecord(g_event_before, a.st);
     if (a.one_sided)
@@ -1007,6 +1011,9 @@ int launch_filtered(const FilteredLaunch& a) {
                            a.h_count, a.thr, a.a_scale, order_arg, a.cnt, a.s1, a.s2, (int)a.batch, blocks_per_pair, 0, 0,
                            a.units, a.chunks_per_unit, split);
     if (g_event_after) (void)hipEventRecord(g_event_after, a.st);
+    if (a.units > 1)
+        hipLaunchKernelGGL(matrixscore::matrix_fold_kernel, dim3(grid_stride(a.h_count, 256, 1024), 1), dim3(256), 0, a.st, split,
+                           (const unsigned char*)nullptr, a.units, a.h_count, a.cnt, a.s1, a.s2);
     return check_launch("score_sed_filtered_kernel");
 }
 
@@ -1024,7 +1031,7 @@ bool valid_options(const sfm_score_options& o) {
     return (o.kernel == SFM_SCORE_KERNEL_AUTO || o.kernel == SFM_SCORE_KERNEL_FILTERED || o.kernel == SFM_SCORE_KERNEL_MATRIX) &&
            (o.hyps_per_wave == 0 || o.hyps_per_wave == 1 || o.hyps_per_wave == 2 || o.hyps_per_wave == 4) && o.split >= -1 &&
            o.order >= -1 && o.order <= 1 && o.one_sided >= -1 && o.one_sided <= 1 && o.xcd_map >= -1 && o.xcd_map <= 1 &&
-           o.block_sync >= -1 && o.reserved == 0;
+           o.block_sync >= -1 && o.persistent >= -1 && o.persistent <= 1;
 }
 
 // The size rule between the two filtered kernels of sfm_score_sed (options.kernel forces the matrix-pipe kernel on where it
@@ -1065,7 +1072,7 @@ int launch_matrix(const FilteredLaunch& a) {
     using namespace matrixscore;
     const unsigned pairs = (unsigned)a.batch;
     const uint4* table = reinterpret_cast<const uint4*>(a.ws + ws_matrix_offset(a.n, a.h_count, a.batch));
-    hipLaunchKernelGGL(matrix_prepare_kernel, dim3((unsigned)steps_of(a.n), pairs), dim3(64), 0, a.st, a.corr, a.n, a.a_scale, a.ws,
+    hipLaunchKernelGGL(matrix_prepare_kernel, dim3((unsigned)table_steps(a.n), pairs), dim3(64), 0, a.st, a.corr, a.n, a.a_scale, a.ws,
                        const_cast<uint4*>(table));
     static_assert(kBlocks * 2 * 16 == 96, "sfm_score_ws.h sizes the tables: 3 blocks");
     const uint4* hyp_table = reinterpret_cast<const uint4*>(a.ws + ws_matrix_hyp_offset(a.n, a.h_count, a.batch));
@@ -1074,7 +1081,7 @@ int launch_matrix(const FilteredLaunch& a) {
                        a.h_count, a.a_scale, const_cast<uint4*>(hyp_table), (float*)nullptr, a.corr, a.n, a.S, a.thr, fix);
     // a single pair: persistent waves — as many blocks as the chip holds at once, every wave takes (group of 32 hypotheses,
     // range) items from a per-XCD counter (see the kernel); the counters were zeroed with the class counters
-    const bool persistent = a.batch == 1;
+    const bool persistent = a.batch == 1 && a.persistent;
     const unsigned resident_blocks = (unsigned)compute_units() * SFM_MATRIX_OCC;
     const int64_t waves = (a.h_count + kHyps - 1) / kHyps;
     const unsigned blocks = grid_for(waves, 256 / kWave);
@@ -1174,7 +1181,7 @@ extern "C" int sfm_debug_matrix_stats(unsigned long long* out, int reset) {   //
 
 #if SFM_MATRIX_STAMPS
 extern "C" int sfm_debug_read_matrix_stamps(unsigned long long* out, int64_t waves) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(matrixscore::g_matrix_stamps), 64 * (size_t)waves) == hipSuccess ? 0 : -2;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(matrixscore::g_matrix_stamps), 80 * (size_t)waves) == hipSuccess ? 0 : -2;
 }
 #endif
 
@@ -1237,7 +1244,8 @@ int sfm_debug_matrix_filter(const double* corr, int64_t n, const double* E, int6
                        n, a_scale, ws);
     uint4* table = reinterpret_cast<uint4*>(ws + ws_matrix_offset(n, h_count, 1));
     uint4* hyp_table = reinterpret_cast<uint4*>(ws + ws_matrix_hyp_offset(n, h_count, 1));
-    hipLaunchKernelGGL(matrix_prepare_kernel, dim3((unsigned)steps, 1), dim3(64), 0, st, (const Corr*)corr, (int)n, a_scale, ws, table);
+    hipLaunchKernelGGL(matrix_prepare_kernel, dim3((unsigned)table_steps(n), 1), dim3(64), 0, st, (const Corr*)corr, (int)n, a_scale, ws,
+                       table);
     hipLaunchKernelGGL(matrix_hypothesis_kernel, dim3(grid_for(2 * h_count, 256), 1), dim3(256), 0, st, ws, E, (int)h_count, a_scale,
                        hyp_table, bound_out, (const Corr*)corr, (int)n, (const int32_t*)nullptr, thr, (unsigned char*)nullptr);
     hipLaunchKernelGGL(matrix_filter_dump_kernel, dim3((unsigned)steps, (unsigned)tiles), dim3(64), 0, st, hyp_table, table, steps,
@@ -1349,9 +1357,15 @@ int sfm_score_sed_ex(const double* corr, int64_t n, const double* E, const int32
         const int64_t by_size = batch > 1 ? (512 + waves32 - 1) / waves32 : (8 * 3072 + waves32 - 1) / waves32;
         int want = split_env > 0 ? split_env : (int)std::min<int64_t>(kSplitMaxUnits, std::max<int64_t>(1, by_size));
         want = std::max(1, std::min(want, kSplitMaxUnits));
+        // a multiple of eight ranges puts range u of every group on XCD u mod 8 (consecutive blocks are the ranges of one group,
+        // blocks are dealt round-robin over the XCDs; the persistent waves hand out items the same way): an XCD then streams its
+        // own eighth of the operand table through its L2 — 5 .. 11 ranges wanted -> 8, 12 and more -> 16 (50 000 x 125 000: 7
+        // ranges 1.86 ms, 8 ranges 1.73)
+        if (split_env <= 0 && batch == 1 && want >= 5) want = want >= 12 ? 16 : 8;
         const int steps = (int)matrixscore::steps_of(n);
         int steps_per_unit = (steps + want - 1) / want;
         if (split_env <= 0) steps_per_unit = std::max(steps_per_unit, batch > 1 ? 32 : 64);
+        steps_per_unit = (steps_per_unit + 3) & ~3;   // ranges start on the step loop's group boundaries (groups of kAhead + 1 <= 4 steps)
         int m_units = (steps + steps_per_unit - 1) / steps_per_unit;
         if (m_units <= 1 || split_env == 0 ||
             !sfmhost::grid_fits((int64_t)grid_for(waves32, 256 / kWave) * (int64_t)m_units * ((batch + 7) / 8 * 8), 1, 256)) {
@@ -1359,7 +1373,7 @@ int sfm_score_sed_ex(const double* corr, int64_t n, const double* E, const int32
             steps_per_unit = steps;
         }
         const FilteredLaunch margs{(const Corr*)corr, ws, (int)n, E, S, (int)h_count, thr, order_env != 0 && h_count > (batch > 1 ? 64 : 2047), cnt, s1, s2,
-                                   buckets, order, batch, st, true, a_scale, m_units, steps_per_unit};
+                                   buckets, order, batch, st, true, a_scale, m_units, steps_per_unit, true, opt.persistent > 0};
         return launch_matrix(margs);
     }
     const FilteredLaunch args{(const Corr*)corr, ws, (int)n, E, S, (int)h_count, thr, use_order, cnt, s1, s2,

@@ -80,7 +80,7 @@ __device__ unsigned long long g_matrix_stats[4];
 #define SFM_MATRIX_STAMPS 0   // diagnostic build (tools/r04/matrix_timeline.py): s_memrealtime stamps of every wave's phases
 #endif
 #if SFM_MATRIX_STAMPS
-__device__ unsigned long long g_matrix_stamps[8 * 65536];   // begin, operands in, loop done, drained, samples fixed, handed off, hw id, wave
+__device__ unsigned long long g_matrix_stamps[10 * 65536];   // begin, operands in, loop done, drained, samples fixed, handed off, hw id, wave, exact-tier lane slots | points popped, shader clocks
 #define SFM_STAMP(k)                                                                     \
     do {                                                                                 \
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                      \
@@ -119,7 +119,13 @@ constexpr int64_t kMaxPoints = sfmws::kMatrixMaxPoints;
 static_assert(kMaxPoints / kTile <= 65536, "a queue entry keeps the step in 16 bits");
 
 __host__ __device__ inline int64_t steps_of(int64_t n) { return (n + kTile - 1) / kTile; }
-__host__ __device__ inline int64_t table_bytes(int64_t n) { return steps_of(n) * kBlocks * 64 * 16; }
+// Steps the point operand table holds: those of the points, rounded up to a multiple of four with PAD steps.  A row past the
+// last point carries zero operands and a NEGATIVE constant slot, so its "denominator" is negative whatever the hypothesis and the
+// sign test rejects it by itself: the step loop needs neither a mask for the ragged last step nor a test for the steps a group
+// of kAhead + 1 runs past the end of the points (two to four VALU instructions per step, in a loop that is bound by their issue).
+__host__ __device__ inline int64_t table_steps(int64_t n) { return sfmws::matrix_table_steps(n); }
+__host__ __device__ inline int64_t table_bytes(int64_t n) { return table_steps(n) * kBlocks * 64 * 16; }
+static_assert(SFM_MATRIX_AHEAD + 1 <= 4, "the table is padded to a multiple of four steps");
 // ... and an eighth of a smaller point set, but no fewer than 1024 points: the pre-pass is tier 1 over that share of the points
 __host__ __device__ inline int estimate_steps(int64_t n) {
     const int64_t eighth = steps_of(n) / 8;
@@ -199,13 +205,14 @@ SFM_DEVICE float hyp_slot_r(const float (&eh)[9], const float (&em)[9], int s) {
 
 // Operand table of the points: for step t (32 points), block b, lane l = 32 half + point: the 8 sixteen-bit values of slots
 // 8 half .. 8 half + 7 of block b — one coalesced 1 KiB load per block and step.  `ws` holds the data-set maxima (of the
-// coordinates scaled by c) that score_prepare_kernel left.  Rows past n are zero (they are masked out of the last step).
+// coordinates scaled by c) that score_prepare_kernel left.  Rows past n (the ragged last step, the pad steps) have zero operands
+// and a negative constant slot: the sign test rejects them under every hypothesis.
 __global__ __launch_bounds__(64) void matrix_prepare_kernel(const Corr* __restrict__ corr, int n, double c,
                                                            const unsigned char* __restrict__ ws, uint4* __restrict__ table) {
     const int64_t pair = blockIdx.y;
     corr += pair * (int64_t)n;
     ws += 16 * pair;                                   // this pair's maxima
-    table += pair * steps_of(n) * kBlocks * 64;
+    table += pair * table_steps(n) * kBlocks * 64;
     const int t = blockIdx.x;
     const int l = threadIdx.x;
     const int i = t * kTile + (l & 31);
@@ -242,7 +249,7 @@ __global__ __launch_bounds__(64) void matrix_prepare_kernel(const Corr* __restri
         const int s = 8 * half + j;
         float x = 0.0f;
         if (s < 12) x = bf_round(q[s]);
-        else if (s == 12) x = (i < n) ? (float)(sp * sp) : 0.0f;
+        else if (s == 12) x = (i < n) ? (float)(sp * sp) : -(float)(sp * sp);   // rows past the points: always rejected (a negative "denominator")
         v[j] = (__bf16)x;
     }
     table[((size_t)t * kBlocks + 2) * 64 + l] = __builtin_bit_cast(uint4, v);
@@ -461,6 +468,7 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
 #if SFM_MATRIX_STAMPS
     unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0};
     stamp[0] = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long clock_begin = __builtin_amdgcn_s_memtime();
 #endif
     const int h0 = wave * kHyps;
     if (h0 >= h_count) return;   // (no block-level synchronisation in this kernel)
@@ -501,7 +509,7 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
     int cur_base = 0;
     double a1 = 0.0, a2 = 0.0;
     // (my_queue: this lane's column of the wave's queue block in LDS — slot k at my_queue[k * kWave])
-#if SFM_MATRIX_STATS
+#if SFM_MATRIX_STATS || SFM_MATRIX_STAMPS
     unsigned stat_rounds = 0, stat_pops = 0, stat_push_iterations = 0;
 #endif
 
@@ -525,7 +533,7 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
             const int i = active[k] ? cur_base + (j & 3) + 8 * (j >> 2) : 0;
             p[k] = pts[i];
         }
-#if SFM_MATRIX_STATS
+#if SFM_MATRIX_STATS || SFM_MATRIX_STAMPS
         stat_rounds += kPops;
 #pragma unroll
         for (int k = 0; k < kPops; ++k) stat_pops += active[k] ? 1u : 0u;
@@ -542,15 +550,9 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
     };
 
     const int steps_total = (int)steps_of(n);
-    const int step_begin = units > 1 ? unit * steps_per_unit : 0;
+    const int step_begin = units > 1 ? unit * steps_per_unit : 0;   // (steps_per_unit is a multiple of kStages: ranges start on group boundaries)
     const int step_end = units > 1 || ESTIMATE ? min(step_begin + steps_per_unit, steps_total) : steps_total;
-    // rows of the LAST step that exist when the point count is no multiple of 32 (bit 15 - j: register j), computed once: inside
-    // the loop the sixteen comparisons cost 25 VGPRs of hoisted row offsets and bit constants — the registers a second step of
-    // operand loads in flight needs
-    unsigned tail_keep = 0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j)
-        tail_keep |= ((steps_total - 1) * kTile + (j & 3) + 8 * (j >> 2) + 4 * half < n) ? (1u << (15 - j)) : 0u;
+    const int last_loadable = (int)table_steps(n) - 1;
     unsigned survivors = 0;   // ESTIMATE
     if (step_begin < step_end) {
         const uint4* __restrict__ src = table + lane;
@@ -567,7 +569,7 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
 #pragma unroll
         for (int a = 0; a < kStages; ++a) {
 #pragma unroll
-            for (int b = 0; b < kBlocks; ++b) A[a][b] = src[((size_t)min(step_begin + a, step_end - 1) * kBlocks + b) * 64];
+            for (int b = 0; b < kBlocks; ++b) A[a][b] = src[((size_t)min(step_begin + a, last_loadable) * kBlocks + b) * 64];
             __builtin_amdgcn_sched_barrier(0);
         }
         int t0 = step_begin;
@@ -576,7 +578,7 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
          do {   // the hot loop: groups of kStages steps until a queue is full (or the range ends)
 #pragma unroll
           for (int stage = 0; stage < kStages; ++stage) {
-            const int t = t0 + stage;   // (steps past the range's end — at most kStages - 1 per wave — run on the last step's operands and keep nothing)
+            const int t = t0 + stage;   // (past the end of the points — at most kStages - 1 steps of the last range — these are the table's pad steps, which keep nothing)
             float16v r = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, d = r;
             r = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[stage][0]), B0, r, 0, 0, 0);
 #if !(SFM_MATRIX_ABLATE & 2)
@@ -597,16 +599,14 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
                 // copy of the old block 1, and a copy waits for the loads.  The empty asm makes the address depend on `keep`.
                 // (the OFFSET goes through the asm, not the pointer: a pointer coming out of an asm has lost its address space and
                 // the loads become flat_load, which the compiler can only wait for with vmcnt(0))
-                unsigned offset = (unsigned)min(t + kStages, step_end - 1) * (kBlocks * 64);
-                asm volatile("" : "+v"(offset), "+v"(keep));
+                unsigned offset = (unsigned)min(t + kStages, last_loadable) * (kBlocks * 64);   // (wave-uniform: stays in a scalar register)
+                asm volatile("" : "+s"(offset), "+v"(keep));
                 const uint4* nxt = src + offset;
 #if !(SFM_MATRIX_ABLATE & 1)
 #pragma unroll
                 for (int b = 0; b < kBlocks; ++b) A[stage][b] = nxt[b * 64];
 #endif
             }
-            if (t == steps_total - 1) keep &= tail_keep;   // (wave-uniform) the last step of a point count that is no multiple of 32
-            if (t >= step_end) keep = 0u;
             if (ESTIMATE) {
                 survivors += (unsigned)__builtin_popcount(keep);
             } else {
@@ -711,9 +711,16 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
         unsigned xcc_id;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
 #pragma unroll
-        for (int k = 0; k < 6; ++k) g_matrix_stamps[8 * wave_id + k] = stamp[k];
-        g_matrix_stamps[8 * wave_id + 6] = ((unsigned long long)xcc_id << 32) | hw_id;
-        g_matrix_stamps[8 * wave_id + 7] = ((unsigned long long)unit << 32) | (unsigned)h0;
+        for (int k = 0; k < 6; ++k) g_matrix_stamps[10 * wave_id + k] = stamp[k];
+        g_matrix_stamps[10 * wave_id + 6] = ((unsigned long long)xcc_id << 32) | hw_id;
+        g_matrix_stamps[10 * wave_id + 7] = ((unsigned long long)unit << 32) | (unsigned)h0;
+        g_matrix_stamps[10 * wave_id + 9] = __builtin_amdgcn_s_memtime() - clock_begin;
+    }
+    {   // exact-tier lane slots (rounds x pops, the same in every lane) and points popped, summed over the wave
+        unsigned long long pops = stat_pops;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) pops += __shfl_xor((unsigned)pops, off, 64);
+        if (lane == 0 && wave_id < 65536u) g_matrix_stamps[10 * wave_id + 8] = ((unsigned long long)stat_rounds << 32) | (unsigned)pops;
     }
 #endif
 }
@@ -725,7 +732,7 @@ __global__ __launch_bounds__(256) void matrix_fold_kernel(const unsigned char* _
     const int64_t pair = blockIdx.y;
     const int64_t hp = sfmws::split_padded(h_count);
     split += pair * sfmws::split_bytes(h_count);
-    fix += pair * sfmws::matrix_fix_bytes(h_count);
+    if (fix != nullptr) fix += pair * sfmws::matrix_fix_bytes(h_count);
     cnt += pair * (int64_t)h_count;
     s1 += pair * (int64_t)h_count;
     s2 += pair * (int64_t)h_count;
@@ -742,9 +749,14 @@ __global__ __launch_bounds__(256) void matrix_fold_kernel(const unsigned char* _
             t1 += part_a1[u * hp + h];
             t2 += part_a2[u * hp + h];
         }
-        cnt[h] = total + fix_c[h];
-        s1[h] = t1 + fix_a1[h];
-        s2[h] = t2 + fix_a1[hp + h];
+        if (fix != nullptr) {   // (the VALU-filter kernel corrects for its sample points itself)
+            total += fix_c[h];
+            t1 += fix_a1[h];
+            t2 += fix_a1[hp + h];
+        }
+        cnt[h] = total;
+        s1[h] = t1;
+        s2[h] = t2;
     }
 }
 
@@ -807,7 +819,7 @@ __global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
             a.split += pair * sfmws::split_bytes(h_count);
         }
         a.pts += pair * (int64_t)n;
-        a.table += pair * steps_of(n) * kBlocks * 64;
+        a.table += pair * table_steps(n) * kBlocks * 64;
         a.hyp_table += pair * (int64_t)h_count * 2 * kBlocks;
         a.E += pair * (int64_t)h_count * 9;
         if (a.order != nullptr) a.order += pair * (int64_t)h_count;

@@ -41,8 +41,8 @@ __host__ __device__ inline int64_t ws_order_offset(int64_t n, int64_t batch) {
     return ws_buckets_offset(n, batch) + ((4 * (int64_t)kBuckets * batch + 15) / 16) * 16;
 }
 // Range split of a single-pair launch (sfm_score.hip): a wave's hypotheses are scored over up to kSplitMaxUnits ranges of
-// the points by different waves.  Behind the scoring order: one arrival counter per hypothesis, then the ranges' partial
-// counts and sums —  [h_pad int32 arrivals][kSplitMaxUnits x h_pad int32][kSplitMaxUnits x h_pad f64][kSplitMaxUnits x h_pad f64]
+// the points by different waves.  Behind the scoring order: h_pad unused ints, then the ranges' partial
+// counts and sums —  [h_pad int32 unused][kSplitMaxUnits x h_pad int32][kSplitMaxUnits x h_pad f64][kSplitMaxUnits x h_pad f64]
 constexpr int kSplitMaxUnits = 16;
 __host__ __device__ inline int64_t split_padded(int64_t h_count) { return (h_count + 3) & ~(int64_t)3; }
 __host__ __device__ inline int64_t ws_split_offset(int64_t n, int64_t h_count) {   // batch == 1
@@ -51,56 +51,15 @@ __host__ __device__ inline int64_t ws_split_offset(int64_t n, int64_t h_count) {
 __host__ __device__ inline int64_t split_bytes(int64_t h_count) {
     return split_padded(h_count) * (4 + kSplitMaxUnits * (4 + 8 + 8));
 }
-// The hand-off itself, one lane per (hypothesis, range): publish this range's partial (count, sum, sum of squares) of
-// hypothesis h, count in on the hypothesis' arrival counter, and — in the lane that arrives last — add the partials of
-// all ranges in range order (a fixed order: the sums are the same from run to run).  Returns true in that lane, with the
-// totals in (c, a1, a2).  Ordering is the memory model's, not a hand-placed wait: the arrival is an ACQ_REL read-modify-write
-// at agent scope — its release half makes this lane's partial stores visible before the count, its acquire half makes
-// every earlier arriver's partials visible to the last one — the same form as select_sharded_kernel (sfm_kernels.hip).
-// The partials are agent-scope atomic accesses themselves, so neither side depends on what a vector L1 may hold.
-// score_split_reset_kernel zeroes the counters before each launch.
-// (-DSFM_SPLIT_HANDOFF_RELAXED=1 builds rounds 2-3's form — relaxed arrival behind a hand-written s_waitcnt — for the A/B.)
-#ifndef SFM_SPLIT_HANDOFF_RELAXED
-#define SFM_SPLIT_HANDOFF_RELAXED 0
-#endif
-__device__ __forceinline__ bool split_arrive_and_fold(unsigned char* __restrict__ split, int64_t h_count, int units, int unit,
-                                                      int64_t h, int& c, double& a1, double& a2) {
-    const int64_t hp = split_padded(h_count);
-    int32_t* arrivals = reinterpret_cast<int32_t*>(split);
-    int32_t* part_c = arrivals + hp;
-    double* part_a1 = reinterpret_cast<double*>(part_c + kSplitMaxUnits * hp);
-    double* part_a2 = part_a1 + kSplitMaxUnits * hp;
-    __hip_atomic_store(part_c + unit * hp + h, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(part_a1 + unit * hp + h, a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(part_a2 + unit * hp + h, a2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#if SFM_SPLIT_HANDOFF_RELAXED
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int arrived = __hip_atomic_fetch_add(arrivals + h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-    const int arrived = __hip_atomic_fetch_add(arrivals + h, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-    if (arrived != units - 1) return false;
-    int total = 0;
-    double t1 = 0.0, t2 = 0.0;
-    for (int uu = 0; uu < units; ++uu) {
-        const int pc = __hip_atomic_load(part_c + uu * hp + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const double p1 = __hip_atomic_load(part_a1 + uu * hp + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const double p2 = __hip_atomic_load(part_a2 + uu * hp + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        total += pc;
-        t1 = (uu == 0) ? p1 : t1 + p1;
-        t2 = (uu == 0) ? p2 : t2 + p2;
-    }
-    c = total;
-    a1 = t1;
-    a2 = t2;
-    return true;
-}
+// The partials are written with plain stores by the scoring kernels and added in range order by matrixscore::matrix_fold_kernel,
+// launched behind them (the arrival words are a leftover of the per-hypothesis counters of rounds 2-3 and are not used).
 // Operand tables of the matrix-pipe kernel (sfm_score_matrix.h; at most kMatrixMaxPoints points per pair), behind everything
 // else: per pair and step of 32 points three blocks of 64 lanes x 16 bytes (96 bytes per point), then per pair and hypothesis
 // 2 halves x 3 blocks x 16 bytes.
 constexpr int64_t kMatrixMaxPoints = 65536;
+__host__ __device__ inline int64_t matrix_table_steps(int64_t n) { return (((n + 31) / 32) + 3) & ~(int64_t)3; }   // (with pad steps: sfm_score_matrix.h)
 __host__ __device__ inline int64_t matrix_table_bytes(int64_t n) {   // one pair
-    return n <= kMatrixMaxPoints ? ((n + 31) / 32) * 3 * 64 * 16 : 0;
+    return n <= kMatrixMaxPoints ? matrix_table_steps(n) * 3 * 64 * 16 : 0;
 }
 __host__ __device__ inline int64_t matrix_hyp_table_bytes(int64_t n, int64_t h_count) {   // one pair
     return n <= kMatrixMaxPoints ? h_count * 96 : 0;

@@ -81,11 +81,11 @@ def test_score_options_are_set_by_the_caller_not_read_from_the_environment(nativ
     def values(o):
         return [getattr(o, f) for f in fields]
 
-    assert values(from_env({})) == [0, 0, -1, -1, -1, -1, -1, 0] == values(_native.ScoreOptions())
+    assert values(from_env({})) == [0, 0, -1, -1, -1, -1, -1, -1] == values(_native.ScoreOptions())
     env = {"SFM_SCORE_MATRIX": "1", "SFM_SCORE_HPW": "2", "SFM_SCORE_SPLIT": "3", "SFM_SCORE_ORDER": "0",
-           "SFM_SCORE_ONE_SIDED": "0", "SFM_SCORE_XCD": "0", "SFM_SCORE_SYNC": "4"}
+           "SFM_SCORE_ONE_SIDED": "0", "SFM_SCORE_XCD": "0", "SFM_SCORE_SYNC": "4", "SFM_SCORE_PERSISTENT": "0"}
     assert values(from_env(env)) == [2, 2, 3, 0, 0, 0, 4, 0]
-    assert values(from_env({"SFM_SCORE_MATRIX": "0", "SFM_SCORE_HPW": "3", "SFM_SCORE_SPLIT": "x"})) == [1, 0, -1, -1, -1, -1, -1, 0]
+    assert values(from_env({"SFM_SCORE_MATRIX": "0", "SFM_SCORE_HPW": "3", "SFM_SCORE_SPLIT": "x"})) == [1, 0, -1, -1, -1, -1, -1, -1]
     assert C.sizeof(_native.ScoreOptions) == 32
     before = _native.ScoreOptions()
     assert native_lib.sfm_score_get_default_options(C.byref(before)) == 0
@@ -103,7 +103,7 @@ def test_score_options_are_set_by_the_caller_not_read_from_the_environment(nativ
         assert native_lib.sfm_score_set_default_options(None) == 0           # NULL: the built-in defaults
         now = _native.ScoreOptions(kernel=2)
         native_lib.sfm_score_get_default_options(C.byref(now))
-        assert values(now) == [0, 0, -1, -1, -1, -1, -1, 0]
+        assert values(now) == [0, 0, -1, -1, -1, -1, -1, -1]
     finally:
         native_lib.sfm_score_set_default_options(C.byref(before))
     # no getenv left in the scoring translation unit

@@ -28,7 +28,7 @@ for _ in range(3):
     cnt, s1, s2 = dev.score_sed(corr, E, S, thr, workspace=ws)
 torch.cuda.synchronize()
 kernel_ms = before.elapsed_time(after)
-st = np.zeros((65536, 8), dtype=np.uint64)
+st = np.zeros((65536, 10), dtype=np.uint64)
 assert lib.sfm_debug_read_matrix_stamps(st.ctypes.data, 65536) == 0
 st = st[st[:, 0] != 0]
 if os.environ.get("STAMPS_OUT"):
@@ -48,6 +48,19 @@ for k, name in enumerate(names):
     print(f"  {name:45s} median {np.median(d):8.2f} us  mean {d.mean():8.2f}  p90 {np.percentile(d, 90):8.2f}  max {d.max():8.2f}  "
           f"share of all wave time {d.sum() / dur.sum():.3f}")
 unit = (st[:, 7] >> np.uint64(32)).astype(np.int64)
+h0 = (st[:, 7] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+slots = (st[:, 8] >> np.uint64(32)).astype(np.float64) * 64.0
+pops = (st[:, 8] & np.uint64(0xFFFFFFFF)).astype(np.float64)
+clock = st[:, 9].astype(np.float64) / np.maximum(dur, 1e-3) * 1e-3   # shader cycles per us -> GHz
+print(f"shader clock while a wave runs: median {np.median(clock):.2f} GHz, p10 {np.percentile(clock, 10):.2f}, p90 {np.percentile(clock, 90):.2f}")
+print(f"exact tier: {pops.sum():.4g} points popped in {slots.sum():.4g} lane slots -> lane utilisation {pops.sum() / max(slots.sum(), 1):.3f}")
+edges = [0, 2048, 4096, 6144, 8192, 16384, 32768, 65536, 1 << 30]
+for lo, hi in zip(edges[:-1], edges[1:]):
+    m = (h0 >= lo) & (h0 < hi)
+    if m.any():
+        print(f"  order slots {lo}-{min(hi, h)}: {int(m.sum())} items, lifetime median {np.median(dur[m]):7.1f} us (sum {dur[m].sum() / 1e3:7.1f} ms), "
+              f"popped {pops[m].sum():.3g} ({pops[m].sum() / max(pops.sum(), 1):.3f} of all), utilisation {pops[m].sum() / max(slots[m].sum(), 1):.3f}, "
+              f"drain median {np.median((T[:, 3] - T[:, 2])[m]):.1f} us, loop {np.median((T[:, 2] - T[:, 1])[m]):.1f}")
 for u in sorted(set(unit.tolist()))[:3] + [int(unit.max())]:
     m = unit == u
     print(f"  range {u}: {m.sum()} waves, lifetime median {np.median(dur[m]):.1f} us; sample fix-up median {np.median((T[:, 4] - T[:, 3])[m]):.1f}")
