@@ -202,6 +202,22 @@ int sfm_ransac_pass_small(uint64_t seed, const uint64_t* seed_dev, int use_philo
 int sfm_debug_matrix_filter(const double* corr, int64_t n, const double* E, int64_t h_count, double thr, void* workspace,
                             int64_t workspace_bytes, float* r_out, float* d_out, float* bound_out, void* stream);
 
+/* The same for a LARGE problem (one image pair, any n and h_count the separate calls take): sfm_sample_fit_philox /
+ * sfm_fit_eight_point -> sfm_score_sed -> sfm_select_best -> sfm_inlier_mask in EIGHT launches instead of eighteen where the
+ * matrix-pipe scoring kernel applies, with the same outputs (S, E, flags, cnt, result, mask bit for bit; s1 / s2 bit for
+ * bit too: the ranges of the scoring launch are added in the same order):
+ *   1  the eight-point fits;  2  partial maxima of the points + every zeroing the pass needs;  3  both operand tables of the
+ *   scoring kernel + the hypotheses' sample corrections;  4  cost pre-pass;  5  class histogram;  6  scan + scatter (the
+ *   heaviest-first order);  7  the scoring kernel;  8  fold of the point ranges + selection (ransac.py:75-86) over up to 256
+ *   blocks + the blocks that write the winner's inlier mask.
+ * Sizes for which sfm_score_sed picks another kernel run that call's launches followed by launch 8.  Arguments as for
+ * sfm_ransac_pass_small. */
+int sfm_ransac_pass_large(uint64_t seed, const uint64_t* seed_dev, int use_philox, int64_t h_begin, const double* corr,
+                          int64_t n, int64_t h_count, double thr, double min_extra, int aggregation, int64_t h_offset,
+                          int32_t* S, double* E, int32_t* flags, int32_t* cnt, double* s1, double* s2,
+                          sfm_select_result* result, uint8_t* mask, void* workspace, int64_t workspace_bytes,
+                          void* stream);
+
 /* Measurement hook: the next sfm_score_sed calls of the calling thread record the hipEvent_t `before` / `after`
  * (passed as void*, either may be NULL) on the launch stream immediately around the scoring kernel itself — not the
  * workspace preparation or the ordering pre-pass — so that a benchmark can time exactly the kernel a profiler

@@ -108,6 +108,8 @@ SIGNATURES = {
     "sfm_score_set_timing_events": [_P, _P],
     "sfm_ransac_pass_small": [_U64, _P, C.c_int, _I64, _P, _I64, _I64, _D, _D, C.c_int, _I64, _P, _P, _P, _P, _P, _P,
                               _P, _P, _P, _I64, _P],
+    "sfm_ransac_pass_large": [_U64, _P, C.c_int, _I64, _P, _I64, _I64, _D, _D, C.c_int, _I64, _P, _P, _P, _P, _P, _P,
+                              _P, _P, _P, _I64, _P],
     "sfm_select_best": [_P, _P, _P, _P, _I64, _I64, _D, C.c_int, _I64, _P, _P],
     "sfm_fold_select_records": [_P, _I64, _I64, _P, _P, _P, _P],
     "sfm_fold_select_records_host": [_P, _I64, _I64, _P, _P, _P],

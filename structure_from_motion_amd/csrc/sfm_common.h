@@ -76,6 +76,30 @@ double small_pass_a_scale(double thr);   // factor the prepared a-side coordinat
 int32_t* small_pass_order(unsigned char* workspace, int64_t n, int64_t h_count);
 int launch_small_score(const SmallPass& pass);
 
+// Scoring of a fused LARGE pass (sfm_ransac_pass_large, sfm_kernels.hip): sfm_score_sed's launches for one pair, except that a
+// range-split launch of the matrix-pipe kernel leaves its ranges' partials to be folded inside the pass's selection launch.
+struct LargeScore {
+    int units;                 // ranges of the points (<= 1: cnt / s1 / s2 are final)
+    unsigned char* split;      // their partials: sfm_score_ws.h, [range][hypothesis]
+    const unsigned char* fix;  // the hypotheses' sample corrections
+};
+struct LargePass {
+    const double* corr;
+    int64_t n;
+    const double* E;
+    const int32_t* S;
+    int64_t h_count;
+    double thr;
+    int32_t* cnt;
+    double* s1;
+    double* s2;
+    unsigned char* workspace;
+    int64_t workspace_bytes;
+    unsigned* select_state;    // 16 words the scoring launches zero for the selection launch (NULL: none)
+    hipStream_t stream;
+};
+int launch_large_score(const LargePass& pass, LargeScore* folded_later);
+
 }  // namespace sfmhost
 
 #define SFM_REQUIRE_GRID(fn, work, per_block, ...)                                                     \

@@ -608,6 +608,137 @@ __global__ __launch_bounds__(256) void select_sharded_kernel(
     }
 }
 
+// Selection launch of a fused LARGE pass (sfm_ransac_pass_large): select_sharded_kernel for any number of hypotheses — up to 256
+// selecting blocks walk them grid-stride — with the fold of a range-split scoring launch in front: a thread first adds the
+// partials of its hypotheses' ranges in range order and the sample correction (what matrix_fold_kernel does as a launch of its
+// own), writes cnt / s1 / s2, and selects from those totals.  State (arrival counter, flag, partial records) in the unused head of
+// the range-split region of the scoring workspace, zeroed by the pass's first scoring launch.
+constexpr int kLargeSelectBlocks = 256;
+__global__ __launch_bounds__(256) void select_large_kernel(
+    int32_t* __restrict__ cnt, double* __restrict__ s1, double* __restrict__ s2, const int32_t* __restrict__ flags,
+    int64_t h_count, int64_t h_offset, double min_extra, int aggregation, unsigned char* __restrict__ state,
+    sfm_select_result* __restrict__ result, int select_blocks, int units, const unsigned char* __restrict__ split,
+    const unsigned char* __restrict__ fix, const Corr* __restrict__ corr, int64_t n, const double* __restrict__ E,
+    const int32_t* __restrict__ S, double thr, uint8_t* __restrict__ mask) {
+    __shared__ sfmsel::SelectScratch<256> scratch;
+    __shared__ int last_block;
+    unsigned* counter = reinterpret_cast<unsigned*>(state);
+    unsigned* done = counter + kSelectDoneWord;
+    PartialSelect* partial = reinterpret_cast<PartialSelect*>(state + sfmws::kFusedPartialOffset);
+    if ((int)blockIdx.x >= select_blocks) {
+        // ---- mask block: points [256 * m, 256 * m + 256), as in select_sharded_kernel ----
+        const int64_t i = (int64_t)(blockIdx.x - select_blocks) * 256 + threadIdx.x;
+        const Corr p = corr[i < n ? i : n - 1];   // in flight while waiting
+        if (threadIdx.x == 0) {
+            // relaxed polls (each one a load that bypasses the caches, nothing else) and ONE acquire fence once the flag is up:
+            // with ~200 blocks polling, an acquire per poll invalidates the XCD's L2 under the selecting blocks' loads
+            int polls = 0;
+            while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && polls < kMaxFlagPolls) {
+                __builtin_amdgcn_s_sleep(16);
+                ++polls;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            last_block = polls < kMaxFlagPolls ? 1 : 0;   // reused as "record is there"
+        }
+        __syncthreads();
+        if (i >= n) return;
+        if (!last_block) {
+            mask[i] = 0xFF;
+            return;
+        }
+        const int64_t global_h = __hip_atomic_load(&result->best_h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int64_t h = global_h - h_offset;
+        if (global_h < 0 || h < 0 || h >= h_count) {
+            mask[i] = 0;
+            return;
+        }
+        double e[9];
+        bool in_sample = false;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) e[k] = E[h * 9 + k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) in_sample |= (S[h * 8 + k] == (int32_t)i);
+        const double sed = sfm::sed_value(e, p.xa, p.ya, p.xb, p.yb);
+        mask[i] = in_sample ? 2 : ((sed <= thr) ? 1 : 0);
+        return;
+    }
+    uint64_t key = kNoModelKey;
+    int64_t best = INT64_MAX, first_flag = INT64_MAX;
+    int n_flag = 0;
+    const int64_t hp = sfmws::split_padded(h_count);
+    const int32_t* part_c = units > 1 ? reinterpret_cast<const int32_t*>(split) + hp : nullptr;
+    const double* part_a1 = units > 1 ? reinterpret_cast<const double*>(part_c + sfmws::kSplitMaxUnits * hp) : nullptr;
+    const double* part_a2 = units > 1 ? part_a1 + sfmws::kSplitMaxUnits * hp : nullptr;
+    const int32_t* fix_c = reinterpret_cast<const int32_t*>(fix);
+    const double* fix_a1 = units > 1 ? reinterpret_cast<const double*>(fix + 4 * hp) : nullptr;
+    for (int64_t h = (int64_t)blockIdx.x * 256 + threadIdx.x; h < h_count; h += (int64_t)select_blocks * 256) {
+        if (units > 1) {   // the ranges in range order, then the sample correction: matrix_fold_kernel's sums, bit for bit
+            int total = part_c[h];
+            double t1 = part_a1[h], t2 = part_a2[h];
+            for (int u = 1; u < units; ++u) {
+                total += part_c[u * hp + h];
+                t1 += part_a1[u * hp + h];
+                t2 += part_a2[u * hp + h];
+            }
+            cnt[h] = total + fix_c[h];
+            s1[h] = t1 + fix_a1[h];
+            s2[h] = t2 + fix_a1[hp + h];
+        }
+        bool flagged = false;
+        const uint64_t k = hypothesis_key(cnt, s1, s2, flags, h, min_extra, aggregation, flagged);
+        if (k < key) {  // increasing h: strict < keeps the earliest
+            key = k;
+            best = h;
+        }
+        if (flagged) {
+            first_flag = h < first_flag ? h : first_flag;
+            ++n_flag;
+        }
+    }
+    sfmsel::block_combine<256>(key, best, first_flag, n_flag, scratch);
+    if (threadIdx.x == 0) {
+        PartialSelect* out = partial + blockIdx.x;
+        __hip_atomic_store(&out->key, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&out->best, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&out->first_flagged, first_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&out->n_flagged, (int32_t)n_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // arrival: release (this block's totals and partial record are visible before the count); the block that arrives last
+        // takes the acquire — one fence, not one per arrival
+        const unsigned arrived = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        last_block = arrived == (unsigned)select_blocks - 1 ? 1 : 0;
+        if (last_block) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (!last_block) return;
+    key = kNoModelKey;
+    best = INT64_MAX;
+    first_flag = INT64_MAX;
+    n_flag = 0;
+    if ((int)threadIdx.x < select_blocks) {
+        const PartialSelect p = partial[threadIdx.x];
+        key = p.key;
+        best = p.best;
+        first_flag = p.first_flagged;
+        n_flag = p.n_flagged;
+    }
+    sfmsel::block_combine<256>(key, best, first_flag, n_flag, scratch);
+    if (threadIdx.x == 0) {
+        const bool found = key != kNoModelKey && best != INT64_MAX;
+        __hip_atomic_store(&result->key, found ? key : kNoModelKey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&result->best_h, found ? best + h_offset : (int64_t)-1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&result->best_err, found ? __longlong_as_double((long long)key) : (double)INFINITY,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&result->first_flagged, first_flag != INT64_MAX ? first_flag + h_offset : INT64_MAX,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&result->n_flagged, (int32_t)n_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (the winner's count was written by another block of this launch: an agent-scope load, behind the acquire above)
+        __hip_atomic_store(&result->best_cnt,
+                           found ? __hip_atomic_load(cnt + best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // publishes the record above
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Inlier mask of the winner (ransac.py:70-76): 1 = surviving non-sample point, 2 = sample point.
 // ------------------------------------------------------------------------------------------------
@@ -929,6 +1060,56 @@ int sfm_ransac_pass_small(uint64_t seed, const uint64_t* seed_dev, int use_philo
                        min_extra, aggregation, state, result, select_blocks, (const Corr*)corr, n, (const double*)E,
                        (const int32_t*)S, thr, mask);
     return check_launch("select_sharded_kernel");
+}
+
+int sfm_ransac_pass_large(uint64_t seed, const uint64_t* seed_dev, int use_philox, int64_t h_begin, const double* corr,
+                          int64_t n, int64_t h_count, double thr, double min_extra, int aggregation, int64_t h_offset,
+                          int32_t* S, double* E, int32_t* flags, int32_t* cnt, double* s1, double* s2,
+                          sfm_select_result* result, uint8_t* mask, void* workspace, int64_t workspace_bytes,
+                          void* stream) {
+    if (n < 8 || n > 0x7FFFFFFF) return fail(SFM_EINVAL, "sfm_ransac_pass_large: need 8 <= n < 2^31");
+    if (h_count < 1 || h_count > 0x3FFFFFFF) return fail(SFM_EINVAL, "sfm_ransac_pass_large: need 1 <= h_count < 2^30");
+    if (h_begin < 0) return fail(SFM_EINVAL, "sfm_ransac_pass_large: negative h_begin");
+    if (aggregation < SFM_AGG_SUM || aggregation > SFM_AGG_RMS)
+        return fail(SFM_EINVAL, "sfm_ransac_pass_large: unknown aggregation");
+    if (!corr || !S || !E || !flags || !cnt || !s1 || !s2 || !result || !workspace)
+        return fail(SFM_EINVAL, "sfm_ransac_pass_large: null pointer");
+    if (workspace_bytes < sfm_score_workspace_bytes(n, h_count, 1))
+        return fail(SFM_EINVAL, "sfm_ransac_pass_large: workspace smaller than sfm_score_workspace_bytes(n, h_count, 1)");
+    if ((reinterpret_cast<uintptr_t>(workspace) & 15u) != 0)
+        return fail(SFM_EINVAL, "sfm_ransac_pass_large: workspace must be 16-byte aligned");
+    SFM_REQUIRE_GRID("sfm_ransac_pass_large", h_count, kWave, kWave, 1);
+    SFM_REQUIRE_GRID("sfm_ransac_pass_large (mask)", n, 256, 256);
+    hipStream_t st = (hipStream_t)stream;
+    // launch 1: the eight-point fits (Philox samples drawn in the kernel, or the caller's table in S)
+    hipLaunchKernelGGL(fit_eight_point_kernel<false>, dim3(grid_for(h_count, kWave), 1u), dim3(kWave), 0, st, (const Corr*)corr, n, S,
+                       h_count, E, flags, (double*)nullptr, (double*)nullptr,
+                       PhiloxSource{seed_dev, seed, 0, h_begin, use_philox ? 1 : 0}, SmallPrep{nullptr, 0.0, 0, nullptr});
+    int rc = check_launch("fit_eight_point_kernel (fused large pass)");
+    if (rc != SFM_OK) return rc;
+    // launches 2 .. 7: sfm_score_sed's — partial maxima + zeroing, both operand tables, cost pre-pass, class count, scan +
+    // scatter, the scoring kernel — with the ranges' partials left unfolded
+    unsigned char* ws = static_cast<unsigned char*>(workspace);
+    unsigned char* state = ws + sfmws::ws_split_offset(n, h_count);   // the unused head of the range-split region
+    const bool state_fits = 4 * sfmws::split_padded(h_count) >= sfmws::kFusedPartialOffset + kLargeSelectBlocks * (int64_t)sizeof(PartialSelect);
+    sfmhost::LargeScore folded_later{1, nullptr, nullptr};
+    rc = sfmhost::launch_large_score(sfmhost::LargePass{corr, n, E, S, h_count, thr, cnt, s1, s2, ws, workspace_bytes,
+                                                         state_fits ? reinterpret_cast<unsigned*>(state) : nullptr, st},
+                                     &folded_later);
+    if (rc != SFM_OK) return rc;
+    if (!state_fits) {   // a few hundred hypotheses: the separate selection and mask launches
+        rc = sfm_select_best(cnt, s1, s2, flags, h_count, 1, min_extra, aggregation, h_offset, result, stream);
+        if (rc != SFM_OK || mask == nullptr) return rc;
+        return sfm_inlier_mask(corr, n, E, S, h_count, 1, result, thr, mask, stream);
+    }
+    // launch 8: fold of the ranges + selection over up to 256 blocks + (behind them) the blocks that write the winner's mask
+    const int select_blocks = (int)std::min<int64_t>(kLargeSelectBlocks, (h_count + 511) / 512);
+    const int mask_blocks = mask != nullptr ? (int)((n + 255) / 256) : 0;
+    hipLaunchKernelGGL(select_large_kernel, dim3((unsigned)(select_blocks + mask_blocks)), dim3(256), 0, st, cnt, s1, s2,
+                       (const int32_t*)flags, h_count, h_offset, min_extra, aggregation, state, result, select_blocks,
+                       folded_later.units, (const unsigned char*)folded_later.split, folded_later.fix, (const Corr*)corr, n,
+                       (const double*)E, (const int32_t*)S, thr, mask);
+    return check_launch("select_large_kernel");
 }
 
 int sfm_fit_trace_doubles(void) { return kTraceDoubles; }

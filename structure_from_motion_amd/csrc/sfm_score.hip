@@ -523,6 +523,37 @@ __global__ __launch_bounds__(256) void score_class_scatter_kernel(const int32_t*
     if (cls >= 0) order[b * (int64_t)h_count + block_base[cls] + rank] = h;
 }
 
+// The same with the scan inside (one launch fewer): every block scans the 241 class counts itself — they are final, the count
+// kernel ran before — and claims its slots on a second word of each class' cache line (zeroed with the counters).
+__global__ __launch_bounds__(256) void score_class_scan_scatter_kernel(const int32_t* __restrict__ estimate, int h_count,
+                                                                       int32_t* __restrict__ buckets,
+                                                                       int32_t* __restrict__ order) {
+    __shared__ int scan[256];
+    __shared__ int block_count[256];
+    __shared__ int block_base[256];
+    const int64_t b = blockIdx.y;
+    const int c = threadIdx.x;
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    const int own = c < kClasses ? buckets[b * kBuckets + c * kClassStride] : 0;
+    scan[c] = own;
+    block_count[c] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int off = 1; off < 256; off <<= 1) {
+        const int below = c >= off ? scan[c - off] : 0;
+        __syncthreads();
+        scan[c] += below;
+        __syncthreads();
+    }
+    const int cls = h < h_count ? cost_class(estimate[b * (int64_t)h_count + h]) : -1;
+    const int rank = cls >= 0 ? atomicAdd(&block_count[cls], 1) : 0;
+    __syncthreads();
+    if (c < kClasses && block_count[c] != 0)
+        block_base[c] = scan[c] - own + atomicAdd(buckets + b * kBuckets + c * kClassStride + 1, block_count[c]);
+    __syncthreads();
+    if (cls >= 0) order[b * (int64_t)h_count + block_base[cls] + rank] = h;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Filtered kernel.
 // ------------------------------------------------------------------------------------------------
@@ -967,6 +998,8 @@ struct FilteredLaunch {
     int units, chunks_per_unit;   // range split (single pair): 1, 0 = off
     bool xcd_map = true;          // batches: all blocks of a pair on one XCD (options.xcd_map)
     bool persistent = true;       // matrix-pipe kernel, single pair: persistent waves (options.persistent)
+    unsigned* select_state = nullptr;          // fused pass: state words of its selection launch, zeroed with everything else
+    sfmhost::LargeScore* deferred = nullptr;   // fused pass: leave the ranges' partials to the selection launch, report them here
 };
 
 template <int HPW>
@@ -1072,13 +1105,26 @@ int launch_matrix(const FilteredLaunch& a) {
     using namespace matrixscore;
     const unsigned pairs = (unsigned)a.batch;
     const uint4* table = reinterpret_cast<const uint4*>(a.ws + ws_matrix_offset(a.n, a.h_count, a.batch));
-    hipLaunchKernelGGL(matrix_prepare_kernel, dim3((unsigned)table_steps(a.n), pairs), dim3(64), 0, a.st, a.corr, a.n, a.a_scale, a.ws,
-                       const_cast<uint4*>(table));
     static_assert(kBlocks * 2 * 16 == 96, "sfm_score_ws.h sizes the tables: 3 blocks");
     const uint4* hyp_table = reinterpret_cast<const uint4*>(a.ws + ws_matrix_hyp_offset(a.n, a.h_count, a.batch));
     unsigned char* fix = a.ws + ws_matrix_fix_offset(a.n, a.h_count, a.batch);   // the sample corrections, per pair
-    hipLaunchKernelGGL(matrix_hypothesis_kernel, dim3(grid_for(2 * (int64_t)a.h_count, 256), pairs), dim3(256), 0, a.st, a.ws, a.E,
-                       a.h_count, a.a_scale, const_cast<uint4*>(hyp_table), (float*)nullptr, a.corr, a.n, a.S, a.thr, fix);
+    const bool fused_setup = a.batch == 1;
+    if (fused_setup) {
+        // partial maxima (in the workspace's fp32-point region, which this kernel does not use) + all zeroing, then both tables
+        float4* partial = reinterpret_cast<float4*>(a.ws + ws_points_offset(1));
+        const unsigned setup_blocks = grid_stride(a.n, 1024, kSetupBlocks);
+        hipLaunchKernelGGL(matrix_setup_kernel, dim3(setup_blocks), dim3(256), 0, a.st, a.corr, a.n, a.a_scale, partial, a.buckets,
+                           a.cnt, a.h_count, a.select_state);
+        const int step_blocks = (int)((table_steps(a.n) + 3) / 4);
+        hipLaunchKernelGGL(matrix_tables_kernel, dim3((unsigned)step_blocks + grid_for(2 * (int64_t)a.h_count, 256)), dim3(256), 0, a.st,
+                           a.corr, a.n, a.a_scale, (const float4*)partial, (int)setup_blocks, const_cast<uint4*>(table), step_blocks, a.E,
+                           a.h_count, const_cast<uint4*>(hyp_table), a.S, a.thr, fix);
+    } else {
+        hipLaunchKernelGGL(matrix_prepare_kernel, dim3((unsigned)table_steps(a.n), pairs), dim3(64), 0, a.st, a.corr, a.n, a.a_scale,
+                           a.ws, const_cast<uint4*>(table));
+        hipLaunchKernelGGL(matrix_hypothesis_kernel, dim3(grid_for(2 * (int64_t)a.h_count, 256), pairs), dim3(256), 0, a.st, a.ws, a.E,
+                           a.h_count, a.a_scale, const_cast<uint4*>(hyp_table), (float*)nullptr, a.corr, a.n, a.S, a.thr, fix);
+    }
     // a single pair: persistent waves — as many blocks as the chip holds at once, every wave takes (group of 32 hypotheses,
     // range) items from a per-XCD counter (see the kernel); the counters were zeroed with the class counters
     const bool persistent = a.batch == 1 && a.persistent;
@@ -1095,7 +1141,7 @@ int launch_matrix(const FilteredLaunch& a) {
         // `cnt`, which the scoring launch rewrites), then the counting sort by class
         const int e_steps = estimate_steps(a.n);
         const int e_units = a.batch == 1 && e_steps >= 128 ? 4 : 1;   // a single pair: four ranges of the pre-pass's steps
-        if (e_units > 1)
+        if (e_units > 1 && !fused_setup)   // (the ranges of the pre-pass add into `cnt`: zeroed by matrix_setup_kernel otherwise)
             hipLaunchKernelGGL(score_split_reset_kernel, dim3(grid_stride(a.h_count, 256, 1024)), dim3(256), 0, a.st, a.cnt,
                                (int64_t)a.h_count);
         hipLaunchKernelGGL(score_sed_matrix_kernel<true>, dim3(flat * (unsigned)e_units), dim3(256), 0, a.st, a.corr, hyp_table, table,
@@ -1103,8 +1149,7 @@ int launch_matrix(const FilteredLaunch& a) {
                            (unsigned char*)nullptr, (const unsigned char*)nullptr, (int)a.batch, blocks_per_pair, (int32_t*)nullptr);
         const dim3 per_hyp(grid_for(a.h_count, 256), pairs);
         hipLaunchKernelGGL(score_class_count_kernel, per_hyp, dim3(256), 0, a.st, a.cnt, a.h_count, a.buckets);
-        hipLaunchKernelGGL(score_class_scan_kernel, dim3(pairs), dim3(256), 0, a.st, a.buckets, a.batch);
-        hipLaunchKernelGGL(score_class_scatter_kernel, per_hyp, dim3(256), 0, a.st, a.cnt, a.h_count, a.buckets, a.order);
+        hipLaunchKernelGGL(score_class_scan_scatter_kernel, per_hyp, dim3(256), 0, a.st, a.cnt, a.h_count, a.buckets, a.order);
         const int rc = check_launch("score order kernels");
         if (rc != SFM_OK) return rc;
         order_arg = a.order;
@@ -1118,9 +1163,12 @@ int launch_matrix(const FilteredLaunch& a) {
                        a.E, a.h_count, a.thr, order_arg, a.cnt, a.s1, a.s2, a.units, a.chunks_per_unit, split, fix,
                        (int)a.batch, blocks_per_pair * a.units, persistent ? a.buckets + kTicketWords : (int32_t*)nullptr);
     if (g_event_after) (void)hipEventRecord(g_event_after, a.st);
-    if (a.units > 1)
+    if (a.deferred != nullptr) {   // a fused pass folds the ranges inside its selection launch
+        *a.deferred = sfmhost::LargeScore{a.units, split, fix};
+    } else if (a.units > 1) {
         hipLaunchKernelGGL(matrix_fold_kernel, dim3(grid_stride(a.h_count, 256, 1024), pairs), dim3(256), 0, a.st, split, fix, a.units,
                            a.h_count, a.cnt, a.s1, a.s2);
+    }
     return check_launch("score_sed_matrix_kernel");
 }
 
@@ -1190,6 +1238,12 @@ extern "C" int sfm_debug_read_wave_stamps(unsigned long long* out, int64_t waves
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_stamps), 32 * (size_t)waves) == hipSuccess ? 0 : -2;
 }
 #endif
+
+namespace {
+int score_sed_impl(const double* corr, int64_t n, const double* E, const int32_t* S, int64_t h_count, int64_t batch, double thr,
+                   int32_t* cnt, double* s1, double* s2, void* workspace, int64_t workspace_bytes, void* stream,
+                   const sfm_score_options& opt, unsigned* select_state, sfmhost::LargeScore* deferred);
+}
 
 extern "C" {
 
@@ -1270,6 +1324,16 @@ int sfm_score_sed_ex(const double* corr, int64_t n, const double* E, const int32
                      int64_t workspace_bytes, void* stream, const sfm_score_options* options) {
     const sfm_score_options opt = resolve_options(options);
     if (!valid_options(opt)) return fail(SFM_EINVAL, "sfm_score_sed_ex: an option is out of range");
+    return score_sed_impl(corr, n, E, S, h_count, batch, thr, cnt, s1, s2, workspace, workspace_bytes, stream, opt, nullptr, nullptr);
+}
+
+}  // extern "C"
+
+namespace {
+
+int score_sed_impl(const double* corr, int64_t n, const double* E, const int32_t* S, int64_t h_count, int64_t batch, double thr,
+                   int32_t* cnt, double* s1, double* s2, void* workspace, int64_t workspace_bytes, void* stream,
+                   const sfm_score_options& opt, unsigned* select_state, sfmhost::LargeScore* deferred) {
     if (h_count < 0 || batch < 0 || n < 0) return fail(SFM_EINVAL, "sfm_score_sed: negative size");
     if (n > 0x7FFFFFFF || h_count > 0x3FFFFFFF) return fail(SFM_EINVAL, "sfm_score_sed: size too large");
     if (h_count == 0 || batch == 0) return SFM_OK;
@@ -1316,15 +1380,20 @@ int sfm_score_sed_ex(const double* corr, int64_t n, const double* E, const int32
     // Small point sets are prepared by one block per pair, which stores the maxima itself; the zeroing kernel is then
     // only needed for the class counters of the ordering pre-pass (a small pass is a chain of ~4 us launches).
     const unsigned prepare_blocks = n <= 8192 ? 1u : grid_stride(n, 256, 64);
-    if (use_order || matrix || prepare_blocks > 1)
-        hipLaunchKernelGGL(score_reset_kernel, dim3((unsigned)batch), dim3(256), 0, st, ws, buckets);
     // options.one_sided = 0 switches tier 1 of the VALU filter back to the two-sided test (ablation)
     const bool one_sided = opt.one_sided != 0;
     const double a_scale = matrix ? matrixscore::scale_for(thr) : (one_sided ? one_sided_scale(thr) : 1.0);
-    hipLaunchKernelGGL(score_prepare_kernel, dim3(prepare_blocks, (unsigned)batch), dim3(256), 0, st,
-                       (const Corr*)corr, n, a_scale, ws);
-    int rc = check_launch("score_prepare_kernel");
-    if (rc != SFM_OK) return rc;
+    // (one pair on the matrix-pipe kernel: launch_matrix prepares everything itself in two launches — partial maxima + zeroing,
+    // then both operand tables — instead of reset / prepare / point table / hypothesis table / estimate zeroing)
+    const bool fused_setup = matrix && batch == 1;
+    if (!fused_setup) {
+        if (use_order || matrix || prepare_blocks > 1)
+            hipLaunchKernelGGL(score_reset_kernel, dim3((unsigned)batch), dim3(256), 0, st, ws, buckets);
+        hipLaunchKernelGGL(score_prepare_kernel, dim3(prepare_blocks, (unsigned)batch), dim3(256), 0, st,
+                           (const Corr*)corr, n, a_scale, ws);
+        const int rc = check_launch("score_prepare_kernel");
+        if (rc != SFM_OK) return rc;
+    }
     // Range split: a single-pair launch of 3 to 8 generations of waves (5120 each) is cut into 2 ranges of the points, so
     // that its last generation — a whole wave duration of draining chip — is half as long: 2.233-2.240 ms against
     // 2.279-2.297 ms at 50 000 x 100 000 (4.9 generations), 2.803 vs 2.831 at 125 000 hypotheses (6.1).  Four ranges
@@ -1373,9 +1442,14 @@ int sfm_score_sed_ex(const double* corr, int64_t n, const double* E, const int32
             steps_per_unit = steps;
         }
         const FilteredLaunch margs{(const Corr*)corr, ws, (int)n, E, S, (int)h_count, thr, order_env != 0 && h_count > (batch > 1 ? 64 : 2047), cnt, s1, s2,
-                                   buckets, order, batch, st, true, a_scale, m_units, steps_per_unit, true, opt.persistent > 0};
+                                   buckets, order, batch, st, true, a_scale, m_units, steps_per_unit, true, opt.persistent > 0,
+                                   fused_setup ? select_state : nullptr, fused_setup ? deferred : nullptr};
+        if (select_state != nullptr && !fused_setup)
+            hipLaunchKernelGGL(score_split_reset_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<int32_t*>(select_state), (int64_t)16);
         return launch_matrix(margs);
     }
+    if (select_state != nullptr)
+        hipLaunchKernelGGL(score_split_reset_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<int32_t*>(select_state), (int64_t)16);
     const FilteredLaunch args{(const Corr*)corr, ws, (int)n, E, S, (int)h_count, thr, use_order, cnt, s1, s2,
                               buckets, order, batch, st, one_sided, a_scale, units, chunks_per_unit, opt.xcd_map != 0};
     switch (hpw) {
@@ -1385,4 +1459,17 @@ int sfm_score_sed_ex(const double* corr, int64_t n, const double* E, const int32
     }
 }
 
-}  // extern "C"
+}  // namespace
+
+namespace sfmhost {
+
+int launch_large_score(const LargePass& p, LargeScore* folded_later) {
+    *folded_later = LargeScore{1, nullptr, nullptr};   // (stays so unless the matrix-pipe kernel split the points into ranges)
+    const sfm_score_options opt = resolve_options(nullptr);
+    if (p.h_count < 1 || p.n < 8 || p.n > 0x7FFFFFFF || p.h_count > 0x3FFFFFFF)
+        return fail(SFM_EINVAL, "sfm_ransac_pass_large: sizes out of range");
+    return score_sed_impl(p.corr, p.n, p.E, p.S, p.h_count, 1, p.thr, p.cnt, p.s1, p.s2, p.workspace, p.workspace_bytes, p.stream, opt,
+                          p.select_state, folded_later);
+}
+
+}  // namespace sfmhost

@@ -207,18 +207,12 @@ SFM_DEVICE float hyp_slot_r(const float (&eh)[9], const float (&em)[9], int s) {
 // 8 half .. 8 half + 7 of block b — one coalesced 1 KiB load per block and step.  `ws` holds the data-set maxima (of the
 // coordinates scaled by c) that score_prepare_kernel left.  Rows past n (the ragged last step, the pad steps) have zero operands
 // and a negative constant slot: the sign test rejects them under every hypothesis.
-__global__ __launch_bounds__(64) void matrix_prepare_kernel(const Corr* __restrict__ corr, int n, double c,
-                                                           const unsigned char* __restrict__ ws, uint4* __restrict__ table) {
-    const int64_t pair = blockIdx.y;
-    corr += pair * (int64_t)n;
-    ws += 16 * pair;                                   // this pair's maxima
-    table += pair * table_steps(n) * kBlocks * 64;
-    const int t = blockIdx.x;
-    const int l = threadIdx.x;
+SFM_DEVICE void prepare_step(const Corr* __restrict__ corr, int n, double c, const uint32_t* maxima, uint4* __restrict__ table,
+                             int t, int l) {
     const int i = t * kTile + (l & 31);
     const int half = l >> 5;
     float M[9];
-    const DataScale data = data_scale(reinterpret_cast<const uint32_t*>(ws), (float)c * (1.0f + 1e-6f), M);
+    const DataScale data = data_scale(maxima, (float)c * (1.0f + 1e-6f), M);
     const double sp = (double)data.sp;
     float mh[9], mm[9], q[12];
 #pragma unroll
@@ -254,6 +248,12 @@ __global__ __launch_bounds__(64) void matrix_prepare_kernel(const Corr* __restri
     }
     table[((size_t)t * kBlocks + 2) * 64 + l] = __builtin_bit_cast(uint4, v);
 }
+__global__ __launch_bounds__(64) void matrix_prepare_kernel(const Corr* __restrict__ corr, int n, double c,
+                                                           const unsigned char* __restrict__ ws, uint4* __restrict__ table) {
+    const int64_t pair = blockIdx.y;   // (`ws`: the pair's maxima as score_prepare_kernel left them)
+    prepare_step(corr + pair * (int64_t)n, n, c, reinterpret_cast<const uint32_t*>(ws + 16 * pair),
+                 table + pair * table_steps(n) * kBlocks * 64, (int)blockIdx.x, (int)threadIdx.x);
+}
 
 // Operand table of the hypotheses: for hypothesis h and half (0: slots 0..7, 1: slots 8..15 of each block) the three B
 // fragments of tier 1 — the scaled fp16 hi / mid split of E for the two r' blocks and the bf16 dB form with its absolute terms
@@ -263,27 +263,17 @@ __global__ __launch_bounds__(64) void matrix_prepare_kernel(const Corr* __restri
 // always summed (ransac.py:70-79), while the scoring scan treats them like any other point — so for each sample point with
 // sed <= thr the count drops by one, and the others add their sed / sed^2 to the sums.  Four samples per thread (their gathers in
 // flight together), the two threads of a hypothesis added first half + second half: fix = [h_pad] int32 | [h_pad] f64 | [h_pad] f64.
-__global__ __launch_bounds__(256) void matrix_hypothesis_kernel(const unsigned char* __restrict__ ws, const double* __restrict__ E,
-                                                                int h_count, double a_scale, uint4* __restrict__ hyp_table,
-                                                                float* __restrict__ bound_out, const Corr* __restrict__ pts, int n,
-                                                                const int32_t* __restrict__ S, double thr,
-                                                                unsigned char* __restrict__ fix) {
-    const int64_t item_raw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+SFM_DEVICE void prepare_hypothesis(const uint32_t* maxima, const double* __restrict__ E, int h_count, double a_scale,
+                                   uint4* __restrict__ hyp_table, float* __restrict__ bound_out, const Corr* __restrict__ pts,
+                                   const int32_t* __restrict__ S, double thr, unsigned char* __restrict__ fix, int64_t item_raw) {
     const bool live = item_raw < 2 * (int64_t)h_count;
     const int64_t item = live ? item_raw : 2 * (int64_t)h_count - 1;   // (the tail threads shadow the last one: the pair sums below are wave operations)
-    const int64_t pair = blockIdx.y;
-    ws += 16 * pair;                                   // this pair's maxima
-    E += pair * (int64_t)h_count * 9;
-    hyp_table += pair * (int64_t)h_count * 2 * kBlocks;
     const int64_t h = item >> 1;
     const int half = (int)(item & 1);
     double e[9];
 #pragma unroll
     for (int j = 0; j < 9; ++j) e[j] = E[(int64_t)h * 9 + j];
     if (fix != nullptr) {
-        pts += pair * (int64_t)n;
-        S += pair * (int64_t)h_count * 8;
-        fix += pair * sfmws::matrix_fix_bytes(h_count);
         const int4 sample = *reinterpret_cast<const int4*>(S + h * 8 + 4 * half);
         const Corr p[4] = {pts[sample.x], pts[sample.y], pts[sample.z], pts[sample.w]};
         int dc = 0;
@@ -309,7 +299,7 @@ __global__ __launch_bounds__(256) void matrix_hypothesis_kernel(const unsigned c
     if (!live) return;
     constexpr float up = 1.0f + 1e-5f;
     float M[9];
-    const DataScale data = data_scale(reinterpret_cast<const uint32_t*>(ws), (float)a_scale * (1.0f + 1e-6f), M);
+    const DataScale data = data_scale(maxima, (float)a_scale * (1.0f + 1e-6f), M);
     const float sp = data.sp;
     float emax = 0.f, poison = 0.f;
 #pragma unroll
@@ -368,7 +358,7 @@ __global__ __launch_bounds__(256) void matrix_hypothesis_kernel(const unsigned c
             B2[j] = (__bf16)x;
         }
         if (bound_out != nullptr && half == 0) {   // diagnostic (sfm_debug_matrix_filter): what the bound of this hypothesis is made of
-            float* b = bound_out + (pair * (int64_t)h_count + h) * 8;
+            float* b = bound_out + h * 8;
             b[0] = delta;
             b[1] = slack;
             b[2] = sh;
@@ -384,6 +374,98 @@ __global__ __launch_bounds__(256) void matrix_hypothesis_kernel(const unsigned c
     out[0] = __builtin_bit_cast(uint4, B0);
     out[1] = __builtin_bit_cast(uint4, B1);
     out[2] = __builtin_bit_cast(uint4, B2);
+}
+__global__ __launch_bounds__(256) void matrix_hypothesis_kernel(const unsigned char* __restrict__ ws, const double* __restrict__ E,
+                                                                int h_count, double a_scale, uint4* __restrict__ hyp_table,
+                                                                float* __restrict__ bound_out, const Corr* __restrict__ pts, int n,
+                                                                const int32_t* __restrict__ S, double thr,
+                                                                unsigned char* __restrict__ fix) {
+    const int64_t pair = blockIdx.y;   // (`ws`: the pair's maxima)
+    prepare_hypothesis(reinterpret_cast<const uint32_t*>(ws + 16 * pair), E + pair * (int64_t)h_count * 9, h_count, a_scale,
+                       hyp_table + pair * (int64_t)h_count * 2 * kBlocks,
+                       bound_out != nullptr ? bound_out + pair * (int64_t)h_count * 8 : nullptr, pts + pair * (int64_t)n,
+                       S != nullptr ? S + pair * (int64_t)h_count * 8 : nullptr, thr,
+                       fix != nullptr ? fix + pair * sfmws::matrix_fix_bytes(h_count) : nullptr,
+                       (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// ---- one pair: the preparation in TWO launches instead of five (a pass is a chain of dependent launches of 4-15 us each) ----
+// Launch 1 (matrix_setup_kernel): per-block partial maxima of the scaled coordinates — plain stores, folded by the blocks of
+// launch 2, so no atomics and nothing to zero first — and the zeroing the later launches need: class counters and their
+// cursors, the cost estimates (`cnt`: the pre-pass adds its ranges' counts), the state words of the pass's selection launch.
+constexpr int kSetupBlocks = 256;   // at most this many partial maxima (one per block; blocks walk the points grid-stride)
+__global__ __launch_bounds__(256) void matrix_setup_kernel(const Corr* __restrict__ corr, int n, double a_scale,
+                                                           float4* __restrict__ partial, int32_t* __restrict__ buckets,
+                                                           int32_t* __restrict__ cnt, int h_count, unsigned* __restrict__ state) {
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+    const int stride = gridDim.x * blockDim.x, first = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int i = first; i < n; i += stride) {
+        const float4 q = sfmws::to_filter_point(corr[i], a_scale);   // NaN coordinates: fmaxf ignores them (such points fail the filter's test)
+        m0 = fmaxf(m0, fabsf(q.x));
+        m1 = fmaxf(m1, fabsf(q.y));
+        m2 = fmaxf(m2, fabsf(q.z));
+        m3 = fmaxf(m3, fabsf(q.w));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        m0 = fmaxf(m0, __shfl_xor(m0, off, 64));
+        m1 = fmaxf(m1, __shfl_xor(m1, off, 64));
+        m2 = fmaxf(m2, __shfl_xor(m2, off, 64));
+        m3 = fmaxf(m3, __shfl_xor(m3, off, 64));
+    }
+    __shared__ float part[4][4];
+    const int w = threadIdx.x / kWave;
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        part[w][0] = m0; part[w][1] = m1; part[w][2] = m2; part[w][3] = m3;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        partial[blockIdx.x] = make_float4(fmaxf(fmaxf(part[0][0], part[1][0]), fmaxf(part[2][0], part[3][0])),
+                                          fmaxf(fmaxf(part[0][1], part[1][1]), fmaxf(part[2][1], part[3][1])),
+                                          fmaxf(fmaxf(part[0][2], part[1][2]), fmaxf(part[2][2], part[3][2])),
+                                          fmaxf(fmaxf(part[0][3], part[1][3]), fmaxf(part[2][3], part[3][3])));
+    for (int i = first; i < sfmws::kBuckets; i += stride) buckets[i] = 0;
+    if (cnt != nullptr)
+        for (int i = first; i < h_count; i += stride) cnt[i] = 0;
+    if (state != nullptr && first < 16) state[first] = 0u;
+}
+
+// Launch 2 (matrix_tables_kernel): every block folds the partial maxima (<= 256 x 16 bytes) and then writes its share of
+// the point operand table (four steps per block) or of the hypothesis operand table and the sample corrections.
+__global__ __launch_bounds__(256) void matrix_tables_kernel(const Corr* __restrict__ corr, int n, double a_scale,
+                                                            const float4* __restrict__ partial, int partials, uint4* __restrict__ table,
+                                                            int step_blocks, const double* __restrict__ E, int h_count,
+                                                            uint4* __restrict__ hyp_table, const int32_t* __restrict__ S, double thr,
+                                                            unsigned char* __restrict__ fix) {
+    __shared__ float part[4][4];
+    __shared__ uint32_t maxima[4];
+    {
+        const float4 m = (int)threadIdx.x < partials ? partial[threadIdx.x] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float m0 = m.x, m1 = m.y, m2 = m.z, m3 = m.w;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            m0 = fmaxf(m0, __shfl_xor(m0, off, 64));
+            m1 = fmaxf(m1, __shfl_xor(m1, off, 64));
+            m2 = fmaxf(m2, __shfl_xor(m2, off, 64));
+            m3 = fmaxf(m3, __shfl_xor(m3, off, 64));
+        }
+        const int w = threadIdx.x / kWave;
+        if ((threadIdx.x & (kWave - 1)) == 0) {
+            part[w][0] = m0; part[w][1] = m1; part[w][2] = m2; part[w][3] = m3;
+        }
+        __syncthreads();
+        if (threadIdx.x < 4)
+            maxima[threadIdx.x] = __float_as_uint(fmaxf(fmaxf(part[0][threadIdx.x], part[1][threadIdx.x]),
+                                                        fmaxf(part[2][threadIdx.x], part[3][threadIdx.x])));
+        __syncthreads();
+    }
+    if ((int)blockIdx.x < step_blocks) {
+        const int t = (int)blockIdx.x * 4 + (int)(threadIdx.x / kWave);
+        if (t < (int)table_steps(n)) prepare_step(corr, n, a_scale, maxima, table, t, (int)(threadIdx.x & (kWave - 1)));
+        return;
+    }
+    prepare_hypothesis(maxima, E, h_count, a_scale, hyp_table, nullptr, corr, S, thr, fix,
+                       (int64_t)((int)blockIdx.x - step_blocks) * 256 + threadIdx.x);
 }
 
 // Diagnostic (sfm_debug_matrix_filter; tests/test_gpu_parity.py measures the bound's margin with it): tier 1 of ONE 32 x 32 tile

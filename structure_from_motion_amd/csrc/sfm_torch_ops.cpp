@@ -244,10 +244,14 @@ std::tuple<Tensor, Tensor, Tensor> score_sed_meta(const Tensor& corr, const Tens
 }
 
 // ---- fused small pass (two launches: fit + workspace preparation, scoring + selection + mask) -------------------
-void ransac_pass_small_out(const Tensor& corr, int64_t seed, const std::optional<Tensor>& seed_dev, bool use_philox,
-                           int64_t h_begin, double thr, double min_extra, int64_t aggregation, int64_t h_offset,
-                           Tensor& S, Tensor& E, Tensor& flags, Tensor& cnt, Tensor& s1, Tensor& s2, Tensor& result,
-                           const std::optional<Tensor>& mask, Tensor& workspace) {
+using PassEntry = int (*)(uint64_t, const uint64_t*, int, int64_t, const double*, int64_t, int64_t, double, double, int, int64_t,
+                          int32_t*, double*, int32_t*, int32_t*, double*, double*, sfm_select_result*, uint8_t*, void*, int64_t,
+                          void*);
+template <PassEntry ENTRY>
+void ransac_pass_out(const char* name, const Tensor& corr, int64_t seed, const std::optional<Tensor>& seed_dev, bool use_philox,
+                     int64_t h_begin, double thr, double min_extra, int64_t aggregation, int64_t h_offset,
+                     Tensor& S, Tensor& E, Tensor& flags, Tensor& cnt, Tensor& s1, Tensor& s2, Tensor& result,
+                     const std::optional<Tensor>& mask, Tensor& workspace) {
     const OpDevice scope(corr);
     need(corr, "corr", at::kDouble);
     need(S, "S", at::kInt);
@@ -261,18 +265,33 @@ void ransac_pass_small_out(const Tensor& corr, int64_t seed, const std::optional
     if (seed_dev.has_value()) need(*seed_dev, "seed_dev", at::kLong);
     if (mask.has_value()) need(*mask, "mask", at::kByte);
     const Dims d = hypothesis_dims(corr, S);
-    TORCH_CHECK(d.batch == 1, "sfm_hip::ransac_pass_small_: one image pair per call");
+    TORCH_CHECK(d.batch == 1, "sfm_hip::", name, "_: one image pair per call");
     check_E(E, d);
     TORCH_CHECK(flags.numel() == d.h && cnt.numel() == d.h && s1.numel() == d.h && s2.numel() == d.h,
                 "sfm_hip: flags, cnt, s1, s2 must be [1, h]");
     TORCH_CHECK(result.numel() == kRecordWords, "sfm_hip: result must be int64 [1, 5]");
     TORCH_CHECK(!mask.has_value() || mask->numel() == d.n, "sfm_hip: mask must be uint8 [1, n]");
-    ok(sfm_ransac_pass_small((uint64_t)seed, reinterpret_cast<const uint64_t*>(ptr<int64_t>(seed_dev)), use_philox ? 1 : 0,
-                             h_begin, ptr<double>(corr), d.n, d.h, thr, min_extra, (int)aggregation, h_offset,
-                             ptr<int32_t>(S), ptr<double>(E), ptr<int32_t>(flags), ptr<int32_t>(cnt), ptr<double>(s1),
-                             ptr<double>(s2), reinterpret_cast<sfm_select_result*>(ptr<int64_t>(result)),
-                             ptr<uint8_t>(mask), ptr<unsigned char>(workspace), workspace.numel(), current_stream()),
-       "sfm_ransac_pass_small");
+    ok(ENTRY((uint64_t)seed, reinterpret_cast<const uint64_t*>(ptr<int64_t>(seed_dev)), use_philox ? 1 : 0,
+             h_begin, ptr<double>(corr), d.n, d.h, thr, min_extra, (int)aggregation, h_offset,
+             ptr<int32_t>(S), ptr<double>(E), ptr<int32_t>(flags), ptr<int32_t>(cnt), ptr<double>(s1),
+             ptr<double>(s2), reinterpret_cast<sfm_select_result*>(ptr<int64_t>(result)),
+             ptr<uint8_t>(mask), ptr<unsigned char>(workspace), workspace.numel(), current_stream()),
+       name);
+}
+void ransac_pass_small_out(const Tensor& corr, int64_t seed, const std::optional<Tensor>& seed_dev, bool use_philox,
+                           int64_t h_begin, double thr, double min_extra, int64_t aggregation, int64_t h_offset,
+                           Tensor& S, Tensor& E, Tensor& flags, Tensor& cnt, Tensor& s1, Tensor& s2, Tensor& result,
+                           const std::optional<Tensor>& mask, Tensor& workspace) {
+    ransac_pass_out<&sfm_ransac_pass_small>("sfm_ransac_pass_small", corr, seed, seed_dev, use_philox, h_begin, thr, min_extra,
+                                            aggregation, h_offset, S, E, flags, cnt, s1, s2, result, mask, workspace);
+}
+// ---- fused large pass (eight launches: see sfm_hip.h) ------------------------------------------------------------
+void ransac_pass_large_out(const Tensor& corr, int64_t seed, const std::optional<Tensor>& seed_dev, bool use_philox,
+                           int64_t h_begin, double thr, double min_extra, int64_t aggregation, int64_t h_offset,
+                           Tensor& S, Tensor& E, Tensor& flags, Tensor& cnt, Tensor& s1, Tensor& s2, Tensor& result,
+                           const std::optional<Tensor>& mask, Tensor& workspace) {
+    ransac_pass_out<&sfm_ransac_pass_large>("sfm_ransac_pass_large", corr, seed, seed_dev, use_philox, h_begin, thr, min_extra,
+                                            aggregation, h_offset, S, E, flags, cnt, s1, s2, result, mask, workspace);
 }
 
 // ---- select_best -----------------------------------------------------------------------------------------------
@@ -396,6 +415,9 @@ TORCH_LIBRARY(sfm_hip, m) {
     m.def("ransac_pass_small_(Tensor corr, int seed, Tensor? seed_dev, bool use_philox, int h_begin, float thr, "
           "float min_extra, int aggregation, int h_offset, Tensor(a!) S, Tensor(b!) E, Tensor(c!) flags, Tensor(d!) cnt, "
           "Tensor(e!) s1, Tensor(f!) s2, Tensor(g!) result, Tensor(h!)? mask, Tensor(i!) workspace) -> ()");
+    m.def("ransac_pass_large_(Tensor corr, int seed, Tensor? seed_dev, bool use_philox, int h_begin, float thr, "
+          "float min_extra, int aggregation, int h_offset, Tensor(a!) S, Tensor(b!) E, Tensor(c!) flags, Tensor(d!) cnt, "
+          "Tensor(e!) s1, Tensor(f!) s2, Tensor(g!) result, Tensor(h!)? mask, Tensor(i!) workspace) -> ()");
     m.def("select_best(Tensor cnt, Tensor s1, Tensor s2, Tensor? flags, float min_extra, int aggregation, "
           "int h_offset=0) -> Tensor");
     m.def("select_best_(Tensor cnt, Tensor s1, Tensor s2, Tensor? flags, float min_extra, int aggregation, "
@@ -416,6 +438,7 @@ TORCH_LIBRARY_IMPL(sfm_hip, CUDA, m) {
     m.impl("score_sed", &score_sed);
     m.impl("score_sed_", &score_sed_out);
     m.impl("ransac_pass_small_", &ransac_pass_small_out);
+    m.impl("ransac_pass_large_", &ransac_pass_large_out);
     m.impl("select_best", &select_best);
     m.impl("select_best_", &select_best_out);
     m.impl("inlier_mask", &inlier_mask);
@@ -447,6 +470,7 @@ TORCH_LIBRARY_IMPL(sfm_hip, Meta, m) {
     m.impl("sample_fit_philox_", &sample_fit_philox_out_meta);
     m.impl("score_sed_", &score_sed_out_meta);
     m.impl("ransac_pass_small_", &ransac_pass_small_out_meta);
+    m.impl("ransac_pass_large_", &ransac_pass_small_out_meta);
     m.impl("select_best_", &select_best_out_meta);
     m.impl("inlier_mask_", &inlier_mask_out_meta);
     m.impl("normalize_coords", &normalize_coords_meta);

@@ -283,6 +283,29 @@ def ransac_pass_small(corr, S, E, flags, cnt, s1, s2, result, mask, workspace, t
                                   int(aggregation), h_offset, S, E, flags, cnt, s1, s2, result, mask, workspace)
 
 
+def ransac_pass_large(corr, S, E, flags, cnt, s1, s2, result, mask, workspace, thr: float, min_extra: float,
+                      aggregation: int, h_offset: int = 0, philox=None) -> None:
+    """One whole pass of a large problem (one pair) in eight launches instead of eighteen (``sfm_ransac_pass_large``): fit,
+    partial maxima + zeroing, both operand tables, cost pre-pass, class histogram, scan + scatter, the scoring kernel, fold of
+    the point ranges + selection + mask.  Arguments and outputs as ``ransac_pass_small``."""
+    if philox is None:
+        seed, seed_dev, use_philox, h_begin = 0, None, False, 0
+    else:
+        seed, h_begin = philox
+        on_device = isinstance(seed, torch.Tensor)
+        seed, seed_dev, use_philox = (0, seed, True) if on_device else (_as_int64(seed), None, True)
+    ops.load().ransac_pass_large_(corr, seed, seed_dev, use_philox, h_begin, float(thr), float(min_extra),
+                                  int(aggregation), h_offset, S, E, flags, cnt, s1, s2, result, mask, workspace)
+
+
+def large_pass_eligible(batch: int, n: int, h: int) -> bool:
+    """Whether ``RansacWorkspace.run`` takes the fused large pass: one pair whose scoring call would launch the matrix-pipe
+    kernel (the size rule of ``sfm_score_kernel_choice``).  ``SFM_LARGE_PASS=0`` keeps the separate calls."""
+    if batch != 1 or os.environ.get("SFM_LARGE_PASS", "1") == "0" or os.environ.get("SFM_SCORE_KERNEL", "filtered") == "exact":
+        return False
+    return _native.load().sfm_score_kernel_choice(n, h, 1) == _native.SCORE_KERNEL_MATRIX
+
+
 def select_best(cnt, s1, s2, flags, min_extra: float, aggregation: int, h_offset: int = 0, out=None):
     """-> int64 tensor [B,5] viewing the sfm_select_result records."""
     op = ops.load()
@@ -474,6 +497,12 @@ class RansacWorkspace:
         if small_pass_eligible(self.batch, self.n, self.h):
             # workspace preparation rides in the fit launch, selection over 32 blocks (seed_stride only matters for batches)
             ransac_pass_small(corr, self.S, self.E, self.flags, self.cnt, self.s1, self.s2, self.result,
+                              self.mask if with_mask else None, self.score_ws, thr, min_extra, aggregation, h_offset,
+                              None if philox is None else (philox[0], philox[1]))
+            return
+        if large_pass_eligible(self.batch, self.n, self.h) and (not with_mask or h_offset == 0):
+            # eight launches instead of eighteen: setup and tables fused, the ranges folded inside the selection launch
+            ransac_pass_large(corr, self.S, self.E, self.flags, self.cnt, self.s1, self.s2, self.result,
                               self.mask if with_mask else None, self.score_ws, thr, min_extra, aggregation, h_offset,
                               None if philox is None else (philox[0], philox[1]))
             return

@@ -850,6 +850,43 @@ def test_fused_small_pass_equals_separate_calls(dev, monkeypatch, n, h, philox):
             np.testing.assert_array_equal(np.nonzero(fused["mask"][0])[0], np.sort(ref["inliers"]))
 
 
+@pytest.mark.parametrize("n,h,philox,h_offset", [(10_000, 50_000, True, 0), (9_000, 70_001, False, 0), (50_000, 20_000, True, 0),
+                                                 (8_192, 65_000, True, 1_000_000), (16_384, 33_000, False, 0)])
+def test_fused_large_pass_equals_separate_calls(dev, monkeypatch, n, h, philox, h_offset):
+    """sfm_ransac_pass_large — eight launches: fit, partial maxima + zeroing, both operand tables, cost pre-pass, class
+    histogram, scan + scatter, the matrix-pipe scoring kernel, fold of the point ranges + selection over up to 256 blocks +
+    mask — against the separate calls (SFM_LARGE_PASS=0: eighteen launches) on the same inputs: samples, E, flags, counts,
+    both sums, the winner record and the mask identical bit for bit (the ranges are added in the same order)."""
+    from structure_from_motion_amd._native import AGG_RMS, AGG_SUM
+
+    _, _, _, corr = scene(n, seed=40 + n % 7)
+    corr_d = dev.to_device(corr).reshape(1, n, 4)
+    thr, min_extra = 1.5e-6, 10
+    outs = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("SFM_LARGE_PASS", fused)
+        assert dev.large_pass_eligible(1, n, h) == (fused == "1")
+        ws = dev.RansacWorkspace(1, n, h)
+        ws.mask.fill_(7)
+        if philox:
+            ws.run(corr_d, thr, min_extra, AGG_RMS, philox=(9, 100, 1), h_offset=h_offset, with_mask=h_offset == 0)
+        else:
+            ws.S.copy_(dev.sample_philox(11, 5, h, n))
+            ws.run(corr_d, thr, min_extra, AGG_SUM, h_offset=h_offset, with_mask=h_offset == 0)
+        outs.append({k: getattr(ws, k).cpu().numpy().copy() for k in ("S", "E", "flags", "cnt", "s1", "s2", "result", "mask")})
+    fused, plain = outs
+    for key in ("S", "E", "flags", "cnt", "result") + (("mask",) if h_offset == 0 else ()):
+        np.testing.assert_array_equal(fused[key], plain[key], err_msg=key)
+    for key in ("s1", "s2"):
+        np.testing.assert_array_equal(fused[key].view(np.int64), plain[key].view(np.int64), err_msg=key)
+    assert fused["result"][0][1] >= h_offset                                  # a model was found, global index
+    if h_offset == 0:
+        assert set(np.unique(fused["mask"]).tolist()) <= {0, 1, 2} and (fused["mask"] == 2).sum() == 8
+    # ... and the counts are the all-fp64 kernel's
+    exact = dev.score_sed(corr_d, dev.to_device(fused["E"]), dev.to_device(fused["S"], torch.int32), thr, exact_only=True)
+    np.testing.assert_array_equal(exact[0].cpu().numpy(), fused["cnt"])
+
+
 def test_fused_small_pass_random_sizes(dev, monkeypatch):
     """The lean small pass against the separate calls on 40 random (points, hypotheses) sizes over its whole range — every
     hypotheses-per-wave choice, loop remainder, partial last block, with and without the block barrier: counts, flags, masks

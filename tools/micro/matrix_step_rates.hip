@@ -103,6 +103,92 @@ __global__ __launch_bounds__(256) void k(int iters, unsigned long long* stamps, 
     if (total == 0x12345u) sink[threadIdx.x] = total + pad[0];
 }
 
+// The same step, software-pipelined inside the wave: the three matrix instructions of step t + 1 are issued BEFORE the sixteen
+// sign tests of step t (two accumulator sets), so the tests issue while the matrix pipe works — nothing else breaks the convoy
+// of identical waves on a SIMD (all in their matrix phase, then all in their test phase).
+template <bool LOADS>
+__global__ __launch_bounds__(256) void kp(int iters, unsigned long long* stamps, unsigned* sink, const uint4* __restrict__ table,
+                                          int steps) {
+    extern __shared__ unsigned pad[];
+    f16x8 B0, B1;
+    bf16x8 B2;
+    for (int j = 0; j < 8; ++j) { B0[j] = (_Float16)(1.0f + j); B1[j] = (_Float16)(0.25f * j); B2[j] = (__bf16)(2.0f + j); }
+    uint4 S0[3], S1[3];
+    const uint4* src = table + (threadIdx.x & 63);
+    const int first = (int)((blockIdx.x & 7) * (unsigned)steps);
+    for (int b = 0; b < 3; ++b) S0[b] = src[((size_t)first * 3 + b) * 64];
+    __builtin_amdgcn_sched_barrier(0);
+    for (int b = 0; b < 3; ++b) S1[b] = src[((size_t)(first + 1) * 3 + b) * 64];
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned total = 0;
+    int t = 0;
+    const float16v z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto matrix = [&](uint4 (&stage)[3], float16v& r, float16v& d) __attribute__((always_inline)) {
+        r = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, stage[0]), B0, z, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, stage[2]), B2, z, 0, 0, 0);
+        r = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, stage[1]), B1, r, 0, 0, 0);
+    };
+    auto refill = [&](uint4 (&stage)[3], unsigned& dep) __attribute__((always_inline)) {
+        if (LOADS) {
+            int next = t + 2;
+            next = next >= steps ? next - steps : next;
+            unsigned offset = (unsigned)(first + next) * 192u;
+            asm volatile("" : "+s"(offset), "+v"(dep));
+#pragma unroll
+            for (int b = 0; b < 3; ++b) stage[b] = src[offset + b * 64];
+        }
+        t = t + 1 >= steps ? 0 : t + 1;
+    };
+    auto tests = [&](const float16v& r, const float16v& d) __attribute__((always_inline)) {
+        unsigned rejected = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            rejected = __builtin_amdgcn_alignbit(rejected, __float_as_uint(__builtin_fmaf(-r[j], r[j], d[j])), 31);
+        return rejected;
+    };
+    float16v r0, d0, r1, d1;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    matrix(S0, r0, d0);                       // step 0
+    for (int i = 0; i < iters; i += 2) {
+        matrix(S1, r1, d1);                   // step i + 1 in the pipe ...
+        __builtin_amdgcn_sched_barrier(0);
+        unsigned rej = tests(r0, d0);         // ... while step i is tested
+        refill(S0, rej);
+        total += rej;
+        __builtin_amdgcn_sched_barrier(0);
+        matrix(S0, r0, d0);                   // step i + 2
+        __builtin_amdgcn_sched_barrier(0);
+        rej = tests(r1, d1);                  // step i + 1
+        refill(S1, rej);
+        total += rej;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * 4 + threadIdx.x / 64] = t1 - t0;
+    if (total == 0x12345u) sink[threadIdx.x] = total + pad[0] + (unsigned)r0[0];
+}
+
+template <bool LOADS>
+int runp(const char* name, int waves_per_simd, int iters, unsigned long long* stamps_dev, unsigned* sink, const uint4* table, int steps) {
+    const int blocks = 256 * waves_per_simd;
+    const size_t lds = (size_t)(160 * 1024 / waves_per_simd) - 1024;
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kp<LOADS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kp<LOADS>, dim3(blocks), dim3(256), lds, 0, iters, stamps_dev, sink, table, steps);
+    CHECK(hipDeviceSynchronize());
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    hipEventRecord(a);
+    hipLaunchKernelGGL(kp<LOADS>, dim3(blocks), dim3(256), lds, 0, iters, stamps_dev, sink, table, steps);
+    hipEventRecord(b); CHECK(hipEventSynchronize(b));
+    float ms; hipEventElapsedTime(&ms, a, b);
+    std::vector<unsigned long long> st(blocks * 4);
+    CHECK(hipMemcpy(st.data(), stamps_dev, st.size() * 8, hipMemcpyDeviceToHost));
+    std::sort(st.begin(), st.end());
+    const double per_wave = (double)st[st.size() / 2] / iters;
+    printf("%-34s %d waves/SIMD: %7.1f cycles per step and wave (median), %7.1f per step and SIMD; kernel %.3f ms -> %.2f GHz\n", name,
+           waves_per_simd, per_wave, per_wave / waves_per_simd, ms, (double)st[st.size() / 2] / (ms * 1e6));
+    return 0;
+}
+
 template <int MODE>
 int run(const char* name, int waves_per_simd, int iters, unsigned long long* stamps_dev, unsigned* sink, const uint4* table = nullptr,
         int steps = 1) {
@@ -133,6 +219,10 @@ int main() {
     uint4* table;
     CHECK(hipMalloc(&table, (size_t)8 * steps * 3 * 64 * 16 + 4096));   // 4.8 MB: the point operand table of the bench workload
     CHECK(hipMemset(table, 0x3c, (size_t)8 * steps * 3 * 64 * 16 + 4096));
+    for (int w : {1, 2, 3, 4}) {
+        if (runp<true>("PIPELINED loads + matrix + tests", w, it, stamps, sink, table, steps)) return 1;
+        if (runp<false>("PIPELINED matrix + tests", w, it, stamps, sink, table, steps)) return 1;
+    }
     for (int w : {1, 2, 4}) {
         if (run<32 + 3>("loads + matrix + 16 x (fma + abit)", w, it, stamps, sink, table, steps)) return 1;
         if (run<32 + 2>("loads + 16 x (fma + alignbit)", w, it, stamps, sink, table, steps)) return 1;
