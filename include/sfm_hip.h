@@ -123,10 +123,14 @@ int sfm_hartley_normalize(const double* coords, int64_t n, double* out, void* st
  * workspace: dev scratch of at least sfm_score_workspace_bytes(n, h_count, batch) bytes, 16-byte aligned; it
  * enables the two-tier kernels (a conservative reject filter + exact fp64 evaluation of the survivors, hypotheses
  * processed longest-first; identical counts and inlier decisions, sums in a fixed order): the fp32 VALU filter, and for a
- * single pair of at least 8192 points, 4096 hypotheses and 5e8 evaluations (at most 65 536 points) the kernel with the
+ * single pair of at least 8192 points, 4096 hypotheses and 5e8 evaluations (at most 4 194 304 points) the kernel with the
  * filter on the fp16 / bf16 matrix pipe and a lane-per-hypothesis exact tier (sfm_score_options.kernel forces it on / off).
  * Large single-pair launches are cut into ranges of the points whose partial results are added in range order.  NULL selects
- * the all-fp64 kernel. */
+ * the all-fp64 kernel.
+ * Footprint: sfm_score_workspace_bytes reserves, whether or not a launch ends up using them, 16 bytes per point (fp32 points),
+ * 16 KiB of counters per pair, 4 + 324 bytes per hypothesis (scoring order, the partials of up to 16 ranges) and — for pairs of at
+ * most 4 194 304 points — the matrix-pipe kernel's tables: 96 bytes per point, 96 + 20 bytes per hypothesis.  50 000 x 100 000:
+ * 50 MB; 256 pairs x 10 000 x 2 000: 521 MB; one pair x 1 000 000 hypotheses: 450 MB. */
 int64_t sfm_score_workspace_bytes(int64_t n, int64_t h_count, int64_t batch);
 int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t* S, int64_t h_count,
                   int64_t batch, double thr, int32_t* cnt, double* s1, double* s2, void* workspace,
@@ -141,7 +145,7 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
  * replaced as a whole. */
 #define SFM_SCORE_KERNEL_AUTO 0     /* the size rule described at sfm_score_sed */
 #define SFM_SCORE_KERNEL_FILTERED 1 /* fp32 VALU filter */
-#define SFM_SCORE_KERNEL_MATRIX 2   /* fp16 / bf16 matrix-pipe filter, where it applies (<= 65 536 points per pair), else FILTERED */
+#define SFM_SCORE_KERNEL_MATRIX 2   /* fp16 / bf16 matrix-pipe filter, where it applies (<= 4 194 304 points per pair), else FILTERED */
 typedef struct sfm_score_options {
     int32_t kernel;        /* SFM_SCORE_KERNEL_AUTO / _FILTERED / _MATRIX */
     int32_t hyps_per_wave; /* VALU-filter kernel: 0 = by launch size, or 1 / 2 / 4 */
@@ -192,7 +196,7 @@ int sfm_ransac_pass_small(uint64_t seed, const uint64_t* seed_dev, int use_philo
 /* Diagnostic of the matrix-pipe reject filter (tests measure the margin of its error bound with it; not on the product
  * path): prepares the operand tables of one pair exactly as sfm_score_sed does and evaluates tier 1 — the three 16-bit
  * matrix instructions — for EVERY (hypothesis, point), writing the raw fp32 accumulators instead of deciding on them.
- * n <= 65536.  workspace as for sfm_score_sed(n, h_count, 1).  With n_pad = 32 * ceil(n / 32):
+ * n <= 4 194 304.  workspace as for sfm_score_sed(n, h_count, 1).  With n_pad = 32 * ceil(n / 32):
  *   r_out  dev float [h_count, n_pad]   r'' = the scaled bilinear form c b^T E a s_p s_h as the matrix unit accumulated it
  *   d_out  dev float [h_count, n_pad]   the accumulated upper bound of (dA + dB) / 4 s_p^2 s_h^2 + slack (a point is rejected
  *                                       iff fma(-r'', r'', d) is negative); columns >= n are padding rows of zeros + slack

@@ -1281,7 +1281,7 @@ int sfm_score_get_default_options(sfm_score_options* out) {
 int sfm_debug_matrix_filter(const double* corr, int64_t n, const double* E, int64_t h_count, double thr, void* workspace,
                             int64_t workspace_bytes, float* r_out, float* d_out, float* bound_out, void* stream) {
     if (n < 8 || h_count < 1 || n > matrixscore::kMaxPoints || h_count > 0x3FFFFFFF)
-        return fail(SFM_EINVAL, "sfm_debug_matrix_filter: 8 <= n <= 65536 points and at least one hypothesis");
+        return fail(SFM_EINVAL, "sfm_debug_matrix_filter: 8 <= n <= 4194304 points and at least one hypothesis");
     if (!corr || !E || !workspace || !r_out || !d_out || !bound_out) return fail(SFM_EINVAL, "sfm_debug_matrix_filter: null pointer");
     if (workspace_bytes < workspace_bytes_for(n, h_count, 1) || (reinterpret_cast<uintptr_t>(workspace) & 15u) != 0)
         return fail(SFM_EINVAL, "sfm_debug_matrix_filter: workspace of sfm_score_workspace_bytes(n, h_count, 1) bytes, 16-byte aligned");
@@ -1436,8 +1436,12 @@ int score_sed_impl(const double* corr, int64_t n, const double* E, const int32_t
         if (split_env <= 0) steps_per_unit = std::max(steps_per_unit, batch > 1 ? 32 : 64);
         steps_per_unit = (steps_per_unit + 3) & ~3;   // ranges start on the step loop's group boundaries (groups of kAhead + 1 <= 4 steps)
         int m_units = (steps + steps_per_unit - 1) / steps_per_unit;
-        if (m_units <= 1 || split_env == 0 ||
-            !sfmhost::grid_fits((int64_t)grid_for(waves32, 256 / kWave) * (int64_t)m_units * ((batch + 7) / 8 * 8), 1, 256)) {
+        const bool must_split = steps > matrixscore::kMaxRangeSteps;   // (a queue entry keeps its step relative to the range in 16 bits)
+        if (must_split && (steps_per_unit > matrixscore::kMaxRangeSteps || m_units <= 1 || split_env == 0)) {
+            steps_per_unit = matrixscore::kMaxRangeSteps;   // more than 2 M points per pair: ranges of 2^16 steps, whatever was asked for
+            m_units = (steps + steps_per_unit - 1) / steps_per_unit;
+        } else if (m_units <= 1 || split_env == 0 ||
+                   !sfmhost::grid_fits((int64_t)grid_for(waves32, 256 / kWave) * (int64_t)m_units * ((batch + 7) / 8 * 8), 1, 256)) {
             m_units = 1;
             steps_per_unit = steps;
         }

@@ -116,7 +116,8 @@ constexpr int kAhead = SFM_MATRIX_AHEAD;   // steps of operand loads in flight b
 constexpr int kEstimateSteps = SFM_MATRIX_ESTIMATE_STEPS;   // steps of 32 points the cost pre-pass scans at most (4096 points)
 constexpr int kPointTop = 14, kHypTop = 11;   // scaled magnitudes: point terms < 2^14, hypothesis entries < 2^11
 constexpr int64_t kMaxPoints = sfmws::kMatrixMaxPoints;
-static_assert(kMaxPoints / kTile <= 65536, "a queue entry keeps the step in 16 bits");
+constexpr int kMaxRangeSteps = 65536;   // a queue entry keeps the step RELATIVE TO ITS RANGE in 16 bits: at most 2^16 steps (2 M points) per range
+static_assert(kMaxPoints <= (int64_t)sfmws::kSplitMaxUnits * kMaxRangeSteps * kTile, "sixteen ranges of 2^16 steps cover the largest pair");
 
 __host__ __device__ inline int64_t steps_of(int64_t n) { return (n + kTile - 1) / kTile; }
 // Steps the point operand table holds: those of the points, rounded up to a multiple of four with PAD steps.  A row past the
@@ -595,6 +596,11 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
     unsigned stat_rounds = 0, stat_pops = 0, stat_push_iterations = 0;
 #endif
 
+    const int steps_total = (int)steps_of(n);
+    const int step_begin = units > 1 ? unit * steps_per_unit : 0;   // (steps_per_unit is a multiple of kStages: ranges start on group boundaries)
+    const int step_end = units > 1 || ESTIMATE ? min(step_begin + steps_per_unit, steps_total) : steps_total;
+    const int last_loadable = (int)table_steps(n) - 1;
+
     // one round of the exact tier: every lane takes up to kPops of its queued points (their gathers in flight together) and
     // scores them, in queue order, under its own hypothesis
     auto round = [&]() __attribute__((always_inline)) {
@@ -606,7 +612,7 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
                 const unsigned entry = my_queue[(head & (kCap - 1)) * kWave];
                 ++head;
                 cur = entry & 0xffffu;
-                cur_base = (int)(entry >> 16) * kTile + 4 * half;
+                cur_base = (step_begin + (int)(entry >> 16)) * kTile + 4 * half;   // (the entry keeps the step relative to its range)
             }
             active[k] = cur != 0u;
             const int lz = __builtin_clz(cur | 1u);           // 16..31 for a live entry: bit 15 - j is register j
@@ -631,10 +637,6 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
         }
     };
 
-    const int steps_total = (int)steps_of(n);
-    const int step_begin = units > 1 ? unit * steps_per_unit : 0;   // (steps_per_unit is a multiple of kStages: ranges start on group boundaries)
-    const int step_end = units > 1 || ESTIMATE ? min(step_begin + steps_per_unit, steps_total) : steps_total;
-    const int last_loadable = (int)table_steps(n) - 1;
     unsigned survivors = 0;   // ESTIMATE
     if (step_begin < step_end) {
         const uint4* __restrict__ src = table + lane;
@@ -696,7 +698,7 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
                 survivors += (unsigned)__builtin_popcount(keep);
 #else
                 if (keep != 0u) {   // push: one entry with this step's survivors
-                    my_queue[(tail & (kCap - 1)) * kWave] = ((unsigned)t << 16) | keep;
+                    my_queue[(tail & (kCap - 1)) * kWave] = ((unsigned)(t - step_begin) << 16) | keep;
                     ++tail;
                 }
 #endif

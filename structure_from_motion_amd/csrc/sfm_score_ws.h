@@ -56,7 +56,7 @@ __host__ __device__ inline int64_t split_bytes(int64_t h_count) {
 // Operand tables of the matrix-pipe kernel (sfm_score_matrix.h; at most kMatrixMaxPoints points per pair), behind everything
 // else: per pair and step of 32 points three blocks of 64 lanes x 16 bytes (96 bytes per point), then per pair and hypothesis
 // 2 halves x 3 blocks x 16 bytes.
-constexpr int64_t kMatrixMaxPoints = 65536;
+constexpr int64_t kMatrixMaxPoints = 1 << 22;   // 4 M points per pair (a 400 MB operand table); until round 4: 65 536 (absolute steps in 16 bits)
 __host__ __device__ inline int64_t matrix_table_steps(int64_t n) { return (((n + 31) / 32) + 3) & ~(int64_t)3; }   // (with pad steps: sfm_score_matrix.h)
 __host__ __device__ inline int64_t matrix_table_bytes(int64_t n) {   // one pair
     return n <= kMatrixMaxPoints ? matrix_table_steps(n) * 3 * 64 * 16 : 0;

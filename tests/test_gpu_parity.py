@@ -1330,18 +1330,27 @@ def test_matrix_score_batches(dev, batch, n, h):
             _assert_same_scores([x[b] for x in exact], [x[b] for x in filt])
 
 
-def test_matrix_kernel_is_not_used_beyond_65536_points(dev):
-    """Queue entries keep the step in 16 bits: a pair of more than 65 536 points runs the VALU-filter kernel even when the matrix
-    one is asked for — same bits as with the VALU-filter kernel asked for, counts equal to the all-fp64 kernel's."""
-    n, h = 66_000, 96
+@pytest.mark.parametrize("n,h", [(66_000, 96), (200_000, 64), (65_537, 33)])
+def test_matrix_kernel_beyond_65536_points(dev, n, h):
+    """Until round 4 a queue entry kept the absolute step of its 32 points in 16 bits and pairs of more than 65 536 points fell
+    back to the VALU-filter kernel; the entry now keeps the step relative to its range (ranges of at most 2^16 steps, up to 4 M
+    points per pair).  The matrix-pipe kernel at 66 000 and 200 000 points: counts equal to the all-fp64 kernel's, the sums to
+    summation order, the same bits when repeated — and it IS the matrix kernel (its sums differ in the last bits from the
+    VALU-filter kernel's, which adds in another order)."""
     _, _, _, corr = scene(n)
     S = orc.philox_sample_table(3, 0, h, n)
     E, _, _ = orc.fit_hypotheses(corr, S)
     exact, asked = _score_both(dev, corr, E, S, 1.5e-6, _options(kernel="matrix"))
+    _, again = _score_both(dev, corr, E, S, 1.5e-6, _options(kernel="matrix"))
     _, valu = _score_both(dev, corr, E, S, 1.5e-6, _options(kernel="filtered"))
     _assert_same_scores(exact, asked)
-    for a, b in zip(asked, valu):
+    _assert_same_scores(exact, valu)
+    for a, b in zip(asked, again):
         np.testing.assert_array_equal(a.view(np.int64) if a.dtype == np.float64 else a, b.view(np.int64) if b.dtype == np.float64 else b)
+    assert not np.array_equal(asked[1].view(np.int64), valu[1].view(np.int64))
+    for split in (2, 16):   # ranges with rebased step indices
+        _, ranged = _score_both(dev, corr, E, S, 1.5e-6, _options(kernel="matrix", split=split))
+        _assert_same_scores(exact, ranged)
 
 
 def test_score_kernel_size_rule_picks_the_matrix_kernel(dev):

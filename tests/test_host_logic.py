@@ -32,15 +32,16 @@ def test_header_symbols_exported(native_lib):
 def test_score_workspace_holds_every_region(native_lib):
     """sfm_score_workspace_bytes (csrc/sfm_score_ws.h): fp32 points, class counters, scoring order, per-pair range-split
     partials (16 ranges: 324 bytes per hypothesis) and the matrix-pipe kernel's operand tables (96 bytes per point and per
-    hypothesis, pairs of at most 65 536 points) — monotone in every argument, nothing for the tables beyond 65 536 points."""
+    hypothesis, pairs of at most 4 M points) — monotone in every argument, nothing for the tables beyond that."""
     size = native_lib.sfm_score_workspace_bytes
     n, h = 50_000, 100_000
     one = size(n, h, 1)
     assert one >= 16 * n + 4 * h + 324 * h + 96 * (n + 31) // 32 * 32 + 96 * h
     assert size(n + 32, h, 1) > one and size(n, h + 1, 1) > one
-    big = size(70_000, h, 1)
-    assert big < size(65_536, h, 1)            # no operand tables for a pair the matrix-pipe kernel cannot take
-    assert big >= 16 * 70_000 + 4 * h + 324 * h
+    big = size(5_000_000, h, 1)
+    assert big < size(4_194_304, h, 1)         # no operand tables for a pair the matrix-pipe kernel cannot take (> 4 M points)
+    assert big >= 16 * 5_000_000 + 4 * h + 324 * h
+    assert size(70_000, h, 1) > size(65_536, h, 1) >= 96 * 65_536   # (the cap of rounds 1-3 is gone)
     batch = size(10_000, 2_000, 256)
     assert batch >= 256 * (16 * 10_000 + 4 * 2_000 + 324 * 2_000 + 96 * 10_016 + 96 * 2_000)
     assert size(10_000, 2_000, 257) > batch
@@ -49,7 +50,7 @@ def test_score_workspace_holds_every_region(native_lib):
 
 def test_score_kernel_choice_rule(native_lib):
     """sfm_score_kernel_choice_ex: 2 = the matrix-pipe kernel — single pairs from 8192 points x 4096 hypotheses x 5e8 evaluations,
-    batches from 8192 x 1024 per pair with 6144 waves and 5e8 evaluations over the batch, never beyond 65 536 points;
+    batches from 8192 x 1024 per pair with 6144 waves and 5e8 evaluations over the batch, never beyond 4 M points per pair;
     options.kernel forces it on (where it applies) / off."""
     from structure_from_motion_amd import _native
 
@@ -60,10 +61,10 @@ def test_score_kernel_choice_rule(native_lib):
 
     assert choice(50_000, 100_000, 1) == 2 and choice(50_000, 125_000, 1) == 2 and choice(50_000, 10_000, 1) == 2
     assert choice(5_000, 10_000, 1) == 1 and choice(16_000, 16_000, 1) == 1 and choice(8_191, 1_000_000, 1) == 1
-    assert choice(70_000, 100_000, 1) == 1
+    assert choice(70_000, 100_000, 1) == 2 and choice(5_000_000, 100_000, 1) == 1
     assert choice(10_000, 2_000, 256) == 2 and choice(10_000, 2_000, 16) == 1 and choice(4_000, 2_000, 256) == 1
     assert choice(50_000, 100_000, 1, valu) == 1
-    assert choice(300, 64, 1, matrix) == 2 and choice(70_000, 100_000, 1, matrix) == 1
+    assert choice(300, 64, 1, matrix) == 2 and choice(70_000, 100_000, 1, matrix) == 2 and choice(5_000_000, 64, 1, matrix) == 1
     assert choice(-1, 5, 1) == -1
     bad = _native.ScoreOptions(kernel=7)
     assert choice(300, 64, 1, C.byref(bad)) == -1
