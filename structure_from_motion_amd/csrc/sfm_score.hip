@@ -1120,8 +1120,8 @@ int launch_matrix(const FilteredLaunch& a) {
                            a.corr, a.n, a.a_scale, (const float4*)partial, (int)setup_blocks, const_cast<uint4*>(table), step_blocks, a.E,
                            a.h_count, const_cast<uint4*>(hyp_table), a.S, a.thr, fix);
     } else {
-        hipLaunchKernelGGL(matrix_prepare_kernel, dim3((unsigned)table_steps(a.n), pairs), dim3(64), 0, a.st, a.corr, a.n, a.a_scale,
-                           a.ws, const_cast<uint4*>(table));
+        hipLaunchKernelGGL(matrix_prepare_kernel, dim3((unsigned)((table_steps(a.n) + 3) / 4), pairs), dim3(256), 0, a.st, a.corr, a.n,
+                           a.a_scale, a.ws, const_cast<uint4*>(table));
         hipLaunchKernelGGL(matrix_hypothesis_kernel, dim3(grid_for(2 * (int64_t)a.h_count, 256), pairs), dim3(256), 0, a.st, a.ws, a.E,
                            a.h_count, a.a_scale, const_cast<uint4*>(hyp_table), (float*)nullptr, a.corr, a.n, a.S, a.thr, fix);
     }
@@ -1298,8 +1298,8 @@ int sfm_debug_matrix_filter(const double* corr, int64_t n, const double* E, int6
                        n, a_scale, ws);
     uint4* table = reinterpret_cast<uint4*>(ws + ws_matrix_offset(n, h_count, 1));
     uint4* hyp_table = reinterpret_cast<uint4*>(ws + ws_matrix_hyp_offset(n, h_count, 1));
-    hipLaunchKernelGGL(matrix_prepare_kernel, dim3((unsigned)table_steps(n), 1), dim3(64), 0, st, (const Corr*)corr, (int)n, a_scale, ws,
-                       table);
+    hipLaunchKernelGGL(matrix_prepare_kernel, dim3((unsigned)((table_steps(n) + 3) / 4), 1), dim3(256), 0, st, (const Corr*)corr, (int)n,
+                       a_scale, ws, table);
     hipLaunchKernelGGL(matrix_hypothesis_kernel, dim3(grid_for(2 * h_count, 256), 1), dim3(256), 0, st, ws, E, (int)h_count, a_scale,
                        hyp_table, bound_out, (const Corr*)corr, (int)n, (const int32_t*)nullptr, thr, (unsigned char*)nullptr);
     hipLaunchKernelGGL(matrix_filter_dump_kernel, dim3((unsigned)steps, (unsigned)tiles), dim3(64), 0, st, hyp_table, table, steps,

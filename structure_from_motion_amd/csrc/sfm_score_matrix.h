@@ -249,11 +249,13 @@ SFM_DEVICE void prepare_step(const Corr* __restrict__ corr, int n, double c, con
     }
     table[((size_t)t * kBlocks + 2) * 64 + l] = __builtin_bit_cast(uint4, v);
 }
-__global__ __launch_bounds__(64) void matrix_prepare_kernel(const Corr* __restrict__ corr, int n, double c,
-                                                           const unsigned char* __restrict__ ws, uint4* __restrict__ table) {
-    const int64_t pair = blockIdx.y;   // (`ws`: the pair's maxima as score_prepare_kernel left them)
+__global__ __launch_bounds__(256) void matrix_prepare_kernel(const Corr* __restrict__ corr, int n, double c,
+                                                            const unsigned char* __restrict__ ws, uint4* __restrict__ table) {
+    const int64_t pair = blockIdx.y;   // (`ws`: the pair's maxima as score_prepare_kernel left them); four steps per block
+    const int t = (int)blockIdx.x * 4 + (int)(threadIdx.x / kWave);
+    if (t >= (int)table_steps(n)) return;
     prepare_step(corr + pair * (int64_t)n, n, c, reinterpret_cast<const uint32_t*>(ws + 16 * pair),
-                 table + pair * table_steps(n) * kBlocks * 64, (int)blockIdx.x, (int)threadIdx.x);
+                 table + pair * table_steps(n) * kBlocks * 64, t, (int)(threadIdx.x & (kWave - 1)));
 }
 
 // Operand table of the hypotheses: for hypothesis h and half (0: slots 0..7, 1: slots 8..15 of each block) the three B

@@ -887,6 +887,29 @@ def test_fused_large_pass_equals_separate_calls(dev, monkeypatch, n, h, philox, 
     np.testing.assert_array_equal(exact[0].cpu().numpy(), fused["cnt"])
 
 
+@pytest.mark.parametrize("n,h", [(9_000, 20_000), (20_000, 3_000), (600, 900)])
+def test_large_pass_entry_on_sizes_of_the_other_kernels(dev, n, h):
+    """sfm_ransac_pass_large takes any size: where sfm_score_sed would not pick the matrix-pipe kernel its own launches run,
+    followed by the pass's one selection + mask launch (no ranges to fold) — or, below a few thousand hypotheses, by the
+    stand-alone selection and mask.  Outputs equal to the separate calls'."""
+    from structure_from_motion_amd._native import AGG_RMS
+
+    _, _, _, corr = scene(n, seed=12)
+    corr_d = dev.to_device(corr).reshape(1, n, 4)
+    thr, min_extra = 1.5e-6, 10
+    a, b = dev.RansacWorkspace(1, n, h), dev.RansacWorkspace(1, n, h)
+    dev.ransac_pass_large(corr_d, a.S, a.E, a.flags, a.cnt, a.s1, a.s2, a.result, a.mask, a.score_ws, thr, min_extra, AGG_RMS,
+                          philox=(9, 100))
+    dev.sample_fit_philox(corr_d, 9, 100, b.S, b.E, b.flags, 1)
+    dev.score_sed(corr_d, b.E, b.S, thr, b.cnt, b.s1, b.s2, workspace=b.score_ws)
+    dev.select_best(b.cnt, b.s1, b.s2, b.flags, min_extra, AGG_RMS, 0, b.result)
+    dev.inlier_mask(corr_d, b.E, b.S, b.result, thr, b.mask)
+    for key in ("S", "E", "flags", "cnt", "result", "mask"):
+        np.testing.assert_array_equal(getattr(a, key).cpu().numpy(), getattr(b, key).cpu().numpy(), err_msg=key)
+    for key in ("s1", "s2"):
+        np.testing.assert_array_equal(getattr(a, key).cpu().numpy().view(np.int64), getattr(b, key).cpu().numpy().view(np.int64))
+
+
 def test_fused_small_pass_random_sizes(dev, monkeypatch):
     """The lean small pass against the separate calls on 40 random (points, hypotheses) sizes over its whole range — every
     hypotheses-per-wave choice, loop remainder, partial last block, with and without the block barrier: counts, flags, masks
@@ -1311,6 +1334,25 @@ def test_matrix_score_ranges_and_order(dev, split, order):
         _assert_same_scores(exact, filt)
         _, again = _score_both(dev, corr, E, S, thr, options)
         for a, b in zip(filt, again):
+            np.testing.assert_array_equal(a.view(np.int64) if a.dtype == np.float64 else a,
+                                          b.view(np.int64) if b.dtype == np.float64 else b)
+
+
+@pytest.mark.parametrize("split", [-1, 1, 3, 8, 16])
+def test_matrix_score_persistent_waves(dev, split):
+    """sfm_score_options.persistent = 1: the grid is what the chip holds and every wave takes (group of 32 hypotheses, range)
+    items from a counter — per XCD when the ranges are a multiple of eight, one counter otherwise — until they run out.  Same
+    counts as the all-fp64 kernel, and the same BITS as the default launch (one block per four items) with the same ranges: which
+    wave scores an item changes nothing about the item."""
+    n, h = 9000, 5000
+    _, _, _, corr = scene(n)
+    S = orc.philox_sample_table(31, 0, h, n)
+    E, _, _ = orc.fit_hypotheses(corr, S)
+    for thr in (1.5e-6, 1e-3):
+        exact, persistent = _score_both(dev, corr, E, S, thr, _options(kernel="matrix", split=split, persistent=1))
+        _, plain = _score_both(dev, corr, E, S, thr, _options(kernel="matrix", split=split, persistent=0))
+        _assert_same_scores(exact, persistent)
+        for a, b in zip(persistent, plain):
             np.testing.assert_array_equal(a.view(np.int64) if a.dtype == np.float64 else a,
                                           b.view(np.int64) if b.dtype == np.float64 else b)
 
