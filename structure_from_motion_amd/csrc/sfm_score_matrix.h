@@ -16,11 +16,19 @@
 // (j & 3) + 8 (j >> 2) + 4 (l >> 5), j = accumulator register).
 //
 // Because a lane belongs to ONE hypothesis, everything behind tier 1 is lane-parallel: each lane pushes its survivors onto its
-// own LDS queue (one word per step with survivors: the step and its 16 survivor bits; slot-major, so the 64 lanes of a push hit 64 banks), and a round of the exact tier has
-// every lane pop one point of its own queue and evaluate it under its own hypothesis (E in 18 VGPRs) into its own (count, sum,
-// sum of squares): no wave reduction anywhere, the two lanes of a hypothesis are added once at the end.  Rounds start when a
-// queue is nearly full and go on until every queue is down to kLow, so with hypotheses of similar load in a wave (the
-// heaviest-first order is dealt row-major here) nearly all lanes are busy in every round.
+// own LDS queue (one word per step with survivors: the step — relative to the item's range — and its 16 survivor bits;
+// slot-major, so the 64 lanes of a push hit 64 banks), and a round of the exact tier has every lane pop two points of its own
+// queue and evaluate them under its own hypothesis (E loaded where a burst of rounds starts) into its own (count, sum, sum of
+// squares): no wave reduction anywhere, the two lanes of a hypothesis are added once at the end.  Rounds start when a queue is
+// nearly full (looked at once per group of steps, outside the hot loop) and go on until every queue is down to kLow, so with
+// hypotheses of similar load in a wave (the heaviest-first order is dealt row-major here) nearly all lanes are busy in every round.
+//
+// Work items and their results (round 4).  An item is (group of 32 hypotheses, range of the points): one wave, placed by block
+// index (consecutive blocks = the ranges of one group; a multiple of eight ranges puts range u on XCD u mod 8) or taken from a
+// per-XCD counter by persistent waves (sfm_score_options.persistent).  A range leaves its partial (count, sum, sum of squares) at
+// [range][hypothesis] with plain stores; matrix_fold_kernel — or the selection launch of a fused pass — adds the ranges in range
+// order and then the hypothesis' sample correction (computed once by matrix_hypothesis_kernel).  No atomics: device-scope
+// atomics were two thirds of every wave's life in rounds 2-3 (profiles/r04/README.md).
 //
 // Ranges.  fp16 holds 2^-14 .. 2^16 at full precision, so both sides of the r' chain are scaled by exact powers of two: the
 // point terms by s_p (data set: the largest term maximum lands in [2^13, 2^14)), the hypothesis entries by s_h (per

@@ -168,6 +168,89 @@ __global__ __launch_bounds__(256) void kp(int iters, unsigned long long* stamps,
     if (total == 0x12345u) sink[threadIdx.x] = total + pad[0] + (unsigned)r0[0];
 }
 
+// The step with its point operands SHARED by the four waves of a block through LDS: per group of four steps (12 KiB) each wave
+// loads three of the twelve 1 KiB pieces from memory (a quarter of the traffic), stores them into the other half of a two-group
+// ring, one block barrier per group; every wave reads its fragments with ds_read_b128.
+__global__ __launch_bounds__(256) void ks(int iters, unsigned long long* stamps, unsigned* sink, const uint4* __restrict__ table,
+                                          int steps) {
+    __shared__ uint4 ring[2][4][3][64];   // 24 KiB
+    extern __shared__ unsigned pad[];
+    f16x8 B0, B1;
+    bf16x8 B2;
+    for (int j = 0; j < 8; ++j) { B0[j] = (_Float16)(1.0f + j); B1[j] = (_Float16)(0.25f * j); B2[j] = (__bf16)(2.0f + j); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int first = (int)((blockIdx.x & 7) * (unsigned)steps);
+    const uint4* src = table + lane;
+    // piece p of a group (p = 0..11: step p / 3, block p % 3) is loaded by wave p % 4: this wave's pieces are wave, wave + 4, wave + 8
+    uint4 mine[3];
+    auto fetch = [&](int group) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int p = wave + 4 * k;
+            int t = group * 4 + p / 3;
+            t = t % steps;
+            mine[k] = src[((size_t)(first + t) * 3 + p % 3) * 64];
+        }
+    };
+    auto stash = [&](int half) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int p = wave + 4 * k;
+            ring[half][p / 3][p % 3][lane] = mine[k];
+        }
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    unsigned total = 0;
+    const float16v z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    int group = 0;
+    for (int i = 0; i < iters; i += 4, ++group) {
+        fetch(group + 1);                                   // a quarter of the next group's pieces, in flight during this group
+        const int half = group & 1;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const f16x8 A0 = __builtin_bit_cast(f16x8, ring[half][s4][0][lane]);
+            const f16x8 A1 = __builtin_bit_cast(f16x8, ring[half][s4][1][lane]);
+            const bf16x8 A2 = __builtin_bit_cast(bf16x8, ring[half][s4][2][lane]);
+            float16v r = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, B0, z, 0, 0, 0);
+            float16v d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B2, z, 0, 0, 0);
+            r = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, B1, r, 0, 0, 0);
+            unsigned rejected = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                rejected = __builtin_amdgcn_alignbit(rejected, __float_as_uint(__builtin_fmaf(-r[j], r[j], d[j])), 31);
+            total += rejected;
+        }
+        stash(half ^ 1);
+        __syncthreads();
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (lane == 0) stamps[blockIdx.x * 4 + wave] = t1 - t0;
+    if (total == 0x12345u) sink[threadIdx.x] = total + pad[0];
+}
+
+int runs(const char* name, int waves_per_simd, int iters, unsigned long long* stamps_dev, unsigned* sink, const uint4* table, int steps) {
+    const int blocks = 256 * waves_per_simd;
+    const size_t lds = (size_t)(160 * 1024 / waves_per_simd) - 1024 - 24 * 1024;
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(ks, dim3(blocks), dim3(256), lds, 0, iters, stamps_dev, sink, table, steps);
+    CHECK(hipDeviceSynchronize());
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    hipEventRecord(a);
+    hipLaunchKernelGGL(ks, dim3(blocks), dim3(256), lds, 0, iters, stamps_dev, sink, table, steps);
+    hipEventRecord(b); CHECK(hipEventSynchronize(b));
+    float ms; hipEventElapsedTime(&ms, a, b);
+    std::vector<unsigned long long> st(blocks * 4);
+    CHECK(hipMemcpy(st.data(), stamps_dev, st.size() * 8, hipMemcpyDeviceToHost));
+    std::sort(st.begin(), st.end());
+    const double per_wave = (double)st[st.size() / 2] / iters;
+    printf("%-34s %d waves/SIMD: %7.1f cycles per step and wave (median), %7.1f per step and SIMD; kernel %.3f ms -> %.2f GHz; %.1f ns per step and SIMD\n", name,
+           waves_per_simd, per_wave, per_wave / waves_per_simd, ms, (double)st[st.size() / 2] / (ms * 1e6), ms * 1e6 / iters / waves_per_simd);
+    return 0;
+}
+
 template <bool LOADS>
 int runp(const char* name, int waves_per_simd, int iters, unsigned long long* stamps_dev, unsigned* sink, const uint4* table, int steps) {
     const int blocks = 256 * waves_per_simd;
@@ -206,8 +289,8 @@ int run(const char* name, int waves_per_simd, int iters, unsigned long long* sta
     CHECK(hipMemcpy(st.data(), stamps_dev, st.size() * 8, hipMemcpyDeviceToHost));
     std::sort(st.begin(), st.end());
     const double per_wave = (double)st[st.size() / 2] / iters;
-    printf("%-34s %d waves/SIMD: %7.1f cycles per step and wave (median), %7.1f per step and SIMD; kernel %.3f ms -> %.2f GHz\n", name,
-           waves_per_simd, per_wave, per_wave / waves_per_simd, ms, (double)st[st.size() / 2] / (ms * 1e6));
+    printf("%-34s %d waves/SIMD: %7.1f cycles per step and wave (median), %7.1f per step and SIMD; kernel %.3f ms -> %.2f GHz; %.1f ns per step and SIMD\n", name,
+           waves_per_simd, per_wave, per_wave / waves_per_simd, ms, (double)st[st.size() / 2] / (ms * 1e6), ms * 1e6 / iters / waves_per_simd);
     return 0;
 }
 
@@ -219,6 +302,10 @@ int main() {
     uint4* table;
     CHECK(hipMalloc(&table, (size_t)8 * steps * 3 * 64 * 16 + 4096));   // 4.8 MB: the point operand table of the bench workload
     CHECK(hipMemset(table, 0x3c, (size_t)8 * steps * 3 * 64 * 16 + 4096));
+    for (int w : {2, 3, 4}) {
+        if (runs("LDS-SHARED loads + matrix + tests", w, it, stamps, sink, table, steps)) return 1;
+        if (run<32 + 3>("per-wave loads + matrix + tests", w, it, stamps, sink, table, steps)) return 1;
+    }
     for (int w : {1, 2, 3, 4}) {
         if (runp<true>("PIPELINED loads + matrix + tests", w, it, stamps, sink, table, steps)) return 1;
         if (runp<false>("PIPELINED matrix + tests", w, it, stamps, sink, table, steps)) return 1;
