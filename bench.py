@@ -13,12 +13,15 @@ Philox stream split over the N ranks (1 000 000 // N each, 125 000 at N = 8), on
 pick the global best model; `--hypotheses H` overrides with H per rank (weak scaling).  One JSON line on stdout
 (rank 0).
 
-Roofline.  The correspondence set (1.6 MB) is L2-resident, so HBM bytes do not bound the scoring kernel; VALU issue
-does.  `roofline.frac` = (VALU wave-instructions of one launch, from the committed rocprofv3 PMC passes, priced at
-the spec issue rates of MI355X_MICROARCH.md: 2 cycles per wave64 instruction on the SIMD-32 pipes, 4 for fp64) /
-(1024 SIMDs x 2.4 GHz x the kernel's duration measured live with HIP events around that kernel).  The HBM views the
-contract asks for are kept beside it: `hbm_algorithmic` (32 B per evaluation / kernel time — exceeds the peak
-because the set is cache-resident) and `hbm_physical` (FETCH_SIZE x 2 + WRITE_SIZE per launch / kernel time).
+Roofline.  The correspondence set (1.6 MB) is L2-resident, so HBM bytes do not bound the scoring kernel (`hbm_algorithmic`
+— 32 B per evaluation / kernel time — exceeds the peak; `hbm_physical` — FETCH_SIZE x 2 + WRITE_SIZE per launch — is ~5 % of it).
+What bounds it is instruction issue at the clock the power manager leaves (1.57 GHz under this load: profiles/r04/README.md):
+`roofline.frac` = (VALU wave-instructions of one launch, from the committed rocprofv3 PMC passes, priced at the spec issue rates of
+MI355X_MICROARCH.md: 2 cycles per wave64 instruction, 4 for fp64, 8 of vector issue per 16-bit MFMA) / (1024 SIMDs x 2.4 GHz x the
+kernel's duration measured live with HIP events around that kernel) — the issue-slot UTILISATION of the executed instruction
+stream, not a bound (a fatter kernel scores higher).  The bound beside it is `roofline.fp64_floor`: the run's own true inliers and
+sample points (sum of cnt + 8 per hypothesis) must go through the 59-instruction fp64 routine — that work at full rate and full
+lane utilisation, as a time and as a fraction of the measured kernel.
 """
 import argparse
 import ctypes as C

@@ -12,6 +12,9 @@
 #include <utility>
 
 #define SFM_DEVICE __device__ __forceinline__
+#ifndef SFM_SED_EXACT_DIVISION
+#define SFM_SED_EXACT_DIVISION 0
+#endif
 
 namespace sfm {
 
@@ -32,6 +35,56 @@ SFM_DEVICE double sed_value(const double e[9], double xa, double ya, double xb, 
     const double da = la0 * la0 + la1 * la1;
     const double db = lb0 * lb0 + lb1 * lb1;
     return (1.0 / da + 1.0 / db) * (r * r);
+}
+
+// The same distance for a caller that thresholds it and sums it (the exact tier of the scoring kernels): r, da and db as above,
+// bit for bit; the two IEEE divisions — 26 of sed_value's 59 fp64 instructions — replaced by ONE reciprocal of da * db (v_rcp_f64:
+// 2^-24) refined by one cubic step (y (1 + e + e^2), e = 1 - q y: 2^-72 before rounding), without the scaling / fix-up instructions
+// of a full division:  sed' = (da + db) * rcp(da * db) * r^2.  Six roundings of 2^-53 against sed_value's three: the two differ
+// by at most 1.2e-15 relative while da * db is far from the ends of the exponent range.  The gate's band is a hundred times that:
+//   sed' <= thr - band  an inlier,  sed' > thr + band  an outlier (NaN: every comparison false) — sed_value would say the same;
+//   in between, or with da * db outside [2^-930, 2^930) (zero, subnormal, huge, inf, NaN), sed_value's own division sequence
+//   decides and is the value.
+// So the DECISION is always sed_value's; the sums carry the 1.2e-15 (their summation order already differs from the reference's
+// by more: DESIGN.md section 4).  43 fp64-rate instructions per evaluation with the caller's two sums, against 59.
+struct SedGate {
+    double thr, lo, hi;
+};
+SFM_DEVICE SedGate sed_gate(double thr) {   // thr NaN: nothing is an inlier; thr = inf: lo is NaN and every finite value takes the division
+    const double band = 1e-13 * fabs(thr) + 1e-290;
+    return SedGate{thr, thr - band, thr + band};
+}
+SFM_DEVICE bool sed_inlier(const double e[9], double xa, double ya, double xb, double yb, const SedGate& gate, double& sed_out) {
+    const double lb0 = (xb * e[0] + yb * e[3]) + e[6];
+    const double lb1 = (xb * e[1] + yb * e[4]) + e[7];
+    const double lb2 = (xb * e[2] + yb * e[5]) + e[8];
+    const double r = (lb0 * xa + lb1 * ya) + lb2;
+    const double la0 = (e[0] * xa + e[1] * ya) + e[2];
+    const double la1 = (e[3] * xa + e[4] * ya) + e[5];
+    const double da = la0 * la0 + la1 * la1;
+    const double db = lb0 * lb0 + lb1 * lb1;
+    const double r2 = r * r;
+#if SFM_SED_EXACT_DIVISION   // (A/B builds: tools/r04/fastdiv.sh)
+    sed_out = (1.0 / da + 1.0 / db) * r2;
+    return sed_out <= gate.thr;
+#endif
+    const double q = da * db;
+    double y = __builtin_amdgcn_rcp(q);
+    const double err = fma(-q, y, 1.0);
+    y = fma(y, fma(err, err, err), y);
+    double sed = ((da + db) * y) * r2;
+    const bool in_lo = sed <= gate.lo, in_hi = sed <= gate.hi;
+    // biased exponent of q in [93, 1953): one subtraction and one unsigned comparison on the high word (q is never negative)
+    const uint32_t q_high = (uint32_t)(__double_as_longlong(q) >> 32);
+    const bool q_normal = (q_high - 0x05D00000u) < (0x7A100000u - 0x05D00000u);
+    bool in = in_lo;
+    if (!q_normal || in_lo != in_hi) {
+        asm volatile("" ::: "memory");   // (a real branch: taken by no lane of almost every wave)
+        sed = (1.0 / da + 1.0 / db) * r2;
+        in = sed <= gate.thr;
+    }
+    sed_out = sed;
+    return in;
 }
 
 // --------------------------------------------------------------------------------------------------

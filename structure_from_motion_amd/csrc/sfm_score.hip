@@ -700,6 +700,7 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
     // tier 2: exact fp64 evaluation of `count` (<= 64) queued points of hypothesis k
     // (Deferring the evaluation by one drain, so that the gather of the fp64 records overlaps the next steps' tier 1,
     // changed nothing at any size: profiles/r02/README.md.)
+    const sfm::SedGate gate = sfm::sed_gate(thr);
     auto drain = [&](int k, int count) __attribute__((always_inline)) {
         const int h = hyp[k];
         double e[9];
@@ -708,8 +709,8 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
         const bool active = lane < count;
         const int idx = active ? stack[wave_in_block][k][top[k] - count + lane] : 0;
         const Corr p = pts[idx];
-        const double sed = sfm::sed_value(e, p.xa, p.ya, p.xb, p.yb);
-        const bool ok = active && (sed <= thr);
+        double sed;
+        const bool ok = sfm::sed_inlier(e, p.xa, p.ya, p.xb, p.yb, gate, sed) && active;
         c[k] += ok ? 1 : 0;
         const double kept = ok ? sed : 0.0;   // masked once; its square is the masked square (same bits, one select less)
         a1[k] += kept;
@@ -895,8 +896,8 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
             if (queued) idx = stack[wave_in_block][k][lane];
             if (sample) idx = Sb[(int64_t)h * 8 + (lane - left)];
             const Corr p = pts[idx];
-            const double sed = sfm::sed_value(e, p.xa, p.ya, p.xb, p.yb);
-            const bool in = sed <= thr;
+            double sed;
+            const bool in = sfm::sed_inlier(e, p.xa, p.ya, p.xb, p.yb, gate, sed);
             // queued point: counted if it is an inlier.  Sample point: the scan has counted it already if it is within
             // the threshold (take it out of the count, keep it in the sums); otherwise add it to the sums only —
             // NaN / inf propagate: such a model never wins

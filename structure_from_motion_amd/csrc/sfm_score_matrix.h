@@ -613,6 +613,7 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
 
     // one round of the exact tier: every lane takes up to kPops of its queued points (their gathers in flight together) and
     // scores them, in queue order, under its own hypothesis
+    const sfm::SedGate gate = sfm::sed_gate(thr);
     auto round = [&]() __attribute__((always_inline)) {
         Corr p[kPops];
         bool active[kPops];
@@ -638,12 +639,12 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
 #endif
 #pragma unroll
         for (int k = 0; k < kPops; ++k) {
-            const double sed = sfm::sed_value(e, p[k].xa, p[k].ya, p[k].xb, p[k].yb);
-            const bool ok = active[k] && (sed <= thr);
+            double sed;
+            const bool ok = sfm::sed_inlier(e, p[k].xa, p[k].ya, p[k].xb, p[k].yb, gate, sed) && active[k];
             c += ok ? 1 : 0;
             const double kept = ok ? sed : 0.0;   // masked once; its square is the masked square
             a1 += kept;
-            a2 += kept * kept;
+            a2 = fma(kept, kept, a2);
         }
     };
 
