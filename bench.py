@@ -20,7 +20,7 @@ What bounds it is instruction issue at the clock the power manager leaves (1.57 
 MI355X_MICROARCH.md: 2 cycles per wave64 instruction, 4 for fp64, 8 of vector issue per 16-bit MFMA) / (1024 SIMDs x 2.4 GHz x the
 kernel's duration measured live with HIP events around that kernel) — the issue-slot UTILISATION of the executed instruction
 stream, not a bound (a fatter kernel scores higher).  The bound beside it is `roofline.fp64_floor`: the run's own true inliers and
-sample points (sum of cnt + 8 per hypothesis) must go through the 59-instruction fp64 routine — that work at full rate and full
+sample points (sum of cnt + 8 per hypothesis) must go through the 43-instruction fp64 routine — that work at full rate and full
 lane utilisation, as a time and as a fraction of the measured kernel.
 """
 import argparse
@@ -43,8 +43,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); ~6290 measur
 SIMDS, CLOCK_GHZ = 1024, 2.4   # 256 CUs x 4 SIMD-32; max clock (MI355X_MICROARCH.md chip table)
 CYC_VALU, CYC_F64 = 2.0, 4.0   # spec issue cycles per wave64 instruction: v_fma_f32 2 (SIMD-32); fp64 at half rate
 CYC_MFMA = 8.0                 # vector-issue cycles a 32x32x16 16-bit MFMA holds (MI355X_MICROARCH.md cycle constants); it runs 32 on the matrix pipe
-FP64_PER_EVAL = 59             # fp64 wave-instructions of one exact SED evaluation (sfm::sed_value as compiled: 21 mul, 17 add, 2 IEEE
-                               # divisions of 10, 1 compare — counted in the disassembly of the exact tier; -ffp-contract=off)
+FP64_PER_EVAL = 43             # fp64-rate wave-instructions of one evaluation of the exact tier (sfm::sed_inlier + the two sums as compiled:
+                               # 20 mul, 16 add, 4 fma, 1 rcp, 2 compares — counted in the disassembly; -ffp-contract=off).  Until
+                               # round 4's last kernel change: 59 + 4 (sfm::sed_value with its two IEEE divisions of 13 each)
 THR, MIN_EXTRA = 1.5e-6, 10    # reference apps/config/config.yaml:6-9 (RMS aggregation)
 C4_TOTAL = 1_000_000           # BASELINE.json configs[3]
 COUNTERS = os.path.join(REPO, "profiles", "score_traffic.json")

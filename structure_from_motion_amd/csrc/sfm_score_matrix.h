@@ -17,9 +17,11 @@
 //
 // Because a lane belongs to ONE hypothesis, everything behind tier 1 is lane-parallel: each lane pushes its survivors onto its
 // own LDS queue (one word per step with survivors: the step — relative to the item's range — and its 16 survivor bits;
-// slot-major, so the 64 lanes of a push hit 64 banks), and a round of the exact tier has every lane pop two points of its own
+// slot-major, so the 64 lanes of a push hit 64 banks), and a round of the exact tier has every lane pop kPops points of its own
 // queue and evaluate them under its own hypothesis (E loaded where a burst of rounds starts) into its own (count, sum, sum of
-// squares): no wave reduction anywhere, the two lanes of a hypothesis are added once at the end.  Rounds start when a queue is
+// squares): no wave reduction anywhere, the two lanes of a hypothesis are added once at the end.  The evaluation is
+// sfm::sed_inlier (sfm_math.h): the reference's r, dA, dB bit for bit, one refined reciprocal instead of two IEEE divisions, the
+// division sequence itself wherever the value is not clear of the threshold — the decision is always the reference's.  Rounds start when a queue is
 // nearly full (looked at once per group of steps, outside the hot loop) and go on until every queue is down to kLow, so with
 // hypotheses of similar load in a wave (the heaviest-first order is dealt row-major here) nearly all lanes are busy in every round.
 //

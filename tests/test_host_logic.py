@@ -519,7 +519,7 @@ def test_bench_roofline_is_a_valu_issue_bound(monkeypatch, tmp_path):
     # the bound the line carries beside the utilisation: the run's own inliers through the fp64 routine at full rate
     assert roof["fp64_floor"] is None and "utilisation" in roof["note"]
     floor = bench.roofline(n, h, 1.5, 1.6, "filtered", exact_evals=1.75e8)["fp64_floor"]
-    assert isclose(floor["floor_ms"], 1.75e8 / 64 * 59 * 4.0 / 1024 / 2.4e9 * 1e3, rel_tol=1e-12)
+    assert isclose(floor["floor_ms"], 1.75e8 / 64 * 43 * 4.0 / 1024 / 2.4e9 * 1e3, rel_tol=1e-12)
     assert isclose(floor["frac_of_kernel"], floor["floor_ms"] / 1.5, rel_tol=1e-12) and floor["exact_evaluations"] == 175000000
     assert roof["hbm_algorithmic"]["frac"] > 1.0            # the L2-resident set: reported, labelled "not a bound"
     assert roof["hbm_physical"]["frac"] < 0.1
