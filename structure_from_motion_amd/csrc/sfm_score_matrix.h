@@ -13,7 +13,9 @@
 // per 32 points x 32 hypotheses: 96 matrix cycles and 3 VALU instructions per accumulator register (square, compare,
 // shift the result bit in) instead of 12 VALU instructions per 64 evaluations.  Points are the A operand (rows), hypotheses
 // the B operand (columns): lane l holds the results of hypothesis (l & 31) for 16 of a step's 32 points (rows
-// (j & 3) + 8 (j >> 2) + 4 (l >> 5), j = accumulator register).
+// (j & 3) + 8 (j >> 2) + 4 (l >> 5), j = accumulator register).  The operand table puts point 16 (l >> 5) + j of the step into
+// that row (point_of_row below), so a lane's sixteen results are sixteen CONSECUTIVE points: the exact tier turns a survivor bit
+// into an address with one shift-and-add, and a lane's gathers fall into one 512-byte stretch of the correspondences.
 //
 // Because a lane belongs to ONE hypothesis, everything behind tier 1 is lane-parallel: each lane pushes its survivors onto its
 // own LDS queue (one word per step with survivors: the step — relative to the item's range — and its 16 survivor bits;
@@ -218,9 +220,13 @@ SFM_DEVICE float hyp_slot_r(const float (&eh)[9], const float (&em)[9], int s) {
 // 8 half .. 8 half + 7 of block b — one coalesced 1 KiB load per block and step.  `ws` holds the data-set maxima (of the
 // coordinates scaled by c) that score_prepare_kernel left.  Rows past n (the ragged last step, the pad steps) have zero operands
 // and a negative constant slot: the sign test rejects them under every hypothesis.
+// Row of the A operand (0..31) -> point of the step it carries: the 32x32 result layout gives lane half H, register j the row
+// (j & 3) + 8 (j >> 2) + 4 H; with this map that row holds point 16 H + j.
+__host__ __device__ inline int point_of_row(int row) { return 16 * ((row >> 2) & 1) + 4 * (row >> 3) + (row & 3); }
+
 SFM_DEVICE void prepare_step(const Corr* __restrict__ corr, int n, double c, const uint32_t* maxima, uint4* __restrict__ table,
                              int t, int l) {
-    const int i = t * kTile + (l & 31);
+    const int i = t * kTile + point_of_row(l & 31);
     const int half = l >> 5;
     float M[9];
     const DataScale data = data_scale(maxima, (float)c * (1.0f + 1e-6f), M);
@@ -501,11 +507,11 @@ __global__ __launch_bounds__(64) void matrix_filter_dump_kernel(const uint4* __r
     d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A2), B2, d, 0, 0, 0);
     r = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A1), B1, r, 0, 0, 0);
     if ((int)blockIdx.y * kHyps + col >= h_count) return;
-    const size_t row0 = (size_t)h * ((size_t)steps * kTile) + (size_t)t * kTile + 4 * half;
+    const size_t point0 = (size_t)h * ((size_t)steps * kTile) + (size_t)t * kTile + 16 * half;   // (register j: point 16 half + j)
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        r_out[row0 + (j & 3) + 8 * (j >> 2)] = r[j];
-        d_out[row0 + (j & 3) + 8 * (j >> 2)] = d[j];
+        r_out[point0 + j] = r[j];
+        d_out[point0 + j] = d[j];
     }
 }
 
@@ -601,7 +607,7 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
     // run to run).  One entry per step and lane instead of one per survivor: the push is a single predicated store.
     int c = 0;
     unsigned head = 0, tail = 0, cur = 0;
-    int cur_base = 0;
+    unsigned cur_off = 0;   // byte offset of the entry's point "-16" in the correspondences (bit 15 - j <-> leading zeros 16 + j)
     double a1 = 0.0, a2 = 0.0;
     // (my_queue: this lane's column of the wave's queue block in LDS — slot k at my_queue[k * kWave])
 #if SFM_MATRIX_STATS || SFM_MATRIX_STAMPS
@@ -616,6 +622,8 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
     // one round of the exact tier: every lane takes up to kPops of its queued points (their gathers in flight together) and
     // scores them, in queue order, under its own hypothesis
     const sfm::SedGate gate = sfm::sed_gate(thr);
+    // bytes: point (step_begin x 32 + 16 half - 16) of the correspondences (kMaxPoints x 32 bytes = 128 MB: 32 bits are plenty)
+    const unsigned lane_off = (unsigned)((step_begin * kTile + 16 * half - 16) * (int)sizeof(Corr));
     auto round = [&]() __attribute__((always_inline)) {
         Corr p[kPops];
         bool active[kPops];
@@ -625,14 +633,14 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
                 const unsigned entry = my_queue[(head & (kCap - 1)) * kWave];
                 ++head;
                 cur = entry & 0xffffu;
-                cur_base = (step_begin + (int)(entry >> 16)) * kTile + 4 * half;   // (the entry keeps the step relative to its range)
+                cur_off = lane_off + ((entry >> 16) << 10);   // (the entry keeps the step relative to its range: 32 points x 32 bytes)
             }
             active[k] = cur != 0u;
-            const int lz = __builtin_clz(cur | 1u);           // 16..31 for a live entry: bit 15 - j is register j
+            const unsigned lz = (unsigned)__builtin_clz(cur | 1u);   // 16..31 for a live entry: bit 15 - j is register j = point j of the lane's sixteen
             cur &= ~(0x80000000u >> lz);
-            const int j = lz - 16;
-            const int i = active[k] ? cur_base + (j & 3) + 8 * (j >> 2) : 0;
-            p[k] = pts[i];
+            // a 32-bit byte offset from the (uniform) base: one shift-and-add, and the load takes base + offset as it is
+            const unsigned off = active[k] ? cur_off + (lz << 5) : 0u;
+            p[k] = *reinterpret_cast<const Corr*>(reinterpret_cast<const unsigned char*>(pts) + off);
         }
 #if SFM_MATRIX_STATS || SFM_MATRIX_STAMPS
         stat_rounds += kPops;
@@ -689,7 +697,7 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
 #pragma unroll
             for (int j = 0; j < ((SFM_MATRIX_ABLATE & 4) ? 1 : 16); ++j)
                 rejected = __builtin_amdgcn_alignbit(rejected, __float_as_uint(__builtin_fmaf(-r[j], r[j], d[j])), 31);
-            unsigned keep = ~rejected & 0xffffu;   // bit 15 - j: row (j & 3) + 8 (j >> 2) + 4 half of this step
+            unsigned keep = ~rejected & 0xffffu;   // bit 15 - j: register j = point 16 half + j of this step
             {
                 // refill this stage.  The loads must stay BEHIND the three matrix instructions that read the stage: hoisted
                 // above the second r' instruction (where instruction selection likes to put them) the load of block 1 needs a

@@ -7,6 +7,9 @@
 #include <algorithm>
 #include <cstdio>
 #include <vector>
+#include <string>
+#include <thread>
+#include <cstdlib>
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -47,7 +50,11 @@ __global__ __launch_bounds__(256) void k(int iters, unsigned long long* stamps, 
             A1 = __builtin_bit_cast(f16x8, stage[1]);
             A2 = __builtin_bit_cast(bf16x8, stage[2]);
         }
-        if (MODE & 1) {
+        if (MODE & 64) {   // matrix instructions alone: accumulate, so that none of them is dead (the sums are consumed after the loop)
+            r = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, B0, r, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B2, d, 0, 0, 0);
+            r = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, B1, r, 0, 0, 0);
+        } else if (MODE & 1) {
             float16v z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             r = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, B0, z, 0, 0, 0);
             d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B2, z, 0, 0, 0);
@@ -87,7 +94,9 @@ __global__ __launch_bounds__(256) void k(int iters, unsigned long long* stamps, 
             t = t + 1 >= steps ? 0 : t + 1;
         }
         total += rejected;
-        if (!(MODE & 1)) {   // keep the test inputs changing so that nothing is hoisted
+        if (MODE & 64) {
+            asm volatile("" : "+v"(A0), "+v"(A1), "+v"(A2));
+        } else if (!(MODE & 1)) {   // keep the test inputs changing so that nothing is hoisted
 #pragma unroll
             for (int j = 0; j < 16; ++j) asm volatile("" : "+v"(r[j]), "+v"(d[j]));
         } else if (!(MODE & 32)) {
@@ -100,7 +109,50 @@ __global__ __launch_bounds__(256) void k(int iters, unsigned long long* stamps, 
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * 4 + threadIdx.x / 64] = t1 - t0;
+    if (MODE & 64) {
+        for (int j = 0; j < 16; ++j) total += __float_as_uint(r[j]) ^ __float_as_uint(d[j]);
+        if (MODE & 32) total += S0[0].x ^ S1[0].x;
+    }
     if (total == 0x12345u) sink[threadIdx.x] = total + pad[0];
+}
+
+// The exact tier's arithmetic alone: `evals` evaluations per iteration of the fp64 sequence of sfm::sed_inlier (20 mul, 16 add,
+// 4 fma, 1 rcp, 2 compares per evaluation), inputs changing through an empty asm; no memory.
+__global__ __launch_bounds__(256) void kf64(int iters, unsigned long long* stamps, unsigned* sink) {
+    extern __shared__ unsigned pad[];
+    double e[9];
+    for (int j = 0; j < 9; ++j) e[j] = 0.1 * (j + 1) + threadIdx.x * 1e-3;
+    double xa = 0.3 + threadIdx.x * 1e-4, ya = -0.2, xb = 0.25, yb = 0.15, a1 = 0.0, a2 = 0.0;
+    int c = 0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            asm volatile("" : "+v"(xa), "+v"(ya), "+v"(xb), "+v"(yb));
+            const double lb0 = (xb * e[0] + yb * e[3]) + e[6];
+            const double lb1 = (xb * e[1] + yb * e[4]) + e[7];
+            const double lb2 = (xb * e[2] + yb * e[5]) + e[8];
+            const double r = (lb0 * xa + lb1 * ya) + lb2;
+            const double la0 = (e[0] * xa + e[1] * ya) + e[2];
+            const double la1 = (e[3] * xa + e[4] * ya) + e[5];
+            const double da = la0 * la0 + la1 * la1;
+            const double db = lb0 * lb0 + lb1 * lb1;
+            const double r2 = r * r;
+            const double q = da * db;
+            double y = __builtin_amdgcn_rcp(q);
+            const double err = __builtin_fma(-q, y, 1.0);
+            y = __builtin_fma(y, __builtin_fma(err, err, err), y);
+            const double sed = ((da + db) * y) * r2;
+            const bool in = sed <= 1.5e-6, in2 = sed <= 1.6e-6;
+            c += (in ? 1 : 0) + (in2 ? 1 : 0);
+            const double kept = in ? sed : 0.0;
+            a1 += kept;
+            a2 = __builtin_fma(kept, kept, a2);
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * 4 + threadIdx.x / 64] = t1 - t0;
+    if (a1 + a2 == 0.12345 && c == 77) sink[threadIdx.x] = pad[0];
 }
 
 // The same step, software-pipelined inside the wave: the three matrix instructions of step t + 1 are issued BEFORE the sixteen
@@ -294,7 +346,65 @@ int run(const char* name, int waves_per_simd, int iters, unsigned long long* sta
     return 0;
 }
 
-int main() {
+// POWER MODE (argv[1] = "power", argv[2] = seconds per variant): each variant is launched back to back for that long at 4
+// waves per SIMD while tools/r04/power_micro.sh samples `rocm-smi --showpower`; one line per variant with its wall-clock
+// window (epoch seconds) and its rate, for the sampler to cut the power trace by.
+#include <chrono>
+static double now_s() {
+    return std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
+}
+template <typename Launch>
+int power_run(const char* name, double seconds, int iters, double units_per_iter, Launch launch) {
+    launch();
+    CHECK(hipDeviceSynchronize());
+    const double begin = now_s();
+    long launches = 0;
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    float ms_total = 0.f;
+    while (now_s() - begin < seconds) {
+        hipEventRecord(a);
+        for (int k = 0; k < 8; ++k) launch();
+        hipEventRecord(b); CHECK(hipEventSynchronize(b));
+        float ms; hipEventElapsedTime(&ms, a, b);
+        ms_total += ms; launches += 8;
+    }
+    const double end = now_s();
+    // 4 waves per SIMD: a launch runs iters x units_per_iter units on every wave, 4 waves share a SIMD
+    printf("POWER %-40s window %.3f %.3f  kernel %.3f ms  %.2f ns per unit and SIMD\n", name, begin, end, ms_total / launches,
+           ms_total / launches * 1e6 / (iters * units_per_iter) / 4.0);
+    fflush(stdout);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1 && std::string(argv[1]) == "power") {
+        const double seconds = argc > 2 ? atof(argv[2]) : 4.0;
+        unsigned long long* stamps; unsigned* sink;
+        CHECK(hipMalloc(&stamps, 8 * 4 * 256 * 8)); CHECK(hipMalloc(&sink, 4096));
+        const int it = 20000, steps = 196, w = 4, blocks = 256 * w;
+        uint4* table;
+        CHECK(hipMalloc(&table, (size_t)8 * steps * 3 * 64 * 16 + 4096));
+        CHECK(hipMemset(table, 0x3c, (size_t)8 * steps * 3 * 64 * 16 + 4096));
+        const size_t lds = (size_t)(160 * 1024 / w) - 1024;
+#define SFM_POWER(KERNEL, NAME, UNITS, ...)                                                                                         \
+        CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
+        if (power_run(NAME, seconds, it, UNITS, [&]() { hipLaunchKernelGGL(KERNEL, dim3(blocks), dim3(256), lds, 0, __VA_ARGS__); })) return 1;
+        printf("POWER idle window %.3f", now_s()); fflush(stdout);
+        std::this_thread::sleep_for(std::chrono::milliseconds((int)(seconds * 1000)));
+        printf(" %.3f\n", now_s());
+        SFM_POWER(k<64 + 1>, "3 matrix instructions (accumulating)", 1.0, it, stamps, sink, (const uint4*)nullptr, 1)
+        SFM_POWER(k<2>, "16 x (fma + alignbit)", 1.0, it, stamps, sink, (const uint4*)nullptr, 1)
+        SFM_POWER(k<3>, "matrix + tests", 1.0, it, stamps, sink, (const uint4*)nullptr, 1)
+        SFM_POWER(k<32 + 3>, "loads + matrix + tests", 1.0, it, stamps, sink, (const uint4*)table, steps)
+        SFM_POWER(k<32 + 2>, "loads + tests", 1.0, it, stamps, sink, (const uint4*)table, steps)
+        SFM_POWER(k<32 + 64 + 1>, "loads + matrix (accumulating)", 1.0, it, stamps, sink, (const uint4*)table, steps)
+        SFM_POWER(kp<true>, "PIPELINED loads + matrix + tests", 1.0, it, stamps, sink, (const uint4*)table, steps)
+        SFM_POWER(kf64, "exact tier arithmetic (4 evaluations)", 4.0, it / 4, stamps, sink)
+        printf("POWER idle window %.3f", now_s()); fflush(stdout);
+        std::this_thread::sleep_for(std::chrono::milliseconds((int)(seconds * 1000)));
+        printf(" %.3f\n", now_s());
+        return 0;
+    }
     unsigned long long* stamps; unsigned* sink;
     CHECK(hipMalloc(&stamps, 8 * 4 * 256 * 8)); CHECK(hipMalloc(&sink, 4096));
     const int it = 20000;

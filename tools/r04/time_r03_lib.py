@@ -13,7 +13,7 @@ from structure_from_motion_amd import device as dev, synthetic  # noqa: E402
 
 n, h = int(os.environ.get("N", 50000)), int(os.environ.get("H", 100000))
 thr = float(os.environ.get("THR", 1.5e-6))
-old = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "base", "libsfm_hip_r03.so"))
+old = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "base", os.environ.get("OLD_LIB", "libsfm_hip_r03.so")))
 old.sfm_score_workspace_bytes.restype = C.c_int64
 old.sfm_score_workspace_bytes.argtypes = [C.c_int64] * 3
 old.sfm_score_sed.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_double, C.c_void_p, C.c_void_p,
