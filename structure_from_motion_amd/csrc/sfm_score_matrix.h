@@ -122,6 +122,13 @@ constexpr int kPops = SFM_MATRIX_POPS;
 #endif
 static_assert(SFM_MATRIX_AHEAD >= 1 && kHigh + SFM_MATRIX_AHEAD <= kCap, "a group of kAhead + 1 steps must fit behind kHigh - 1 entries");
 constexpr int kAhead = SFM_MATRIX_AHEAD;   // steps of operand loads in flight behind the one being processed (register stages: kAhead + 1)
+#ifndef SFM_MATRIX_BUFFER_LOADS
+#define SFM_MATRIX_BUFFER_LOADS 1   // operand refills of the step loop as buffer loads (0: global loads with a 64-bit vector add per step)
+#endif
+#ifndef SFM_MATRIX_MASKED_SUMS
+#define SFM_MATRIX_MASKED_SUMS 0    // 1: the exact tier's count and sums under the execution mask instead of three selects — measured: equal at
+                                    // 50 000 x 100 000, 3-4 % slower at 20 000 x 40 000 and 50 000 x 20 000 (the branch in light waves' drains)
+#endif
 #ifndef SFM_MATRIX_ESTIMATE_STEPS
 #define SFM_MATRIX_ESTIMATE_STEPS 128
 #endif
@@ -606,7 +613,14 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
     // order of the counting sort's atomics: a stack would make the summation order, i.e. the last bits of the sums, vary from
     // run to run).  One entry per step and lane instead of one per survivor: the push is a single predicated store.
     int c = 0;
+    // (head and tail count BYTES of the lane's column, 256 per entry: the slot's address is one and-or away)
     unsigned head = 0, tail = 0, cur = 0;
+    constexpr unsigned kSlotBytes = kWave * 4, kRingMask = (kCap - 1) * kSlotBytes;
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    const uint32_t queue_base = (uint32_t)(uintptr_t)(lds_u32*)my_queue;   // LDS byte address of slot 0: a wave's ring is 8 KiB-aligned
+    auto ring_slot = [&](unsigned counter) __attribute__((always_inline)) {
+        return (lds_u32*)(uintptr_t)(queue_base | (counter & kRingMask));
+    };
     unsigned cur_off = 0;   // byte offset of the entry's point "-16" in the correspondences (bit 15 - j <-> leading zeros 16 + j)
     double a1 = 0.0, a2 = 0.0;
     // (my_queue: this lane's column of the wave's queue block in LDS — slot k at my_queue[k * kWave])
@@ -630,8 +644,8 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
 #pragma unroll
         for (int k = 0; k < kPops; ++k) {
             if (cur == 0u && head != tail) {
-                const unsigned entry = my_queue[(head & (kCap - 1)) * kWave];
-                ++head;
+                const unsigned entry = *ring_slot(head);
+                head += kSlotBytes;
                 cur = entry & 0xffffu;
                 cur_off = lane_off + ((entry >> 16) << 10);   // (the entry keeps the step relative to its range: 32 points x 32 bytes)
             }
@@ -651,16 +665,29 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
         for (int k = 0; k < kPops; ++k) {
             double sed;
             const bool ok = sfm::sed_inlier(e, p[k].xa, p[k].ya, p[k].xb, p[k].yb, gate, sed) && active[k];
+#if SFM_MATRIX_MASKED_SUMS
+            if (ok) {   // under the execution mask (three instructions for the inlier lanes) instead of three selects + three instructions for all
+                asm volatile("" : "+v"(c));
+                c += 1;
+                a1 += sed;
+                a2 = fma(sed, sed, a2);
+            }
+#else
             c += ok ? 1 : 0;
             const double kept = ok ? sed : 0.0;   // masked once; its square is the masked square
             a1 += kept;
             a2 = fma(kept, kept, a2);
+#endif
         }
     };
 
     unsigned survivors = 0;   // ESTIMATE
     if (step_begin < step_end) {
         const uint4* __restrict__ src = table + lane;
+        const unsigned lane_bytes = (unsigned)lane * 16u;
+        // the point operand table as a buffer (gfx9 descriptor: raw, 32-bit data format; range = the table, pad steps included)
+        const __amdgpu_buffer_rsrc_t table_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint4*>(table), (short)0, (int)(table_steps(n) * (int64_t)(kBlocks * 64 * 16)), 0x00020000);
         // Operand loads run kStages steps ahead of the step being processed.  The stages ROTATE — the step loop is unrolled
         // kStages times and stage s is refilled (with the operands of step t + kStages) right behind the three matrix
         // instructions that consumed it — so no register is ever copied: rounds 3's form shifted the stages down once per
@@ -704,12 +731,20 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
                 // copy of the old block 1, and a copy waits for the loads.  The empty asm makes the address depend on `keep`.
                 // (the OFFSET goes through the asm, not the pointer: a pointer coming out of an asm has lost its address space and
                 // the loads become flat_load, which the compiler can only wait for with vmcnt(0))
-                unsigned offset = (unsigned)min(t + kStages, last_loadable) * (kBlocks * 64);   // (wave-uniform: stays in a scalar register)
-                asm volatile("" : "+s"(offset), "+v"(keep));
-                const uint4* nxt = src + offset;
+                // (a buffer load: descriptor + scalar step offset + the lane's constant 32-bit offset + immediate are the load's own
+                // addressing mode — no vector instruction computes an address in this loop; the scalar offset goes through the asm)
+                unsigned step_bytes = (unsigned)min(t + kStages, last_loadable) * (unsigned)(kBlocks * 64 * 16);   // (wave-uniform: a scalar register)
+                asm volatile("" : "+s"(step_bytes), "+v"(keep));
 #if !(SFM_MATRIX_ABLATE & 1)
+#if SFM_MATRIX_BUFFER_LOADS
+#pragma unroll
+                for (int b = 0; b < kBlocks; ++b)
+                    A[stage][b] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(table_rsrc, (int)lane_bytes + b * 1024, (int)step_bytes, 0));
+#else
+                const uint4* nxt = src + step_bytes / 16;
 #pragma unroll
                 for (int b = 0; b < kBlocks; ++b) A[stage][b] = nxt[b * 64];
+#endif
 #endif
             }
             if (ESTIMATE) {
@@ -719,14 +754,14 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
                 survivors += (unsigned)__builtin_popcount(keep);
 #else
                 if (keep != 0u) {   // push: one entry with this step's survivors
-                    my_queue[(tail & (kCap - 1)) * kWave] = ((unsigned)(t - step_begin) << 16) | keep;
-                    ++tail;
+                    *ring_slot(tail) = ((unsigned)(t - step_begin) << 16) | keep;
+                    tail += kSlotBytes;
                 }
 #endif
             }
           }
           t0 += kStages;
-          queue_full = !ESTIMATE && __builtin_amdgcn_ballot_w64((int)(tail - head) >= kHigh) != 0ull;
+          queue_full = !ESTIMATE && __builtin_amdgcn_ballot_w64((int)(tail - head) >= kHigh * (int)kSlotBytes) != 0ull;
          } while (t0 < step_end && !queue_full);
          // Rounds of the exact tier are looked at once per group of kStages steps, not between its stages, and run OUTSIDE the
          // hot loop: that loop is then straight-line code whose operand loads the compiler can count (s_waitcnt
@@ -738,7 +773,7 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
              load_e();
 #endif
              __builtin_amdgcn_wave_barrier();
-             do round(); while (__builtin_amdgcn_ballot_w64((int)(tail - head) > kLow) != 0ull);
+             do round(); while (__builtin_amdgcn_ballot_w64((int)(tail - head) > kLow * (int)kSlotBytes) != 0ull);
          }
         }
     }
@@ -882,7 +917,7 @@ __global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
     const double* __restrict__ E, int h_count, double thr, const int32_t* __restrict__ order, int32_t* __restrict__ cnt,
     double* __restrict__ s1, double* __restrict__ s2, int units, int steps_per_unit, unsigned char* __restrict__ split,
     const unsigned char* __restrict__ fix, int batch, int blocks_per_pair, int32_t* __restrict__ tickets) {
-    __shared__ uint32_t queues[ESTIMATE ? 1 : 256 / kWave][ESTIMATE ? 1 : kCap][kWave];
+    __shared__ alignas(kCap * kWave * 4) uint32_t queues[ESTIMATE ? 1 : 256 / kWave][ESTIMATE ? 1 : kCap][kWave];   // (a wave's ring: 8 KiB, aligned: ring_slot() in matrix_item)
     const int lane = threadIdx.x & (kWave - 1);
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     uint32_t* const my_queue = &queues[ESTIMATE ? 0 : wave_in_block][0][lane];
