@@ -724,17 +724,20 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
 #pragma unroll
             for (int j = 0; j < ((SFM_MATRIX_ABLATE & 4) ? 1 : 16); ++j)
                 rejected = __builtin_amdgcn_alignbit(rejected, __float_as_uint(__builtin_fmaf(-r[j], r[j], d[j])), 31);
-            unsigned keep = ~rejected & 0xffffu;   // bit 15 - j: register j = point 16 half + j of this step
+            // (sixteen shifts: the upper half of `rejected` is zero.)  keep = ~rejected & 0xffff — bit 15 - j: register j = point
+            // 16 half + j of this step — is never materialised on the scoring path: "any survivor" is rejected != 0xffff and the
+            // queue entry (step << 16) | keep is one exclusive-nor of `rejected` with a wave-uniform word
+#define SFM_KEEP_OF(REJECTED) (~(REJECTED) & 0xffffu)
             {
                 // refill this stage.  The loads must stay BEHIND the three matrix instructions that read the stage: hoisted
                 // above the second r' instruction (where instruction selection likes to put them) the load of block 1 needs a
-                // copy of the old block 1, and a copy waits for the loads.  The empty asm makes the address depend on `keep`.
+                // copy of the old block 1, and a copy waits for the loads.  The empty asm makes the address depend on `rejected`.
                 // (the OFFSET goes through the asm, not the pointer: a pointer coming out of an asm has lost its address space and
                 // the loads become flat_load, which the compiler can only wait for with vmcnt(0))
                 // (a buffer load: descriptor + scalar step offset + the lane's constant 32-bit offset + immediate are the load's own
                 // addressing mode — no vector instruction computes an address in this loop; the scalar offset goes through the asm)
                 unsigned step_bytes = (unsigned)min(t + kStages, last_loadable) * (unsigned)(kBlocks * 64 * 16);   // (wave-uniform: a scalar register)
-                asm volatile("" : "+s"(step_bytes), "+v"(keep));
+                asm volatile("" : "+s"(step_bytes), "+v"(rejected));
 #if !(SFM_MATRIX_ABLATE & 1)
 #if SFM_MATRIX_BUFFER_LOADS
 #pragma unroll
@@ -748,13 +751,14 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
 #endif
             }
             if (ESTIMATE) {
-                survivors += (unsigned)__builtin_popcount(keep);
+                survivors += (unsigned)__builtin_popcount(SFM_KEEP_OF(rejected));
             } else {
 #if SFM_MATRIX_ABLATE & 8
-                survivors += (unsigned)__builtin_popcount(keep);
+                survivors += (unsigned)__builtin_popcount(SFM_KEEP_OF(rejected));
 #else
-                if (keep != 0u) {   // push: one entry with this step's survivors
-                    *ring_slot(tail) = ((unsigned)(t - step_begin) << 16) | keep;
+                if (rejected != 0xffffu) {   // push: one entry with this step's survivors
+                    // (step << 16) | keep  ==  ~(rejected ^ k),  k = (step << 16) ^ 0xffff0000 (wave-uniform): one v_xnor
+                    *ring_slot(tail) = ~(rejected ^ ((((unsigned)(t - step_begin)) << 16) ^ 0xffff0000u));
                     tail += kSlotBytes;
                 }
 #endif
