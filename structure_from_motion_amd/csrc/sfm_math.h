@@ -43,10 +43,10 @@ SFM_DEVICE double sed_value(const double e[9], double xa, double ya, double xb, 
 // of a full division:  sed' = (da + db) * rcp(da * db) * r^2.  Six roundings of 2^-53 against sed_value's three: the two differ
 // by at most 1.2e-15 relative while da * db is far from the ends of the exponent range.  The gate's band is a hundred times that:
 //   sed' <= thr - band  an inlier,  sed' > thr + band  an outlier (NaN: every comparison false) — sed_value would say the same;
-//   in between, or with da * db outside [2^-930, 2^930) (zero, subnormal, huge, inf, NaN), sed_value's own division sequence
-//   decides and is the value.
+//   in between, or with a da * db whose reciprocal is not a finite number (zero, deep subnormal, inf, NaN: sed' is then NaN),
+//   sed_value's own division sequence decides and is the value.
 // So the DECISION is always sed_value's; the sums carry the 1.2e-15 (their summation order already differs from the reference's
-// by more: DESIGN.md section 4).  43 fp64-rate instructions per evaluation with the caller's two sums, against 59.
+// by more: DESIGN.md section 4).  43 fp64-rate instructions per evaluation with the caller's two sums, against 63.
 struct SedGate {
     double thr, lo, hi;
 };
@@ -73,12 +73,13 @@ SFM_DEVICE bool sed_inlier(const double e[9], double xa, double ya, double xb, d
     const double err = fma(-q, y, 1.0);
     y = fma(y, fma(err, err, err), y);
     double sed = ((da + db) * y) * r2;
-    const bool in_lo = sed <= gate.lo, in_hi = sed <= gate.hi;
-    // biased exponent of q in [93, 1953): one subtraction and one unsigned comparison on the high word (q is never negative)
-    const uint32_t q_high = (uint32_t)(__double_as_longlong(q) >> 32);
-    const bool q_normal = (q_high - 0x05D00000u) < (0x7A100000u - 0x05D00000u);
+    // No range check of q is needed: when 1 / q is not a finite number (q zero, deep subnormal, inf, NaN) the residual `err` is
+    // -inf or NaN, so y and sed are NaN — and a NaN is "not above hi" and "not at most lo": unclear, like a value inside the band.
+    // (A q in the last two binades next to either end passes with one or two bits of q or y lost to the subnormal grid: 5e-16,
+    // far inside the band.)
+    const bool in_lo = sed <= gate.lo, in_hi = !(sed > gate.hi);
     bool in = in_lo;
-    if (!q_normal || in_lo != in_hi) {
+    if (in_lo != in_hi) {
         asm volatile("" ::: "memory");   // (a real branch: taken by no lane of almost every wave)
         sed = (1.0 / da + 1.0 / db) * r2;
         in = sed <= gate.thr;

@@ -116,6 +116,59 @@ __global__ __launch_bounds__(256) void k(int iters, unsigned long long* stamps, 
     if (total == 0x12345u) sink[threadIdx.x] = total + pad[0];
 }
 
+// Two groups of 32 hypotheses per wave against ONE stream of point operands: six matrix instructions and 2 x 16 sign tests per
+// 3 KiB loaded — half the bytes per evaluation through the L1's 64 B/clk return path.  Same two-stage rotation as k<35>.
+__global__ __launch_bounds__(256) void k2(int iters, unsigned long long* stamps, unsigned* sink, const uint4* __restrict__ table, int steps) {
+    extern __shared__ unsigned pad[];
+    f16x8 B0[2], B1[2];
+    bf16x8 B2[2];
+    for (int g = 0; g < 2; ++g)
+        for (int j = 0; j < 8; ++j) { B0[g][j] = (_Float16)(1.0f + j + g); B1[g][j] = (_Float16)(0.25f * j + g); B2[g][j] = (__bf16)(2.0f + j + g); }
+    unsigned total = 0;
+    uint4 S0[3], S1[3];
+    const uint4* src = table + (threadIdx.x & 63);
+    const int first = (int)((blockIdx.x & 7) * (unsigned)steps);
+    for (int b = 0; b < 3; ++b) S0[b] = src[((size_t)first * 3 + b) * 64];
+    __builtin_amdgcn_sched_barrier(0);
+    for (int b = 0; b < 3; ++b) S1[b] = src[((size_t)(first + 1) * 3 + b) * 64];
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    int t = 0;
+    auto step = [&](uint4 (&stage)[3]) __attribute__((always_inline)) {
+        const f16x8 A0 = __builtin_bit_cast(f16x8, stage[0]), A1 = __builtin_bit_cast(f16x8, stage[1]);
+        const bf16x8 A2 = __builtin_bit_cast(bf16x8, stage[2]);
+        const float16v z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        float16v r[2], d[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            r[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0, B0[g], z, 0, 0, 0);
+            d[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B2[g], z, 0, 0, 0);
+            r[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1, B1[g], r[g], 0, 0, 0);
+        }
+        unsigned rejected[2] = {0, 0};
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                rejected[g] = __builtin_amdgcn_alignbit(rejected[g], __float_as_uint(__builtin_fmaf(-r[g][j], r[g][j], d[g][j])), 31);
+        int next = t + 2;
+        next = next >= steps ? next - steps : next;
+        unsigned offset = (unsigned)(first + next) * 192u;
+        asm volatile("" : "+v"(offset), "+v"(rejected[1]));
+#pragma unroll
+        for (int b = 0; b < 3; ++b) stage[b] = src[offset + b * 64];
+        t = t + 1 >= steps ? 0 : t + 1;
+        total += rejected[0] + rejected[1];
+    };
+    for (int i = 0; i < iters; i += 2) {
+        step(S0);
+        step(S1);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * 4 + threadIdx.x / 64] = t1 - t0;
+    if (total == 0x12345u) sink[threadIdx.x] = total + pad[0];
+}
+
 // The exact tier's arithmetic alone: `evals` evaluations per iteration of the fp64 sequence of sfm::sed_inlier (20 mul, 16 add,
 // 4 fma, 1 rcp, 2 compares per evaluation), inputs changing through an empty asm; no memory.
 __global__ __launch_bounds__(256) void kf64(int iters, unsigned long long* stamps, unsigned* sink) {
@@ -399,6 +452,17 @@ int main(int argc, char** argv) {
         SFM_POWER(k<32 + 2>, "loads + tests", 1.0, it, stamps, sink, (const uint4*)table, steps)
         SFM_POWER(k<32 + 64 + 1>, "loads + matrix (accumulating)", 1.0, it, stamps, sink, (const uint4*)table, steps)
         SFM_POWER(kp<true>, "PIPELINED loads + matrix + tests", 1.0, it, stamps, sink, (const uint4*)table, steps)
+        SFM_POWER(k2, "TWO GROUPS per wave, 4 waves/SIMD (per 2048 evaluations)", 1.0, it, stamps, sink, (const uint4*)table, steps)
+        {
+            const int blocks2 = 256 * 2;
+            const size_t lds2 = (size_t)(160 * 1024 / 2) - 1024;
+            CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+            if (power_run("TWO GROUPS per wave, 2 waves/SIMD (x2: per 2048 evaluations at 4-wave normalisation)", seconds, it, 1.0,
+                          [&]() { hipLaunchKernelGGL(k2, dim3(blocks2), dim3(256), lds2, 0, it, stamps, sink, (const uint4*)table, steps); })) return 1;
+            CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k<32 + 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+            if (power_run("ONE group per wave, 2 waves/SIMD (same normalisation)", seconds, it, 1.0,
+                          [&]() { hipLaunchKernelGGL(k<32 + 3>, dim3(blocks2), dim3(256), lds2, 0, it, stamps, sink, (const uint4*)table, steps); })) return 1;
+        }
         SFM_POWER(kf64, "exact tier arithmetic (4 evaluations)", 4.0, it / 4, stamps, sink)
         printf("POWER idle window %.3f", now_s()); fflush(stdout);
         std::this_thread::sleep_for(std::chrono::milliseconds((int)(seconds * 1000)));
