@@ -42,6 +42,7 @@ BYTES_PER_EVAL = 32.0          # xa, ya, xb, yb as f64, read once per hypothesis
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); ~6290 measured-achievable
 SIMDS, CLOCK_GHZ = 1024, 2.4   # 256 CUs x 4 SIMD-32; max clock (MI355X_MICROARCH.md chip table)
 CYC_VALU, CYC_F64 = 2.0, 4.0   # spec issue cycles per wave64 instruction: v_fma_f32 2 (SIMD-32); fp64 at half rate
+MEASURED_CYC_VALU, MEASURED_CYC_F64, MEASURED_CYC_MFMA = 3.3, 4.16, 32.0   # profiles/r04/micro_power_by_piece.txt (see roofline())
 CYC_MFMA = 8.0                 # vector-issue cycles a 32x32x16 16-bit MFMA holds (MI355X_MICROARCH.md cycle constants); it runs 32 on the matrix pipe
 FP64_PER_EVAL = 43             # fp64-rate wave-instructions of one evaluation of the exact tier (sfm::sed_inlier + the two sums as compiled:
                                # 20 mul, 16 add, 4 fma, 1 rcp, 2 compares — counted in the disassembly; -ffp-contract=off).  Until
@@ -240,6 +241,15 @@ def roofline(n, h, kernel_ms, call_ms, variant, exact_evals=None):
                    "issue_cycles_per_simd": cycles / SIMDS, "mfma_mops_f32": mfma or None, "mfma_insts": mfma_insts or None,
                    "matrix_pipe_busy_frac": (c["SQ_VALU_MFMA_BUSY_CYCLES"] / SIMDS / (seconds * CLOCK_GHZ * 1e9)
                                              if c.get("SQ_VALU_MFMA_BUSY_CYCLES") else None)}
+    # the same instruction stream at the rates this part was MEASURED to sustain (tools/micro/matrix_step_rates.hip, power mode,
+    # 4 waves per SIMD: profiles/r04/micro_power_by_piece.txt): 3.3 cycles per plain vector instruction, 4.16 per fp64 one, and
+    # the 32 matrix-pipe cycles of a 16-bit MFMA in full — matrix and vector work of a SIMD add up on this part, they do not overlap
+    measured = (valu - f64) * MEASURED_CYC_VALU + f64 * MEASURED_CYC_F64 + mfma_insts * MEASURED_CYC_MFMA
+    out["issue_at_measured_rates"] = {
+        "ms_at_2p4_GHz": measured / SIMDS / (CLOCK_GHZ * 1e9) * 1e3, "frac_of_kernel": measured / SIMDS / (CLOCK_GHZ * 1e9) / seconds,
+        "cycles_per_inst": {"valu": MEASURED_CYC_VALU, "fp64": MEASURED_CYC_F64, "mfma_16bit_32x32x16": MEASURED_CYC_MFMA},
+        "note": "what the counted instructions take at the issue rates measured on this part, at the nominal clock: the rest of "
+                "the kernel time is the clock the power manager leaves (1.35 kW of a 1.4 kW cap under this load) and idle slots"}
     if "GRBM_GUI_ACTIVE" in c and c.get("profiled_kernel_ms"):
         clock = c["GRBM_GUI_ACTIVE"] / 8.0 / (c["profiled_kernel_ms"] * 1e-3) / 1e9
         out["valu"]["clock_GHz_under_profiler"] = clock
