@@ -643,7 +643,7 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
         bool active[kPops];
 #pragma unroll
         for (int k = 0; k < kPops; ++k) {
-            if (cur == 0u && head != tail) {
+            if ((cur == 0u) & (head != tail)) {   // (one masked region, not two nested ones)
                 const unsigned entry = *ring_slot(head);
                 head += kSlotBytes;
                 cur = entry & 0xffffu;
