@@ -129,8 +129,9 @@ int sfm_hartley_normalize(const double* coords, int64_t n, double* out, void* st
  * the all-fp64 kernel.
  * Footprint: sfm_score_workspace_bytes reserves, whether or not a launch ends up using them, 16 bytes per point (fp32 points),
  * 16 KiB of counters per pair, 4 + 324 bytes per hypothesis (scoring order, the partials of up to 16 ranges) and — for pairs of at
- * most 4 194 304 points — the matrix-pipe kernel's tables: 96 bytes per point, 96 + 20 bytes per hypothesis.  50 000 x 100 000:
- * 50 MB; 256 pairs x 10 000 x 2 000: 521 MB; one pair x 1 000 000 hypotheses: 450 MB. */
+ * most 4 194 304 points — the matrix-pipe kernel's tables: 96 bytes per point, 96 + 20 bytes per hypothesis, and for a single
+ * pair 512 bytes per hypothesis of filter results that the cost pre-pass hands to the scoring launch.  50 000 x 100 000:
+ * 101 MB; 256 pairs x 10 000 x 2 000: 521 MB; one pair x 1 000 000 hypotheses: 962 MB. */
 int64_t sfm_score_workspace_bytes(int64_t n, int64_t h_count, int64_t batch);
 int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t* S, int64_t h_count,
                   int64_t batch, double thr, int32_t* cnt, double* s1, double* s2, void* workspace,

@@ -129,6 +129,9 @@ constexpr int kAhead = SFM_MATRIX_AHEAD;   // steps of operand loads in flight b
 #define SFM_MATRIX_MASKED_SUMS 0    // 1: the exact tier's count and sums under the execution mask instead of three selects — measured: equal at
                                     // 50 000 x 100 000, 3-4 % slower at 20 000 x 40 000 and 50 000 x 20 000 (the branch in light waves' drains)
 #endif
+#ifndef SFM_MATRIX_REPLAY
+#define SFM_MATRIX_REPLAY 1         // the scoring launch replays the tier-1 results of the cost pre-pass (MatrixPair::record); 0: computes them again
+#endif
 #ifndef SFM_MATRIX_ESTIMATE_STEPS
 #define SFM_MATRIX_ESTIMATE_STEPS 128
 #endif
@@ -540,7 +543,16 @@ struct MatrixPair {   // the arrays of one image pair
     double* __restrict__ s2;
     unsigned char* __restrict__ split;
     const unsigned char* __restrict__ fix;   // sample corrections of matrix_hypothesis_kernel: [h] int32 | [h] double | [h] double
+    // Tier-1 results the cost pre-pass leaves for the scoring launch (nullptr: none): the reject word of every (hypothesis, lane
+    // half, range, step) it scanned — [h][half][kReplayRanges][kReplaySteps] uint16, 32 bytes per (hypothesis, half, range) —
+    // when the pre-pass scans the FIRST kReplaySteps steps of each of the scoring launch's ranges instead of the first steps of
+    // the points: the scoring wave of a range then replays those words (five vector instructions a step) instead of computing
+    // them again (three matrix and 36 vector instructions): the pre-pass' 8 % of tier 1 is no longer done twice.
+    uint16_t* __restrict__ record;
+    int range_stride;   // steps between the starts of the pre-pass' ranges (= the scoring launch's steps per range) when recording
 };
+constexpr int kReplaySteps = 16, kReplayRanges = 8;   // 8 ranges x 16 steps = the pre-pass' 128 steps (4096 points)
+__host__ __device__ inline int64_t record_bytes(int64_t h_count) { return sfmws::matrix_record_bytes(h_count); }
 
 // One wave-uniform ticket from an agent-scope counter, in straight-line assembly with the exec mask set by hand: written as
 // `if (lane == 0) t = atomicAdd(..); t = readfirstlane(t)` inside a loop the compiler may thread the inactive lanes past the
@@ -629,7 +641,12 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
 #endif
 
     const int steps_total = (int)steps_of(n);
-    const int step_begin = units > 1 ? unit * steps_per_unit : 0;   // (steps_per_unit is a multiple of kStages: ranges start on group boundaries)
+    const bool recording = ESTIMATE && a.record != nullptr;    // the pre-pass of a launch that replays (see MatrixPair::record)
+    const bool replaying = !ESTIMATE && a.record != nullptr;
+    // (steps_per_unit is a multiple of kStages: ranges start on group boundaries)
+    const int step_begin = units > 1 ? unit * (recording ? a.range_stride : steps_per_unit) : 0;
+    uint16_t* const my_record = a.record == nullptr ? nullptr
+        : a.record + (((int64_t)h * 2 + half) * kReplayRanges + unit) * kReplaySteps;   // this lane's 16 words of this range
     const int step_end = units > 1 || ESTIMATE ? min(step_begin + steps_per_unit, steps_total) : steps_total;
     const int last_loadable = (int)table_steps(n) - 1;
 
@@ -682,6 +699,9 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
     };
 
     unsigned survivors = 0;   // ESTIMATE
+    unsigned rec[4] = {0u, 0u, 0u, 0u}, rec_low = 0u;   // ESTIMATE, recording: the reject words of the last eight steps
+    static_assert(kAhead + 1 == 2 || !SFM_MATRIX_REPLAY, "the recording pre-pass packs the two steps of a loop group into one dword");
+    const int first_step = step_begin + (replaying ? kReplaySteps : 0);   // (the host replays only when every range has that many steps)
     if (step_begin < step_end) {
         const uint4* __restrict__ src = table + lane;
         const unsigned lane_bytes = (unsigned)lane * 16u;
@@ -701,10 +721,24 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
 #pragma unroll
         for (int a = 0; a < kStages; ++a) {
 #pragma unroll
-            for (int b = 0; b < kBlocks; ++b) A[a][b] = src[((size_t)min(step_begin + a, last_loadable) * kBlocks + b) * 64];
+            for (int b = 0; b < kBlocks; ++b) A[a][b] = src[((size_t)min(first_step + a, last_loadable) * kBlocks + b) * 64];
             __builtin_amdgcn_sched_barrier(0);
         }
-        int t0 = step_begin;
+        if (replaying) {
+            // the first kReplaySteps steps of the range: the pre-pass' reject words instead of tier 1 (at most 16 pushes into an
+            // empty ring of kCap = 32: no round can be due)
+            const uint4 w0 = reinterpret_cast<const uint4*>(my_record)[0], w1 = reinterpret_cast<const uint4*>(my_record)[1];
+            const unsigned words[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+            for (int s = 0; s < kReplaySteps; ++s) {
+                const unsigned rejected = (s & 1) ? words[s >> 1] >> 16 : words[s >> 1] & 0xffffu;
+                if (rejected != 0xffffu) {
+                    *ring_slot(tail) = ~(rejected ^ (((unsigned)s << 16) ^ 0xffff0000u));
+                    tail += kSlotBytes;
+                }
+            }
+        }
+        int t0 = first_step;
         while (t0 < step_end) {
          bool queue_full = false;
          do {   // the hot loop: groups of kStages steps until a queue is full (or the range ends)
@@ -752,6 +786,16 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
             }
             if (ESTIMATE) {
                 survivors += (unsigned)__builtin_popcount(SFM_KEEP_OF(rejected));
+                if (recording) {   // two steps make a dword, four dwords a 16-byte store (below): not sixteen scattered 2-byte stores a wave
+                    if (stage & 1) {
+                        rec[0] = rec[1];
+                        rec[1] = rec[2];
+                        rec[2] = rec[3];
+                        rec[3] = rec_low | (rejected << 16);
+                    } else {
+                        rec_low = rejected;
+                    }
+                }
             } else {
 #if SFM_MATRIX_ABLATE & 8
                 survivors += (unsigned)__builtin_popcount(SFM_KEEP_OF(rejected));
@@ -765,6 +809,8 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
             }
           }
           t0 += kStages;
+          if (recording && ((t0 - step_begin) & 7) == 0)   // (wave-uniform) the last eight steps' words: [t0 - 8, t0)
+              *reinterpret_cast<uint4*>(my_record + (t0 - step_begin - 8)) = make_uint4(rec[0], rec[1], rec[2], rec[3]);
           queue_full = !ESTIMATE && __builtin_amdgcn_ballot_w64((int)(tail - head) >= kHigh * (int)kSlotBytes) != 0ull;
          } while (t0 < step_end && !queue_full);
          // Rounds of the exact tier are looked at once per group of kStages steps, not between its stages, and run OUTSIDE the
@@ -920,12 +966,13 @@ __global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
     const Corr* __restrict__ pts, const uint4* __restrict__ hyp_table, const uint4* __restrict__ table, int n,
     const double* __restrict__ E, int h_count, double thr, const int32_t* __restrict__ order, int32_t* __restrict__ cnt,
     double* __restrict__ s1, double* __restrict__ s2, int units, int steps_per_unit, unsigned char* __restrict__ split,
-    const unsigned char* __restrict__ fix, int batch, int blocks_per_pair, int32_t* __restrict__ tickets) {
+    const unsigned char* __restrict__ fix, int batch, int blocks_per_pair, int32_t* __restrict__ tickets,
+    uint16_t* __restrict__ record, int range_stride) {
     __shared__ alignas(kCap * kWave * 4) uint32_t queues[ESTIMATE ? 1 : 256 / kWave][ESTIMATE ? 1 : kCap][kWave];   // (a wave's ring: 8 KiB, aligned: ring_slot() in matrix_item)
     const int lane = threadIdx.x & (kWave - 1);
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     uint32_t* const my_queue = &queues[ESTIMATE ? 0 : wave_in_block][0][lane];
-    MatrixPair a{pts, hyp_table, table, E, order, cnt, s1, s2, split, fix};
+    MatrixPair a{pts, hyp_table, table, E, order, cnt, s1, s2, split, fix, record, range_stride};
     if (tickets != nullptr) {
         const int waves32 = (h_count + kHyps - 1) / kHyps;
         const bool by_xcc = units % 8 == 0;

@@ -81,8 +81,14 @@ __host__ __device__ inline int64_t matrix_fix_bytes(int64_t h_count) { return sp
 __host__ __device__ inline int64_t ws_matrix_fix_offset(int64_t n, int64_t h_count, int64_t batch) {
     return ((ws_matrix_hyp_offset(n, h_count, batch) + batch * matrix_hyp_table_bytes(n, h_count) + 255) / 256) * 256;
 }
+// ... and, for one pair, the reject words the cost pre-pass records for the scoring launch (sfm_score_matrix.h, MatrixPair::record):
+// [h_pad][2 halves][8 ranges][16 steps] uint16
+__host__ __device__ inline int64_t matrix_record_bytes(int64_t h_count) { return split_padded(h_count) * (2 * 8 * 16 * 2); }
+__host__ __device__ inline int64_t ws_matrix_record_offset(int64_t n, int64_t h_count, int64_t batch) {
+    return ((ws_matrix_fix_offset(n, h_count, batch) + (n <= kMatrixMaxPoints ? batch * matrix_fix_bytes(h_count) : 0) + 255) / 256) * 256;
+}
 __host__ __device__ inline int64_t workspace_bytes_for(int64_t n, int64_t h_count, int64_t batch) {
-    return ws_matrix_fix_offset(n, h_count, batch) + (n <= kMatrixMaxPoints ? batch * matrix_fix_bytes(h_count) : 0);
+    return ws_matrix_record_offset(n, h_count, batch) + (n <= kMatrixMaxPoints && batch == 1 ? matrix_record_bytes(h_count) : 0);
 }
 // Work counters of the matrix-pipe kernel's persistent waves (one per XCD, a 64-byte line each), in the words of the class-counter
 // block that no class uses (classes end at int 16 * 240 = 3840); score_reset_kernel zeroes them with the class counters.
