@@ -551,7 +551,8 @@ struct MatrixPair {   // the arrays of one image pair
     uint16_t* __restrict__ record;
     int range_stride;   // steps between the starts of the pre-pass' ranges (= the scoring launch's steps per range) when recording
 };
-constexpr int kReplaySteps = 16, kReplayRanges = 8;   // 8 ranges x 16 steps = the pre-pass' 128 steps (4096 points)
+constexpr int kReplayRanges = 8, kReplaySteps = kEstimateSteps / kReplayRanges;   // 8 ranges x 16 steps = the pre-pass' 128 steps (4096 points)
+static_assert(kReplaySteps % 8 == 0 && kReplaySteps <= kCap - 4, "whole 16-byte stores; the replayed entries fit the empty ring");
 __host__ __device__ inline int64_t record_bytes(int64_t h_count) { return sfmws::matrix_record_bytes(h_count); }
 
 // One wave-uniform ticket from an agent-scope counter, in straight-line assembly with the exec mask set by hand: written as
@@ -727,8 +728,12 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
         if (replaying) {
             // the first kReplaySteps steps of the range: the pre-pass' reject words instead of tier 1 (at most 16 pushes into an
             // empty ring of kCap = 32: no round can be due)
-            const uint4 w0 = reinterpret_cast<const uint4*>(my_record)[0], w1 = reinterpret_cast<const uint4*>(my_record)[1];
-            const unsigned words[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+            unsigned words[kReplaySteps / 2];
+#pragma unroll
+            for (int q = 0; q < kReplaySteps / 8; ++q) {
+                const uint4 w = reinterpret_cast<const uint4*>(my_record)[q];
+                words[4 * q] = w.x, words[4 * q + 1] = w.y, words[4 * q + 2] = w.z, words[4 * q + 3] = w.w;
+            }
 #pragma unroll
             for (int s = 0; s < kReplaySteps; ++s) {
                 const unsigned rejected = (s & 1) ? words[s >> 1] >> 16 : words[s >> 1] & 0xffffu;

@@ -82,8 +82,11 @@ __host__ __device__ inline int64_t ws_matrix_fix_offset(int64_t n, int64_t h_cou
     return ((ws_matrix_hyp_offset(n, h_count, batch) + batch * matrix_hyp_table_bytes(n, h_count) + 255) / 256) * 256;
 }
 // ... and, for one pair, the reject words the cost pre-pass records for the scoring launch (sfm_score_matrix.h, MatrixPair::record):
-// [h_pad][2 halves][8 ranges][16 steps] uint16
-__host__ __device__ inline int64_t matrix_record_bytes(int64_t h_count) { return split_padded(h_count) * (2 * 8 * 16 * 2); }
+// [h_pad][2 halves][8 ranges][an eighth of the pre-pass' steps] uint16
+#ifndef SFM_MATRIX_ESTIMATE_STEPS
+#define SFM_MATRIX_ESTIMATE_STEPS 128   // steps of 32 points the matrix-pipe kernel's cost pre-pass scans at most (4096 points)
+#endif
+__host__ __device__ inline int64_t matrix_record_bytes(int64_t h_count) { return split_padded(h_count) * (2 * SFM_MATRIX_ESTIMATE_STEPS * 2); }
 __host__ __device__ inline int64_t ws_matrix_record_offset(int64_t n, int64_t h_count, int64_t batch) {
     return ((ws_matrix_fix_offset(n, h_count, batch) + (n <= kMatrixMaxPoints ? batch * matrix_fix_bytes(h_count) : 0) + 255) / 256) * 256;
 }
