@@ -1153,12 +1153,14 @@ int launch_matrix(const FilteredLaunch& a) {
         // `cnt`, which the scoring launch rewrites), then the counting sort by class
         const int e_steps = estimate_steps(a.n);
         // a single pair: four ranges of the pre-pass's steps — or, recording, the first steps of each of the scoring launch's eight
-        const int e_units = record != nullptr ? kReplayRanges : (a.batch == 1 && e_steps >= 128 ? 4 : 1);
+        // (recording: kReplayRanges / 2 units in the launch, each wave takes two of the ranges — see the kernel)
+        const int e_units = record != nullptr ? kReplayRanges / 2 : (a.batch == 1 && e_steps >= 128 ? 4 : 1);
         if (e_units > 1 && !fused_setup)   // (the ranges of the pre-pass add into `cnt`: zeroed by matrix_setup_kernel otherwise)
             hipLaunchKernelGGL(score_split_reset_kernel, dim3(grid_stride(a.h_count, 256, 1024)), dim3(256), 0, a.st, a.cnt,
                                (int64_t)a.h_count);
         hipLaunchKernelGGL(score_sed_matrix_kernel<true>, dim3(flat * (unsigned)e_units), dim3(256), 0, a.st, a.corr, hyp_table, table,
-                           a.n, a.E, a.h_count, a.thr, (const int32_t*)nullptr, a.cnt, a.s1, a.s2, e_units, e_steps / e_units,
+                           a.n, a.E, a.h_count, a.thr, (const int32_t*)nullptr, a.cnt, a.s1, a.s2, e_units,
+                           record != nullptr ? kReplaySteps : e_steps / e_units,
                            (unsigned char*)nullptr, (const unsigned char*)nullptr, (int)a.batch, blocks_per_pair, (int32_t*)nullptr,
                            record, a.chunks_per_unit);
         const dim3 per_hyp(grid_for(a.h_count, 256), pairs);

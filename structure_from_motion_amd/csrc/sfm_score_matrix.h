@@ -544,7 +544,7 @@ struct MatrixPair {   // the arrays of one image pair
     unsigned char* __restrict__ split;
     const unsigned char* __restrict__ fix;   // sample corrections of matrix_hypothesis_kernel: [h] int32 | [h] double | [h] double
     // Tier-1 results the cost pre-pass leaves for the scoring launch (nullptr: none): the reject word of every (hypothesis, lane
-    // half, range, step) it scanned — [h][half][kReplayRanges][kReplaySteps] uint16, 32 bytes per (hypothesis, half, range) —
+    // half, range, step) it scanned — 32 bytes per (hypothesis, half, range), laid out [range][8 steps][hypothesis][half] x 16 bytes —
     // when the pre-pass scans the FIRST kReplaySteps steps of each of the scoring launch's ranges instead of the first steps of
     // the points: the scoring wave of a range then replays those words (five vector instructions a step) instead of computing
     // them again (three matrix and 36 vector instructions): the pre-pass' 8 % of tier 1 is no longer done twice.
@@ -646,8 +646,13 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
     const bool replaying = !ESTIMATE && a.record != nullptr;
     // (steps_per_unit is a multiple of kStages: ranges start on group boundaries)
     const int step_begin = units > 1 ? unit * (recording ? a.range_stride : steps_per_unit) : 0;
-    uint16_t* const my_record = a.record == nullptr ? nullptr
-        : a.record + (((int64_t)h * 2 + half) * kReplayRanges + unit) * kReplaySteps;   // this lane's 16 words of this range
+    // this lane's words of this range: 16-byte chunks of eight steps, [range][chunk][hypothesis][half] — the pre-pass, whose lanes
+    // are consecutive hypotheses, stores 2 KiB per wave and chunk in one piece; the scoring wave gathers its chunks by hypothesis
+    // either way.  (The first layout kept a lane's chunks together, 512 bytes from the next lane's: the pre-pass took 73 us
+    // instead of 55 for its 50 000 store instructions of 64 separate lines each.)
+    const int64_t record_stride = sfmws::split_padded(h_count) * 2;   // chunks between a lane's consecutive chunks
+    uint4* const my_record = a.record == nullptr ? nullptr
+        : reinterpret_cast<uint4*>(a.record) + (int64_t)unit * (kReplaySteps / 8) * record_stride + (int64_t)h * 2 + half;
     const int step_end = units > 1 || ESTIMATE ? min(step_begin + steps_per_unit, steps_total) : steps_total;
     const int last_loadable = (int)table_steps(n) - 1;
 
@@ -731,7 +736,7 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
             unsigned words[kReplaySteps / 2];
 #pragma unroll
             for (int q = 0; q < kReplaySteps / 8; ++q) {
-                const uint4 w = reinterpret_cast<const uint4*>(my_record)[q];
+                const uint4 w = my_record[q * record_stride];
                 words[4 * q] = w.x, words[4 * q + 1] = w.y, words[4 * q + 2] = w.z, words[4 * q + 3] = w.w;
             }
 #pragma unroll
@@ -815,7 +820,7 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
           }
           t0 += kStages;
           if (recording && ((t0 - step_begin) & 7) == 0)   // (wave-uniform) the last eight steps' words: [t0 - 8, t0)
-              *reinterpret_cast<uint4*>(my_record + (t0 - step_begin - 8)) = make_uint4(rec[0], rec[1], rec[2], rec[3]);
+              my_record[((t0 - step_begin) / 8 - 1) * record_stride] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
           queue_full = !ESTIMATE && __builtin_amdgcn_ballot_w64((int)(tail - head) >= kHigh * (int)kSlotBytes) != 0ull;
          } while (t0 < step_end && !queue_full);
          // Rounds of the exact tier are looked at once per group of kStages steps, not between its stages, and run OUTSIDE the
@@ -838,7 +843,8 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
         unsigned sixteenths = (unsigned)(((unsigned long long)both * 16384ull) / (scanned > 0u ? scanned : 1u));
         sixteenths = both > 0u && sixteenths == 0u ? 1u : sixteenths;
         if (half == 0 && valid) {
-            if (units > 1) atomicAdd(cnt + h, (int32_t)sixteenths);   // integer sums: any order (the launcher zeroed cnt)
+            // integer sums: any order (the launcher zeroed cnt).  (Plain stores instead — a timing experiment — change nothing: 70 vs 73 us.)
+            if (units > 1) atomicAdd(cnt + h, (int32_t)sixteenths);
             else cnt[h] = (int32_t)sixteenths;
         }
         return;
@@ -1028,6 +1034,13 @@ __global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
         block_of_range /= units;
     }
     const int wave = block_of_range * (256 / kWave) + wave_in_block;
+    if (ESTIMATE && record != nullptr) {
+        // the recording pre-pass: a wave scans the first steps of TWO of the scoring launch's ranges (the launch has kReplayRanges / 2
+        // "units"): waves of 16 steps spend a quarter of their time starting up (72 us for the pre-pass against 55 with 32-step waves)
+        matrix_item<ESTIMATE>(a, n, h_count, thr, 2 * units, steps_per_unit, wave, 2 * unit, my_queue, lane, 0u);
+        matrix_item<ESTIMATE>(a, n, h_count, thr, 2 * units, steps_per_unit, wave, 2 * unit + 1, my_queue, lane, 0u);
+        return;
+    }
     matrix_item<ESTIMATE>(a, n, h_count, thr, units, steps_per_unit, wave, unit, my_queue, lane,
                           blockIdx.x * (256 / kWave) + wave_in_block);
 }
