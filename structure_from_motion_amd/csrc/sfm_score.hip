@@ -1137,32 +1137,36 @@ int launch_matrix(const FilteredLaunch& a) {
     const int blocks_per_pair = a.batch > 1 ? (int)blocks : 0;
     const unsigned flat = a.batch > 1 ? blocks * (unsigned)((a.batch + 7) / 8 * 8) : blocks;
     const int32_t* order_arg = nullptr;
-    // The pre-pass' tier-1 results are kept for the scoring launch when that launch has kReplayRanges ranges of at least
-    // kReplaySteps steps each and the pre-pass scans its full 128 steps: it then scans the first 16 steps of every range and
-    // records the reject words, which the scoring waves replay (MatrixPair::record).
+    // The pre-pass' tier-1 results are kept for the scoring launch (MatrixPair::record): the pre-pass then scans the first
+    // kReplaySteps steps of every range of the scoring launch — which must all have that many — instead of the first steps of the
+    // points, records the reject words, and the scoring waves replay them.  Taken when that scan is exactly as large as the
+    // pre-pass would be otherwise (8 ranges x 16 steps = the 128 steps of a large single pair; with 16 ranges — 50 000 x 20 000,
+    // 20 000 x 40 000 — the larger pre-pass costs 3-8 us more than the replay saves), and for a single pair only: for
+    // the 256 pairs of C5 — 9 ranges of 36 steps, so 44 % of all reject words would go through memory, 590 MB written and read —
+    // it was measured a loss (2.71 ms per batch against 2.57-2.69, whether a pre-pass wave took one range or all nine).
     uint16_t* record = nullptr;
-    using matrixscore::kReplayRanges;
     using matrixscore::kReplaySteps;
 #if SFM_MATRIX_REPLAY
-    if (a.use_order && a.batch == 1 && a.units == kReplayRanges && matrixscore::estimate_steps(a.n) == kReplayRanges * kReplaySteps &&
-        a.chunks_per_unit >= kReplaySteps && (int)matrixscore::steps_of(a.n) - (a.units - 1) * a.chunks_per_unit >= kReplaySteps)
-        record = reinterpret_cast<uint16_t*>(a.ws + ws_matrix_record_offset(a.n, a.h_count, 1));
+    if (a.use_order && a.batch == 1 && a.units >= 2 && a.units % 2 == 0 && a.units * kReplaySteps == matrixscore::estimate_steps(a.n) &&
+        a.chunks_per_unit >= kReplaySteps &&
+        (int)matrixscore::steps_of(a.n) - (a.units - 1) * a.chunks_per_unit >= kReplaySteps)
+        record = reinterpret_cast<uint16_t*>(a.ws + ws_matrix_record_offset(a.n, a.h_count, a.batch));
 #endif
     if (a.use_order) {
         // cost pre-pass with this kernel's own tier 1 over the first steps (survivors per 1024 points, in sixteenths, into
         // `cnt`, which the scoring launch rewrites), then the counting sort by class
         const int e_steps = estimate_steps(a.n);
-        // a single pair: four ranges of the pre-pass's steps — or, recording, the first steps of each of the scoring launch's eight
-        // (recording: kReplayRanges / 2 units in the launch, each wave takes two of the ranges — see the kernel)
-        const int e_units = record != nullptr ? kReplayRanges / 2 : (a.batch == 1 && e_steps >= 128 ? 4 : 1);
-        if (e_units > 1 && !fused_setup)   // (the ranges of the pre-pass add into `cnt`: zeroed by matrix_setup_kernel otherwise)
-            hipLaunchKernelGGL(score_split_reset_kernel, dim3(grid_stride(a.h_count, 256, 1024)), dim3(256), 0, a.st, a.cnt,
-                               (int64_t)a.h_count);
+        // a single pair: four ranges of the pre-pass's steps — or, recording, the first steps of each of the scoring launch's ranges
+        // (a single pair: half as many units in the launch, each wave takes two of the ranges; a batch: one unit, all ranges — see the kernel)
+        const int e_units = record != nullptr ? (a.batch == 1 ? a.units / 2 : 1) : (a.batch == 1 && e_steps >= 128 ? 4 : 1);
+        if ((e_units > 1 || record != nullptr) && !fused_setup)   // (the ranges of the pre-pass add into `cnt`: zeroed by matrix_setup_kernel otherwise)
+            hipLaunchKernelGGL(score_split_reset_kernel, dim3(grid_stride((int64_t)a.h_count * a.batch, 256, 1024)), dim3(256), 0, a.st,
+                               a.cnt, (int64_t)a.h_count * a.batch);
         hipLaunchKernelGGL(score_sed_matrix_kernel<true>, dim3(flat * (unsigned)e_units), dim3(256), 0, a.st, a.corr, hyp_table, table,
                            a.n, a.E, a.h_count, a.thr, (const int32_t*)nullptr, a.cnt, a.s1, a.s2, e_units,
                            record != nullptr ? kReplaySteps : e_steps / e_units,
-                           (unsigned char*)nullptr, (const unsigned char*)nullptr, (int)a.batch, blocks_per_pair, (int32_t*)nullptr,
-                           record, a.chunks_per_unit);
+                           (unsigned char*)nullptr, (const unsigned char*)nullptr, (int)a.batch, blocks_per_pair * e_units, (int32_t*)nullptr,
+                           record, a.chunks_per_unit, a.units);
         const dim3 per_hyp(grid_for(a.h_count, 256), pairs);
         hipLaunchKernelGGL(score_class_count_kernel, per_hyp, dim3(256), 0, a.st, a.cnt, a.h_count, a.buckets);
         hipLaunchKernelGGL(score_class_scan_scatter_kernel, per_hyp, dim3(256), 0, a.st, a.cnt, a.h_count, a.buckets, a.order);
@@ -1177,7 +1181,7 @@ int launch_matrix(const FilteredLaunch& a) {
     const unsigned grid_blocks = persistent ? (unsigned)std::min<int64_t>(item_blocks, resident_blocks) : (unsigned)item_blocks;
     hipLaunchKernelGGL(score_sed_matrix_kernel<false>, dim3(grid_blocks), dim3(256), 0, a.st, a.corr, hyp_table, table, a.n,
                        a.E, a.h_count, a.thr, order_arg, a.cnt, a.s1, a.s2, a.units, a.chunks_per_unit, split, fix,
-                       (int)a.batch, blocks_per_pair * a.units, persistent ? a.buckets + kTicketWords : (int32_t*)nullptr, record, 0);
+                       (int)a.batch, blocks_per_pair * a.units, persistent ? a.buckets + kTicketWords : (int32_t*)nullptr, record, 0, 0);
     if (g_event_after) (void)hipEventRecord(g_event_after, a.st);
     if (a.deferred != nullptr) {   // a fused pass folds the ranges inside its selection launch
         *a.deferred = sfmhost::LargeScore{a.units, split, fix};

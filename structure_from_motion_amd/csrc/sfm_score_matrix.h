@@ -544,14 +544,14 @@ struct MatrixPair {   // the arrays of one image pair
     unsigned char* __restrict__ split;
     const unsigned char* __restrict__ fix;   // sample corrections of matrix_hypothesis_kernel: [h] int32 | [h] double | [h] double
     // Tier-1 results the cost pre-pass leaves for the scoring launch (nullptr: none): the reject word of every (hypothesis, lane
-    // half, range, step) it scanned — 32 bytes per (hypothesis, half, range), laid out [range][8 steps][hypothesis][half] x 16 bytes —
+    // half, range, step) it scanned — 32 bytes per (hypothesis, half, range), laid out [range][8 steps][hypothesis][half] x 16 bytes, per pair —
     // when the pre-pass scans the FIRST kReplaySteps steps of each of the scoring launch's ranges instead of the first steps of
     // the points: the scoring wave of a range then replays those words (five vector instructions a step) instead of computing
     // them again (three matrix and 36 vector instructions): the pre-pass' 8 % of tier 1 is no longer done twice.
     uint16_t* __restrict__ record;
     int range_stride;   // steps between the starts of the pre-pass' ranges (= the scoring launch's steps per range) when recording
 };
-constexpr int kReplayRanges = 8, kReplaySteps = kEstimateSteps / kReplayRanges;   // 8 ranges x 16 steps = the pre-pass' 128 steps (4096 points)
+constexpr int kReplaySteps = sfmws::kMatrixReplaySteps;   // 16 steps of every range: 8 ranges = the 128 steps (4096 points) of the bench workload's pre-pass
 static_assert(kReplaySteps % 8 == 0 && kReplaySteps <= kCap - 4, "whole 16-byte stores; the replayed entries fit the empty ring");
 __host__ __device__ inline int64_t record_bytes(int64_t h_count) { return sfmws::matrix_record_bytes(h_count); }
 
@@ -978,7 +978,7 @@ __global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
     const double* __restrict__ E, int h_count, double thr, const int32_t* __restrict__ order, int32_t* __restrict__ cnt,
     double* __restrict__ s1, double* __restrict__ s2, int units, int steps_per_unit, unsigned char* __restrict__ split,
     const unsigned char* __restrict__ fix, int batch, int blocks_per_pair, int32_t* __restrict__ tickets,
-    uint16_t* __restrict__ record, int range_stride) {
+    uint16_t* __restrict__ record, int range_stride, int record_ranges) {
     __shared__ alignas(kCap * kWave * 4) uint32_t queues[ESTIMATE ? 1 : 256 / kWave][ESTIMATE ? 1 : kCap][kWave];   // (a wave's ring: 8 KiB, aligned: ring_slot() in matrix_item)
     const int lane = threadIdx.x & (kWave - 1);
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
@@ -1018,7 +1018,7 @@ __global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
         if (units > 1) {
             unit = block_of_range % units;
             block_of_range /= units;
-            a.split += pair * sfmws::split_bytes(h_count);
+            if (a.split != nullptr) a.split += pair * sfmws::split_bytes(h_count);   // (the pre-pass has ranges and no partials)
         }
         a.pts += pair * (int64_t)n;
         a.table += pair * table_steps(n) * kBlocks * 64;
@@ -1029,16 +1029,19 @@ __global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
         a.s1 += pair * (int64_t)h_count;
         a.s2 += pair * (int64_t)h_count;
         if (a.fix != nullptr) a.fix += pair * sfmws::matrix_fix_bytes(h_count);
+        if (a.record != nullptr) a.record += pair * (sfmws::matrix_record_bytes(h_count) / 2);
     } else if (units > 1) {   // `units` consecutive blocks take the same hypotheses over one range of the points each
         unit = block_of_range % units;
         block_of_range /= units;
     }
     const int wave = block_of_range * (256 / kWave) + wave_in_block;
     if (ESTIMATE && record != nullptr) {
-        // the recording pre-pass: a wave scans the first steps of TWO of the scoring launch's ranges (the launch has kReplayRanges / 2
-        // "units"): waves of 16 steps spend a quarter of their time starting up (72 us for the pre-pass against 55 with 32-step waves)
-        matrix_item<ESTIMATE>(a, n, h_count, thr, 2 * units, steps_per_unit, wave, 2 * unit, my_queue, lane, 0u);
-        matrix_item<ESTIMATE>(a, n, h_count, thr, 2 * units, steps_per_unit, wave, 2 * unit + 1, my_queue, lane, 0u);
+        // the recording pre-pass: a wave scans the first steps of SEVERAL of the scoring launch's `record_ranges` ranges — two for a
+        // single pair (the launch has half as many units), all of them for a pair of a batch (one unit: 145 000 waves of 16 steps
+        // for the 256 pairs of C5 cost more in starting up than the replay saves)
+        const int per_wave = record_ranges / units;
+        for (int p = 0; p < per_wave; ++p)
+            matrix_item<ESTIMATE>(a, n, h_count, thr, record_ranges, steps_per_unit, wave, unit * per_wave + p, my_queue, lane, 0u);
         return;
     }
     matrix_item<ESTIMATE>(a, n, h_count, thr, units, steps_per_unit, wave, unit, my_queue, lane,

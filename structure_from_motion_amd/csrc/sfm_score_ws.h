@@ -81,12 +81,12 @@ __host__ __device__ inline int64_t matrix_fix_bytes(int64_t h_count) { return sp
 __host__ __device__ inline int64_t ws_matrix_fix_offset(int64_t n, int64_t h_count, int64_t batch) {
     return ((ws_matrix_hyp_offset(n, h_count, batch) + batch * matrix_hyp_table_bytes(n, h_count) + 255) / 256) * 256;
 }
-// ... and, for one pair, the reject words the cost pre-pass records for the scoring launch (sfm_score_matrix.h, MatrixPair::record):
-// [h_pad][2 halves][8 ranges][an eighth of the pre-pass' steps] uint16
-#ifndef SFM_MATRIX_ESTIMATE_STEPS
-#define SFM_MATRIX_ESTIMATE_STEPS 128   // steps of 32 points the matrix-pipe kernel's cost pre-pass scans at most (4096 points)
-#endif
-__host__ __device__ inline int64_t matrix_record_bytes(int64_t h_count) { return split_padded(h_count) * (2 * SFM_MATRIX_ESTIMATE_STEPS * 2); }
+// ... and, for a single pair, the reject words the cost pre-pass records for the scoring launch (sfm_score_matrix.h, MatrixPair::record):
+// [range < kSplitMaxUnits][2 chunks of 8 steps][h_pad][2 halves] x 16 bytes (the first 16 steps of every range)
+constexpr int kMatrixReplaySteps = 16;
+__host__ __device__ inline int64_t matrix_record_bytes(int64_t h_count) {   // one pair
+    return split_padded(h_count) * (int64_t)(kSplitMaxUnits * (kMatrixReplaySteps / 8) * 2 * 16);
+}
 __host__ __device__ inline int64_t ws_matrix_record_offset(int64_t n, int64_t h_count, int64_t batch) {
     return ((ws_matrix_fix_offset(n, h_count, batch) + (n <= kMatrixMaxPoints ? batch * matrix_fix_bytes(h_count) : 0) + 255) / 256) * 256;
 }
