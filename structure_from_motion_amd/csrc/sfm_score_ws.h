@@ -82,10 +82,14 @@ __host__ __device__ inline int64_t ws_matrix_fix_offset(int64_t n, int64_t h_cou
     return ((ws_matrix_hyp_offset(n, h_count, batch) + batch * matrix_hyp_table_bytes(n, h_count) + 255) / 256) * 256;
 }
 // ... and, for a single pair, the reject words the cost pre-pass records for the scoring launch (sfm_score_matrix.h, MatrixPair::record):
-// [range < kSplitMaxUnits][2 chunks of 8 steps][h_pad][2 halves] x 16 bytes (the first 16 steps of every range)
+// [range][2 chunks of 8 steps][h_pad][2 halves] x 16 bytes (the first 16 steps of every range; the launcher records only when the
+// ranges x 16 steps are exactly the pre-pass' steps: at most SFM_MATRIX_ESTIMATE_STEPS / 16 = 8 ranges)
+#ifndef SFM_MATRIX_ESTIMATE_STEPS
+#define SFM_MATRIX_ESTIMATE_STEPS 128   // steps of 32 points the matrix-pipe kernel's cost pre-pass scans at most (4096 points)
+#endif
 constexpr int kMatrixReplaySteps = 16;
 __host__ __device__ inline int64_t matrix_record_bytes(int64_t h_count) {   // one pair
-    return split_padded(h_count) * (int64_t)(kSplitMaxUnits * (kMatrixReplaySteps / 8) * 2 * 16);
+    return split_padded(h_count) * (int64_t)((SFM_MATRIX_ESTIMATE_STEPS / kMatrixReplaySteps) * (kMatrixReplaySteps / 8) * 2 * 16);
 }
 __host__ __device__ inline int64_t ws_matrix_record_offset(int64_t n, int64_t h_count, int64_t batch) {
     return ((ws_matrix_fix_offset(n, h_count, batch) + (n <= kMatrixMaxPoints ? batch * matrix_fix_bytes(h_count) : 0) + 255) / 256) * 256;
