@@ -1357,6 +1357,26 @@ def test_matrix_score_persistent_waves(dev, split):
                                           b.view(np.int64) if b.dtype == np.float64 else b)
 
 
+@pytest.mark.parametrize("n,h", [(32768, 2100), (40011, 4100), (33000, 2050)])
+@pytest.mark.parametrize("persistent", [0, 1])
+def test_matrix_score_replays_the_cost_prepass(dev, n, h, persistent):
+    """Eight ranges over at least 32 768 points: the cost pre-pass scans the first 16 steps of each range and leaves its reject
+    words; the scoring waves replay them instead of running tier 1 on those steps again (csrc/sfm_score_matrix.h, MatrixPair::record).
+    Forced here at sizes the size rule would give other range counts (the full-size tests run the shape the bench uses): counts
+    equal to the all-fp64 kernel's, sums to summation order, and the SAME BITS as the launch with the order switched off, which
+    has no pre-pass and computes every step itself."""
+    _, _, _, corr = scene(n)
+    S = orc.philox_sample_table(37, 0, h, n)
+    E, _, _ = orc.fit_hypotheses(corr, S)
+    for thr in (1.5e-6, 2e-4):
+        exact, replayed = _score_both(dev, corr, E, S, thr, _options(kernel="matrix", split=8, order=1, persistent=persistent))
+        _assert_same_scores(exact, replayed)
+        _, computed = _score_both(dev, corr, E, S, thr, _options(kernel="matrix", split=8, order=0, persistent=persistent))
+        for a, b in zip(replayed, computed):
+            np.testing.assert_array_equal(a.view(np.int64) if a.dtype == np.float64 else a,
+                                          b.view(np.int64) if b.dtype == np.float64 else b)
+
+
 @pytest.mark.parametrize("batch,n,h", [(5, 700, 70), (9, 300, 33), (17, 2100, 40), (3, 4099, 300)])
 def test_matrix_score_batches(dev, batch, n, h):
     """The matrix-pipe kernel on a batch of pairs (blocks of a pair share one L2: groups of eight pairs, the last one
