@@ -122,7 +122,9 @@ int sfm_hartley_normalize(const double* coords, int64_t n, double* out, void* st
  * plus those survivors.  cnt: dev int32 [batch,h_count]; s1, s2: dev [batch,h_count].
  * workspace: dev scratch of at least sfm_score_workspace_bytes(n, h_count, batch) bytes, 16-byte aligned; it
  * enables the two-tier kernels (a conservative reject filter + exact fp64 evaluation of the survivors, hypotheses
- * processed longest-first; identical counts and inlier decisions, sums in a fixed order): the fp32 VALU filter, and for a
+ * processed longest-first; identical counts and inlier decisions — the exact tier decides with sed.py's own operation sequence
+ * wherever a cheaper form of the same fp64 value is not clear of the threshold by 1e-13 — sums in a fixed order, each summand
+ * within 1.2e-15 of the all-fp64 kernel's): the fp32 VALU filter, and for a
  * single pair of at least 8192 points, 4096 hypotheses and 5e8 evaluations (at most 4 194 304 points) the kernel with the
  * filter on the fp16 / bf16 matrix pipe and a lane-per-hypothesis exact tier (sfm_score_options.kernel forces it on / off).
  * Large single-pair launches are cut into ranges of the points whose partial results are added in range order.  NULL selects
@@ -139,7 +141,8 @@ int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t*
 
 /* Launch options of the two-tier scoring kernels.  They change HOW a call is launched, never what it returns: counts and
  * decisions are identical under every setting, the sums differ in their last bits between kernels / numbers of ranges
- * (summation order) and are bit-identical from run to run under one setting.  The library does not read the process
+ * (summation order; the two-tier kernels' summands within 1.2e-15 of the all-fp64 kernel's) and are bit-identical from run to
+ * run under one setting.  The library does not read the process
  * environment: a call carries its options (sfm_score_sed_ex; NULL = the process-wide defaults) and the embedding application
  * sets the defaults once (sfm_score_set_default_options; the Python package translates SFM_SCORE_MATRIX / _HPW / _SPLIT /
  * _ORDER / _ONE_SIDED / _XCD / _SYNC / _PERSISTENT there when it is imported).  Safe to call from several threads: a default set is
