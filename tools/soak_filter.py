@@ -19,12 +19,13 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     dev.require_gpu()
     rng = np.random.default_rng(seed)
-    pa, pb, K, *_ = synthetic.two_view_scene(20000, seed=6)
+    n_max = int(os.environ.get("SOAK_N_MAX", 20000))   # (>= 32768 with SFM_SCORE_SPLIT=8: the scoring launch replays the cost pre-pass)
+    pa, pb, K, *_ = synthetic.two_view_scene(n_max, seed=6)
     corr_full = dev.normalize_correspondences(dev.to_device(pa), dev.to_device(pb), K).cpu().numpy()
     checked, boundary, t0 = 0, 0, time.time()
     for trial in range(trials):
         # SOAK_N_MIN / SOAK_H_MIN / SOAK_H_MAX move the size ranges (e.g. thousands of hypotheses: cost order, ranges of the points)
-        n = int(rng.integers(int(os.environ.get("SOAK_N_MIN", 8)), 20000))
+        n = int(rng.integers(int(os.environ.get("SOAK_N_MIN", 8)), n_max))
         h = int(rng.integers(int(os.environ.get("SOAK_H_MIN", 1)), int(os.environ.get("SOAK_H_MAX", 40))))
         corr = corr_full[rng.permutation(len(corr_full))[:n]].copy()
         if trial % 7 == 0:
