@@ -10,8 +10,9 @@
 // rate).  The 16-bit MFMAs run at 16 x that rate, and a value is the sum of two fp16 values to 2^-22:
 //   r'  ~ sum_t  m_hi E_hi + m_hi E_mid + m_mid E_hi                                   27 products, K = 32: 2 x v_mfma_f32_32x32x16_f16
 //   dS / 4 <= sum_k bf(q_k) bf(g_k / 4) + slack(h) + eps sum_k |g_k / 4| Q_k            13 products, K = 16: 1 x v_mfma_f32_32x32x16_bf16
-// per 32 points x 32 hypotheses: 96 matrix cycles and 3 VALU instructions per accumulator register (square, compare,
-// shift the result bit in) instead of 12 VALU instructions per 64 evaluations.  Points are the A operand (rows), hypotheses
+// per 32 points x 32 hypotheses: 96 matrix cycles and 2 vector instructions per accumulator register (dS - r^2 in one fma, its
+// sign shifted in with an alignbit) + 4 for the push — 36 a step — instead of 12 vector instructions per 64 evaluations.  (Matrix
+// and vector work of a SIMD add up on this part, they do not overlap at full clock: profiles/r04/README.md item 9.)  Points are the A operand (rows), hypotheses
 // the B operand (columns): lane l holds the results of hypothesis (l & 31) for 16 of a step's 32 points (rows
 // (j & 3) + 8 (j >> 2) + 4 (l >> 5), j = accumulator register).  The operand table puts point 16 (l >> 5) + j of the step into
 // that row (point_of_row below), so a lane's sixteen results are sixteen CONSECUTIVE points: the exact tier turns a survivor bit
@@ -26,6 +27,10 @@
 // division sequence itself wherever the value is not clear of the threshold — the decision is always the reference's.  Rounds start when a queue is
 // nearly full (looked at once per group of steps, outside the hot loop) and go on until every queue is down to kLow, so with
 // hypotheses of similar load in a wave (the heaviest-first order is dealt row-major here) nearly all lanes are busy in every round.
+//
+// The cost pre-pass (the <true> instantiation: tier 1 alone, survivors counted) scans, for a launch of eight ranges, the first 16
+// steps of each range and leaves its reject words for the scoring waves, which replay them instead of computing those steps
+// again (MatrixPair::record).
 //
 // Work items and their results (round 4).  An item is (group of 32 hypotheses, range of the points): one wave, placed by block
 // index (consecutive blocks = the ranges of one group; a multiple of eight ranges puts range u on XCD u mod 8) or taken from a
