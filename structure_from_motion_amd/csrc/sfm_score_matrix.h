@@ -76,7 +76,7 @@
 #define SFM_MATRIX_OCC 4     // blocks per CU the matrix-pipe kernel is compiled for (32 KiB of queues each)
 #endif
 #ifndef SFM_MATRIX_POPS
-#define SFM_MATRIX_POPS 2    // points a lane pops per round of the exact tier
+#define SFM_MATRIX_POPS 4    // points a lane pops per round of the exact tier (2: the same at 50 000 x 100 000, 10-13 % slower at 20 000 x 40 000 and 50 000 x 20 000 where the final drains dominate; 6: a wave less per SIMD; 8: spills)
 #endif
 #ifndef SFM_MATRIX_ABLATE
 #define SFM_MATRIX_ABLATE 0  // measurement builds only (WRONG results; tools/r04/ablate.sh): bit 0 no operand refills, bit 1 one matrix
