@@ -21,7 +21,7 @@
 // Because a lane belongs to ONE hypothesis, everything behind tier 1 is lane-parallel: each lane pushes its survivors onto its
 // own LDS queue (one word per step with survivors: the step — relative to the item's range — and its 16 survivor bits;
 // slot-major, so the 64 lanes of a push hit 64 banks), and a round of the exact tier has every lane pop kPops points of its own
-// queue and evaluate them under its own hypothesis (E loaded where a burst of rounds starts) into its own (count, sum, sum of
+// queue and evaluate them under its own hypothesis into its own (count, sum, sum of
 // squares): no wave reduction anywhere, the two lanes of a hypothesis are added once at the end.  The evaluation is
 // sfm::sed_inlier (sfm_math.h): the reference's r, dA, dB bit for bit, one refined reciprocal instead of two IEEE divisions, the
 // division sequence itself wherever the value is not clear of the threshold — the decision is always the reference's.  Rounds start when a queue is
@@ -82,7 +82,8 @@
 #define SFM_MATRIX_ABLATE 0  // measurement builds only (WRONG results; tools/r04/ablate.sh): bit 0 no operand refills, bit 1 one matrix
 #endif                       // instruction instead of three, bit 2 one sign test instead of sixteen, bit 3 no queue push, bit 4 no fp16 subnormal operands
 #ifndef SFM_MATRIX_E_IN_REGISTERS
-#define SFM_MATRIX_E_IN_REGISTERS 0   // 1: rounds 3's form — E held in 18 VGPRs through the tier-1 loop (A/B)
+#define SFM_MATRIX_E_IN_REGISTERS 1   // E held in 18 VGPRs through the tier-1 loop (0: loaded where a burst of rounds starts — better while the
+                                      // loop's registers were the constraint, 2.8 % slower at the bench size on the final kernel)
 #endif
 #ifndef SFM_MATRIX_STATS
 #define SFM_MATRIX_STATS 0   // diagnostic build: rounds of the exact tier, points popped, push-loop iterations (sfm_debug_matrix_stats)
