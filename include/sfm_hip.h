@@ -56,7 +56,7 @@ typedef struct sfm_select_result {
 
 /* Version of this interface: libsfm_hip.so reports the one it was compiled from (sfm_abi_version), the Python binding
  * and the torch op library (sfm_torch_ops_abi_version) refuse a library of another version. */
-#define SFM_ABI_VERSION 10
+#define SFM_ABI_VERSION 11
 
 const char* sfm_last_error(void);
 int sfm_abi_version(void);
@@ -326,16 +326,27 @@ int sfm_triangulate_selected(const double* pix_a, const double* pix_b, int64_t n
 /* ---- brute-force window matching (reference lib/feature_matching: matching.py, ncc.py, ssd.py, util.py) ---- */
 #define SFM_MATCH_NCC 0 /* ncc.py:7-54: 1 - normalised cross-correlation, in [0,2]; 2.0 if a window leaves the image */
 #define SFM_MATCH_SSD 1 /* ssd.py:7-36: mean squared difference; +inf if a window leaves the image */
+/* ssd.py:31-36 on INTEGER images: the reference subtracts and squares in the image dtype — both wrap modulo 2^bits, into the
+ * signed range for signed types (uint8 images, what apps/sfm.py:222-224 produces: modulo 256) —, np.sum accumulates in
+ * int64 / uint64 and the division by the window size is float64.  bits: 8, 16, 32 or 64 (the NumPy result type of
+ * image_a - image_b).  The patches then hold the pixels as int64 bit patterns (SFM_PATCH_RAW64).  Bit-exact. */
+#define SFM_MATCH_SSD_INT(bits, is_signed) (0x100 | ((is_signed) ? 0x80 : 0) | (bits))
 
-/* Windows of n features of one image (util.py:8-27).  image: dev f64 [height,width]; feats: dev f64 [n,2]
- * (x, y); patches: dev f64 [window_size^2][stride] k-major (stride >= n), mean-removed if subtract_mean
- * (ncc.py:33-37); ssq: dev [n] sum of squares of the stored patch; ok: dev uint8 [n] window inside the image. */
+/* patch modes of sfm_patch_extract (its `subtract_mean` argument) */
+#define SFM_PATCH_PLAIN 0        /* float64 pixels as they are (SSD on float images) */
+#define SFM_PATCH_MEAN_REMOVED 1 /* float64 pixels minus the window mean (ncc.py:33-37) */
+#define SFM_PATCH_RAW64 2        /* image holds int64 pixels: 8-byte copies, no arithmetic (SFM_MATCH_SSD_INT) */
+
+/* Windows of n features of one image (util.py:8-27).  image: dev f64 [height,width] (int64 with SFM_PATCH_RAW64);
+ * feats: dev f64 [n,2] (x, y); patches: dev f64 [window_size^2][stride] k-major (stride >= n), by `subtract_mean` =
+ * SFM_PATCH_PLAIN / SFM_PATCH_MEAN_REMOVED (ncc.py:33-37) / SFM_PATCH_RAW64 (int64 bit patterns in the 8-byte slots);
+ * ssq: dev [n] sum of squares of the stored patch (0 with SFM_PATCH_RAW64); ok: dev uint8 [n] window inside the image. */
 int sfm_patch_extract(const double* image, int64_t height, int64_t width, const double* feats, int64_t n,
                       int window_size, int subtract_mean, int64_t stride, double* patches, double* ssq,
                       uint8_t* ok, void* stream);
 
 /* scores[a,b] for every pair of features (the score_function calls of matching.py:57-65).
- * metric SFM_MATCH_NCC needs mean-removed patches.  scores: dev f64 [n_a,n_b].
+ * metric SFM_MATCH_NCC needs mean-removed patches, SFM_MATCH_SSD_INT(bits, signed) raw int64 ones.  scores: dev f64 [n_a,n_b].
  * Fast path (LDS-DMA staging) when both patch arrays are 16-byte aligned with an even `stride` >= n rounded up to a
  * multiple of 128 (the padding may hold anything); any other layout works through a slower staging loop. */
 int sfm_pair_scores(int metric, const double* patches_a, int64_t stride_a, const double* patches_b,

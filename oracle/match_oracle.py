@@ -74,19 +74,102 @@ def ncc_scores(image_a, image_b, feats_a, feats_b, window_size: int = 3) -> np.n
     return np.where(bad, 2.0, score)
 
 
+def ssd_result_kind(dtype_a, dtype_b):
+    """What ssd.py:31-35 computes in, given the two image dtypes: NumPy promotes the operands of ``window_a - window_b``
+    and every later step stays in that type.  Returns ("int", bits, signed) for an integer result type — difference and
+    square then wrap modulo 2**bits (into the signed range for signed types) —, ("float",) otherwise; bool raises the
+    TypeError NumPy raises for ``bool - bool``."""
+    rt = np.result_type(dtype_a, dtype_b)
+    if rt == np.bool_:
+        raise TypeError("numpy boolean subtract, the `-` operator, is not supported, use the bitwise_xor, the `^` operator, "
+                        "or the logical_xor function instead.")
+    if rt.kind in "iu":
+        return ("int", 8 * rt.itemsize, rt.kind == "i")
+    return ("float",)
+
+
+def _wrap(values, bits: int, signed: bool):
+    """Python-int array reduced modulo 2**bits into the dtype's range (object arrays: exact integers of any size)."""
+    m = 1 << bits
+    v = values % m
+    if signed:
+        v = np.where(v >= (m >> 1), v - m, v)
+    return v
+
+
 def ssd_scores(image_a, image_b, feats_a, feats_b, window_size: int = 5) -> np.ndarray:
-    """ssd.py:7-36 for every pair: mean squared difference; +inf when a window leaves the image."""
+    """ssd.py:7-36 for every pair: mean squared difference; +inf when a window leaves the image.
+
+    Integer images (ssd.py:31-35 run in the image dtype): ``diff`` wraps modulo 2**bits, ``np.square(diff)`` wraps again,
+    ``np.sum`` accumulates in int64 / uint64 (wrapping modulo 2**64 only for 64-bit types) and ``/ size`` converts that
+    integer to float64 and divides.  Restated here with exact Python integers and explicit reductions."""
     if image_a.shape != image_b.shape:
         raise ValueError("the images must have the same shape")
-    pa, oka = windows(image_a, np.asarray(feats_a, dtype=np.float64), window_size)
-    pb, okb = windows(image_b, np.asarray(feats_b, dtype=np.float64), window_size)
-    acc = np.zeros((len(pa), len(pb)))
-    for k in range(pa.shape[1]):
-        d = pa[:, k][:, None] - pb[:, k][None, :]
-        acc = acc + d * d
-    score = acc / pa.shape[1]
+    image_a, image_b = np.asarray(image_a), np.asarray(image_b)
+    kind = ssd_result_kind(image_a.dtype, image_b.dtype)
+    fa, fb = np.asarray(feats_a, dtype=np.float64), np.asarray(feats_b, dtype=np.float64)
+    if kind[0] == "float":
+        pa, oka = windows(image_a, fa, window_size)
+        pb, okb = windows(image_b, fb, window_size)
+        acc = np.zeros((len(pa), len(pb)))
+        for k in range(pa.shape[1]):
+            d = pa[:, k][:, None] - pb[:, k][None, :]
+            acc = acc + d * d
+        score = acc / pa.shape[1]
+        bad = (~oka)[:, None] | (~okb)[None, :]
+        return np.where(bad, np.inf, score)
+    _, bits, signed = kind
+    h = half_window(window_size)
+    side = 2 * h + 1
+    oka, okb = within_bounds(fa, image_a.shape, window_size), within_bounds(fb, image_b.shape, window_size)
+
+    def int_windows(image, feats, ok):
+        out = np.zeros((len(feats), side * side), dtype=object)
+        for i, (x, y) in enumerate(feats):
+            if ok[i]:
+                out[i] = [int(v) for v in image[int(y) - h:int(y) + h + 1, int(x) - h:int(x) + h + 1].ravel()]
+        return out
+
+    pa, pb = int_windows(image_a, fa, oka), int_windows(image_b, fb, okb)
+    total = np.zeros((len(pa), len(pb)), dtype=object)
+    for k in range(side * side):
+        d = _wrap(pa[:, k][:, None] - pb[:, k][None, :], bits, signed)
+        total = total + _wrap(d * d, bits, signed)
+    total = _wrap(total, 64, signed)   # the int64 / uint64 accumulator of np.sum
+    score = np.array([[float(v) for v in row] for row in total], dtype=np.float64).reshape(total.shape) / float(side * side)
     bad = (~oka)[:, None] | (~okb)[None, :]
     return np.where(bad, np.inf, score)
+
+
+def ssd_scores_in_dtype(image_a, image_b, feats_a, feats_b, window_size: int = 5) -> np.ndarray:
+    """The same scores for INTEGER images by the other route: NumPy's own fixed-width arithmetic in the promoted dtype,
+    vectorised over all pairs (subtract, square — both wrap silently —, sum in the dtype's 64-bit accumulator, float64
+    division).  Fast enough for the large GPU parity cases; test_matching_oracle.py checks it against ``ssd_scores`` and G14."""
+    image_a, image_b = np.asarray(image_a), np.asarray(image_b)
+    kind = ssd_result_kind(image_a.dtype, image_b.dtype)
+    assert kind[0] == "int", "integer images only"
+    rt = np.result_type(image_a.dtype, image_b.dtype)
+    fa, fb = np.asarray(feats_a, dtype=np.float64), np.asarray(feats_b, dtype=np.float64)
+    h = half_window(window_size)
+    side = 2 * h + 1
+    oka, okb = within_bounds(fa, image_a.shape, window_size), within_bounds(fb, image_b.shape, window_size)
+
+    def dtype_windows(image, feats, ok):
+        out = np.zeros((len(feats), side * side), dtype=rt)
+        for i, (x, y) in enumerate(feats):
+            if ok[i]:
+                out[i] = image[int(y) - h:int(y) + h + 1, int(x) - h:int(x) + h + 1].astype(rt).ravel()
+        return out
+
+    pa, pb = dtype_windows(image_a, fa, oka), dtype_windows(image_b, fb, okb)
+    acc_t = np.int64 if rt.kind == "i" else np.uint64
+    total = np.zeros((len(pa), len(pb)), dtype=acc_t)
+    with np.errstate(over="ignore"):
+        for k in range(side * side):
+            d = pa[:, k][:, None] - pb[:, k][None, :]
+            total = total + np.square(d).astype(acc_t)
+    score = total.astype(np.float64) / float(side * side)
+    return np.where((~oka)[:, None] | (~okb)[None, :], np.inf, score)
 
 
 # --------------------------------------------------------------------------------------------------

@@ -14,8 +14,15 @@ SFM_OK = 0
 AGG_SUM, AGG_SQUARE, AGG_MEAN, AGG_RMS = 0, 1, 2, 3
 FIT_DEGENERATE = 1
 MATCH_NCC, MATCH_SSD = 0, 1
+PATCH_PLAIN, PATCH_MEAN_REMOVED, PATCH_RAW64 = 0, 1, 2
 INT64_MAX = (1 << 63) - 1
-ABI_VERSION = 10
+ABI_VERSION = 11
+
+
+def match_ssd_int(bits: int, signed: bool) -> int:
+    """SFM_MATCH_SSD_INT(bits, is_signed): SSD of integer images in the image dtype's modular arithmetic (ssd.py:31-36)."""
+    assert bits in (8, 16, 32, 64)
+    return 0x100 | (0x80 if signed else 0) | bits
 
 
 class SelectResult(C.Structure):

@@ -1113,9 +1113,11 @@ int sfm_ransac_pass_large(uint64_t seed, const uint64_t* seed_dev, int use_philo
     unsigned char* state = ws + sfmws::ws_split_offset(n, h_count);   // the unused head of the range-split region
     const bool state_fits = 4 * sfmws::split_padded(h_count) >= sfmws::kFusedPartialOffset + kLargeSelectBlocks * (int64_t)sizeof(PartialSelect);
     sfmhost::LargeScore folded_later{1, nullptr, nullptr};
+    // (without room for the selection state the scoring call folds its ranges itself — folded_later = NULL —: the separate
+    // selection below reads cnt / s1 / s2.  Round 4 deferred the fold in that case too, and selected from unfolded partials.)
     rc = sfmhost::launch_large_score(sfmhost::LargePass{corr, n, E, S, h_count, thr, cnt, s1, s2, ws, workspace_bytes,
                                                          state_fits ? reinterpret_cast<unsigned*>(state) : nullptr, st},
-                                     &folded_later);
+                                     state_fits ? &folded_later : nullptr);
     if (rc != SFM_OK) return rc;
     if (!state_fits) {   // a few hundred hypotheses: the separate selection and mask launches
         rc = sfm_select_best(cnt, s1, s2, flags, h_count, 1, min_extra, aggregation, h_offset, result, stream);

@@ -56,6 +56,18 @@ __global__ void patch_extract_kernel(const double* __restrict__ image, int64_t h
         return;
     }
     const int64_t x0 = (int64_t)x - half, y0 = (int64_t)y - half;
+    if (subtract_mean == SFM_PATCH_RAW64) {
+        // integer images (ssd.py:31-35 in the image dtype): the pixels are int64 bit patterns, copied as they are — no
+        // floating-point instruction may touch them
+        const unsigned long long* raw = reinterpret_cast<const unsigned long long*>(image);
+        unsigned long long* out = reinterpret_cast<unsigned long long*>(patches);
+        int k = 0;
+        for (int r = 0; r < side; ++r)
+            for (int c = 0; c < side; ++c) out[(int64_t)(k++) * stride + i] = raw[(y0 + r) * width + (x0 + c)];
+        ssq[i] = 0.0;
+        ok[i] = 1;
+        return;
+    }
     double mean = 0.0;
     if (subtract_mean) {
         double total = 0.0;
@@ -110,72 +122,183 @@ SFM_DEVICE void direct_row(const double* src, double* row) {
                                      (__attribute__((address_space(3))) void*)row, 16, 0, 0);
 }
 
-template <int MODE, bool DIRECT>
-SFM_DEVICE void tile_accumulate(const double* __restrict__ Pa, int64_t stride_a, const double* __restrict__ Pb,
-                                int64_t stride_b, int64_t nA, int64_t nB, int K, int64_t a0, int64_t b0,
-                                double (*sA)[kTileA], double (*sB)[kTileB],
-                                double (&acc)[kRowsPerLane][kColsPerLane]) {
+// MODEs of the tile core.  0: NCC numerator sum a*b (patches mean-removed); 1: SSD sum (a-b)^2 in float64;
+// 2 / 3 / 4: SSD of INTEGER images in the image dtype's modular arithmetic (ssd.py:31-35: `diff` and `np.square(diff)`
+// wrap modulo 2^bits — into the signed range for signed types —, np.sum accumulates in int64 / uint64) on patches that
+// hold the pixels as int64 bit patterns (SFM_PATCH_RAW64):
+//   2  signed 8 / 16-bit types, 3  unsigned 8 / 16-bit types: 32-bit arithmetic (subtract, bit-field extract, 24-bit
+//      multiply, bit-field extract, add — five full-rate integer instructions per pair and window element), int32
+//      accumulators: windows of at most kNarrowMaxWindow elements
+//   4  any width (32- and 64-bit types; narrow types with huge windows): 64-bit arithmetic, int64 accumulators
+constexpr int kModeNcc = 0, kModeSsd = 1, kModeSsdNarrowSigned = 2, kModeSsdNarrowUnsigned = 3, kModeSsdWide = 4;
+constexpr int kNarrowMaxWindow = 32768;   // 32768 terms of magnitude < 2^16 fit an int32 / uint32 accumulator
+struct IntKind {
+    int bits;        // 8, 16, 32, 64
+    int is_signed;
+};
+
+template <bool DIRECT>
+SFM_DEVICE void stage_chunk(const double* __restrict__ Pa, int64_t stride_a, const double* __restrict__ Pb, int64_t stride_b,
+                            int64_t nA, int64_t nB, int k0, int kc, int64_t a0, int64_t b0, double (*sA)[kTileA],
+                            double (*sB)[kTileB]) {
     const int tid = threadIdx.x;
-    const int ty = tid / 16, tx = tid % 16;
-#pragma unroll
-    for (int i = 0; i < kRowsPerLane; ++i)
-#pragma unroll
-        for (int j = 0; j < kColsPerLane; ++j) acc[i][j] = 0.0;
-    for (int k0 = 0; k0 < K; k0 += kChunk) {
-        const int kc = min(kChunk, K - k0);
-        __syncthreads();
-        if constexpr (DIRECT) {
-            // LDS-DMA staging: one global_load_lds_dwordx4 per window row and matrix moves 64 lanes x 16 B = the
-            // 128 features of the row straight into sA[kk] / sB[kk] — no staging registers (the kernel sits at the
-            // two-waves-per-SIMD register limit with its 8x8 accumulators), all rows of the chunk in flight at once.
-            // Needs 16-byte aligned rows padded to a multiple of 128 features (checked by the launcher).
-            const int wave = tid / kWave, lane = tid % kWave;
-            for (int kk = wave; kk < kc; kk += 256 / kWave) {
-                direct_row(Pa + (int64_t)(k0 + kk) * stride_a + a0 + 2 * lane, &sA[kk][0]);
-                direct_row(Pb + (int64_t)(k0 + kk) * stride_b + b0 + 2 * lane, &sB[kk][0]);
-            }
-        } else {
-            for (int idx = tid; idx < kc * kTileA; idx += 256) {
-                const int kk = idx / kTileA, f = idx % kTileA;
-                const int64_t ia = a0 + f;
-                sA[kk][f] = ia < nA ? Pa[(int64_t)(k0 + kk) * stride_a + ia] : 0.0;
-            }
-            for (int idx = tid; idx < kc * kTileB; idx += 256) {
-                const int kk = idx / kTileB, f = idx % kTileB;
-                const int64_t ib = b0 + f;
-                sB[kk][f] = ib < nB ? Pb[(int64_t)(k0 + kk) * stride_b + ib] : 0.0;
-            }
+    if constexpr (DIRECT) {
+        // LDS-DMA staging: one global_load_lds_dwordx4 per window row and matrix moves 64 lanes x 16 B = the
+        // 128 features of the row straight into sA[kk] / sB[kk] — no staging registers (the kernel sits at the
+        // two-waves-per-SIMD register limit with its 8x8 accumulators), all rows of the chunk in flight at once.
+        // Needs 16-byte aligned rows padded to a multiple of 128 features (checked by the launcher).
+        const int wave = tid / kWave, lane = tid % kWave;
+        for (int kk = wave; kk < kc; kk += 256 / kWave) {
+            direct_row(Pa + (int64_t)(k0 + kk) * stride_a + a0 + 2 * lane, &sA[kk][0]);
+            direct_row(Pb + (int64_t)(k0 + kk) * stride_b + b0 + 2 * lane, &sB[kk][0]);
         }
-        __syncthreads();
-        for (int kk = 0; kk < kc; ++kk) {
-            double av[kRowsPerLane], bv[kColsPerLane];
-#pragma unroll
-            for (int i = 0; i < kRowsPerLane; ++i) av[i] = sA[kk][ty * kRowsPerLane + i];
-#pragma unroll
-            for (int g = 0; g < kColGroups; ++g) {
-                bv[2 * g] = sB[kk][g * 32 + tx * 2];
-                bv[2 * g + 1] = sB[kk][g * 32 + tx * 2 + 1];
-            }
-#pragma unroll
-            for (int i = 0; i < kRowsPerLane; ++i)
-#pragma unroll
-                for (int j = 0; j < kColsPerLane; ++j) {
-                    if (MODE == 0) {
-                        acc[i][j] += av[i] * bv[j];
-                    } else {
-                        const double d = av[i] - bv[j];
-                        acc[i][j] += d * d;
-                    }
-                }
+    } else {
+        for (int idx = tid; idx < kc * kTileA; idx += 256) {
+            const int kk = idx / kTileA, f = idx % kTileA;
+            const int64_t ia = a0 + f;
+            sA[kk][f] = ia < nA ? Pa[(int64_t)(k0 + kk) * stride_a + ia] : 0.0;   // (0.0 is also the integer 0)
+        }
+        for (int idx = tid; idx < kc * kTileB; idx += 256) {
+            const int kk = idx / kTileB, f = idx % kTileB;
+            const int64_t ib = b0 + f;
+            sB[kk][f] = ib < nB ? Pb[(int64_t)(k0 + kk) * stride_b + ib] : 0.0;
         }
     }
 }
 
-// Window sum -> score.  MODE 0: (num / sqrt(qa qb)) * -1 + 1, 2.0 if a window is out of the image or the
-// denominator is zero (ncc.py:24-54).  MODE 1: sum / K, +inf if a window is out of the image (ssd.py:24-36).
+template <int MODE, bool DIRECT>
+SFM_DEVICE void tile_accumulate(const double* __restrict__ Pa, int64_t stride_a, const double* __restrict__ Pb,
+                                int64_t stride_b, int64_t nA, int64_t nB, int K, int64_t a0, int64_t b0,
+                                double (*sA)[kTileA], double (*sB)[kTileB],
+                                double (&acc)[kRowsPerLane][kColsPerLane], IntKind kind) {
+    const int tid = threadIdx.x;
+    const int ty = tid / 16, tx = tid % 16;
+    if constexpr (MODE == kModeNcc || MODE == kModeSsd) {
+#pragma unroll
+        for (int i = 0; i < kRowsPerLane; ++i)
+#pragma unroll
+            for (int j = 0; j < kColsPerLane; ++j) acc[i][j] = 0.0;
+        for (int k0 = 0; k0 < K; k0 += kChunk) {
+            const int kc = min(kChunk, K - k0);
+            __syncthreads();
+            stage_chunk<DIRECT>(Pa, stride_a, Pb, stride_b, nA, nB, k0, kc, a0, b0, sA, sB);
+            __syncthreads();
+            for (int kk = 0; kk < kc; ++kk) {
+                double av[kRowsPerLane], bv[kColsPerLane];
+#pragma unroll
+                for (int i = 0; i < kRowsPerLane; ++i) av[i] = sA[kk][ty * kRowsPerLane + i];
+#pragma unroll
+                for (int g = 0; g < kColGroups; ++g) {
+                    bv[2 * g] = sB[kk][g * 32 + tx * 2];
+                    bv[2 * g + 1] = sB[kk][g * 32 + tx * 2 + 1];
+                }
+#pragma unroll
+                for (int i = 0; i < kRowsPerLane; ++i)
+#pragma unroll
+                    for (int j = 0; j < kColsPerLane; ++j) {
+                        if (MODE == kModeNcc) {
+                            acc[i][j] += av[i] * bv[j];
+                        } else {
+                            const double d = av[i] - bv[j];
+                            acc[i][j] += d * d;
+                        }
+                    }
+            }
+        }
+    } else if constexpr (MODE == kModeSsdNarrowSigned || MODE == kModeSsdNarrowUnsigned) {
+        // 8 / 16-bit pixels: everything fits 32-bit registers — the low dword of the staged int64 IS the pixel (two's
+        // complement), the difference is reduced to `bits` by one bit-field extract (sign- or zero-extending: the wrap of the
+        // image dtype), its square (|d| < 2^16: a 24-bit multiply, exact in 32 bits) is reduced the same way, and the sum of at
+        // most kNarrowMaxWindow such terms cannot leave 32 bits.
+        constexpr bool kSigned = MODE == kModeSsdNarrowSigned;
+        const unsigned bits = (unsigned)kind.bits;
+        int total[kRowsPerLane][kColsPerLane];
+#pragma unroll
+        for (int i = 0; i < kRowsPerLane; ++i)
+#pragma unroll
+            for (int j = 0; j < kColsPerLane; ++j) total[i][j] = 0;
+        auto narrow = [&](int x) __attribute__((always_inline)) {
+            return kSigned ? __builtin_amdgcn_sbfe(x, 0u, bits) : (int)__builtin_amdgcn_ubfe((unsigned)x, 0u, bits);
+        };
+        for (int k0 = 0; k0 < K; k0 += kChunk) {
+            const int kc = min(kChunk, K - k0);
+            __syncthreads();
+            stage_chunk<DIRECT>(Pa, stride_a, Pb, stride_b, nA, nB, k0, kc, a0, b0, sA, sB);
+            __syncthreads();
+            for (int kk = 0; kk < kc; ++kk) {
+                int av[kRowsPerLane], bv[kColsPerLane];
+#pragma unroll
+                for (int i = 0; i < kRowsPerLane; ++i) av[i] = __double2loint(sA[kk][ty * kRowsPerLane + i]);
+#pragma unroll
+                for (int g = 0; g < kColGroups; ++g) {
+                    bv[2 * g] = __double2loint(sB[kk][g * 32 + tx * 2]);
+                    bv[2 * g + 1] = __double2loint(sB[kk][g * 32 + tx * 2 + 1]);
+                }
+#pragma unroll
+                for (int i = 0; i < kRowsPerLane; ++i)
+#pragma unroll
+                    for (int j = 0; j < kColsPerLane; ++j) {
+                        const int d = narrow(av[i] - bv[j]);
+                        const int sq = kSigned ? __mul24(d, d) : (int)__umul24((unsigned)d, (unsigned)d);
+                        total[i][j] += narrow(sq);
+                    }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kRowsPerLane; ++i)
+#pragma unroll
+            for (int j = 0; j < kColsPerLane; ++j) acc[i][j] = kSigned ? (double)total[i][j] : (double)(unsigned)total[i][j];
+    } else {
+        // any width: 64-bit two's-complement arithmetic wraps modulo 2^64 by itself; a reduction to `bits` is a shift up and an
+        // arithmetic (signed) or logical (unsigned) shift back down.  The int64 / uint64 accumulator of np.sum wraps the same way.
+        const unsigned sh = 64u - (unsigned)kind.bits;
+        const bool is_signed = kind.is_signed != 0;
+        unsigned long long total[kRowsPerLane][kColsPerLane];
+#pragma unroll
+        for (int i = 0; i < kRowsPerLane; ++i)
+#pragma unroll
+            for (int j = 0; j < kColsPerLane; ++j) total[i][j] = 0ull;
+        auto narrow = [&](unsigned long long x) __attribute__((always_inline)) {
+            const unsigned long long up = x << sh;
+            return is_signed ? (unsigned long long)((long long)up >> sh) : up >> sh;
+        };
+        for (int k0 = 0; k0 < K; k0 += kChunk) {
+            const int kc = min(kChunk, K - k0);
+            __syncthreads();
+            stage_chunk<DIRECT>(Pa, stride_a, Pb, stride_b, nA, nB, k0, kc, a0, b0, sA, sB);
+            __syncthreads();
+            for (int kk = 0; kk < kc; ++kk) {
+                unsigned long long av[kRowsPerLane], bv[kColsPerLane];
+#pragma unroll
+                for (int i = 0; i < kRowsPerLane; ++i) av[i] = (unsigned long long)__double_as_longlong(sA[kk][ty * kRowsPerLane + i]);
+#pragma unroll
+                for (int g = 0; g < kColGroups; ++g) {
+                    bv[2 * g] = (unsigned long long)__double_as_longlong(sB[kk][g * 32 + tx * 2]);
+                    bv[2 * g + 1] = (unsigned long long)__double_as_longlong(sB[kk][g * 32 + tx * 2 + 1]);
+                }
+#pragma unroll
+                for (int i = 0; i < kRowsPerLane; ++i)
+#pragma unroll
+                    for (int j = 0; j < kColsPerLane; ++j) {
+                        const unsigned long long d = narrow(av[i] - bv[j]);
+                        total[i][j] += narrow(d * d);
+                    }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kRowsPerLane; ++i)
+#pragma unroll
+            for (int j = 0; j < kColsPerLane; ++j)
+                acc[i][j] = is_signed ? (double)(long long)total[i][j] : (double)total[i][j];
+    }
+}
+
+// Window sum -> score.  NCC: (num / sqrt(qa qb)) * -1 + 1, 2.0 if a window is out of the image or the denominator is zero
+// (ncc.py:24-54).  Every SSD mode: sum / K in float64 (for integer images: the int64 / uint64 sum converted to float64,
+// ssd.py:36), +inf if a window is out of the image (ssd.py:24-29).
 template <int MODE>
 SFM_DEVICE double finish_score(double acc, bool inside, double qa, double qb, int K) {
-    if (MODE == 0) {
+    if (MODE == kModeNcc) {
         const double den = sqrt(qa * qb);
         return (!inside || den == 0.0) ? 2.0 : (acc / den) * -1.0 + 1.0;
     }
@@ -186,7 +309,7 @@ template <int MODE, bool DIRECT>
 __global__ __launch_bounds__(256, 2) void pair_scores_kernel(
     const double* __restrict__ Pa, int64_t stride_a, const double* __restrict__ Pb, int64_t stride_b,
     const double* __restrict__ qa, const double* __restrict__ qb, const uint8_t* __restrict__ oka,
-    const uint8_t* __restrict__ okb, int64_t nA, int64_t nB, int K, double* __restrict__ scores) {
+    const uint8_t* __restrict__ okb, int64_t nA, int64_t nB, int K, double* __restrict__ scores, IntKind kind) {
     __shared__ double sA[kChunk][kTileA];
     __shared__ double sB[kChunk][kTileB];
     const int ty = threadIdx.x / 16, tx = threadIdx.x % 16;
@@ -194,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void pair_scores_kernel(
     if (!tile.valid) return;  // whole block
     const int64_t a0 = tile.a_tile * kTileA, b0 = tile.b_tile * kTileB;
     double acc[kRowsPerLane][kColsPerLane];
-    tile_accumulate<MODE, DIRECT>(Pa, stride_a, Pb, stride_b, nA, nB, K, a0, b0, sA, sB, acc);
+    tile_accumulate<MODE, DIRECT>(Pa, stride_a, Pb, stride_b, nA, nB, K, a0, b0, sA, sB, acc, kind);
 #pragma unroll
     for (int i = 0; i < kRowsPerLane; ++i) {
         const int64_t ia = a0 + ty * kRowsPerLane + i;
@@ -330,7 +453,7 @@ template <int MODE, bool DIRECT>
 __global__ __launch_bounds__(256, 2) void pair_summary_kernel(
     const double* __restrict__ Pa, int64_t stride_a, const double* __restrict__ Pb, int64_t stride_b,
     const double* __restrict__ qa, const double* __restrict__ qb, const uint8_t* __restrict__ oka,
-    const uint8_t* __restrict__ okb, int64_t nA, int64_t nB, int K, TileSummary* __restrict__ tiles) {
+    const uint8_t* __restrict__ okb, int64_t nA, int64_t nB, int K, TileSummary* __restrict__ tiles, IntKind kind) {
     __shared__ double sA[kChunk][kTileA];
     __shared__ double sB[kChunk][kTileB];
     const int ty = threadIdx.x / 16, tx = threadIdx.x % 16;
@@ -338,7 +461,7 @@ __global__ __launch_bounds__(256, 2) void pair_summary_kernel(
     if (!tile.valid) return;  // whole block
     const int64_t a0 = tile.a_tile * kTileA, b0 = tile.b_tile * kTileB;
     double acc[kRowsPerLane][kColsPerLane];
-    tile_accumulate<MODE, DIRECT>(Pa, stride_a, Pb, stride_b, nA, nB, K, a0, b0, sA, sB, acc);
+    tile_accumulate<MODE, DIRECT>(Pa, stride_a, Pb, stride_b, nA, nB, K, a0, b0, sA, sB, acc, kind);
     // Per-column and per-row operands of this lane's 8 x 8 block, fetched in one batch: unconditional loads at
     // clamped indices (a predicated load per element compiles to load -> wait -> next load, 32 memory latencies in a
     // row at two waves per SIMD — it was most of the kernel's fixed 1.5 ms).
@@ -495,6 +618,19 @@ bool direct_staging_ok(const double* patches, int64_t stride, int64_t n) {
            stride >= (n + kTileA - 1) / kTileA * kTileA;
 }
 
+// metric code of the C ABI -> tile-core mode (+ the integer kind); -1: unknown
+int decode_metric(int metric, int window_elements, IntKind* kind) {
+    *kind = IntKind{0, 0};
+    if (metric == SFM_MATCH_NCC) return kModeNcc;
+    if (metric == SFM_MATCH_SSD) return kModeSsd;
+    if ((metric & ~0xFF) != 0x100) return -1;
+    const int bits = metric & 0x7F, is_signed = (metric >> 7) & 1;
+    if (bits != 8 && bits != 16 && bits != 32 && bits != 64) return -1;
+    *kind = IntKind{bits, is_signed};
+    if (bits <= 16 && window_elements <= kNarrowMaxWindow) return is_signed ? kModeSsdNarrowSigned : kModeSsdNarrowUnsigned;
+    return kModeSsdWide;
+}
+
 }  // namespace
 
 extern "C" {
@@ -504,6 +640,8 @@ int sfm_patch_extract(const double* image, int64_t height, int64_t width, const 
                       uint8_t* ok, void* stream) {
     if (n < 0 || height <= 0 || width <= 0 || window_size < 1)
         return fail(SFM_EINVAL, "sfm_patch_extract: bad size");
+    if (subtract_mean != SFM_PATCH_PLAIN && subtract_mean != SFM_PATCH_MEAN_REMOVED && subtract_mean != SFM_PATCH_RAW64)
+        return fail(SFM_EINVAL, "sfm_patch_extract: unknown patch mode");
     if (n == 0) return SFM_OK;
     if (stride < n) return fail(SFM_EINVAL, "sfm_patch_extract: stride < n");
     if (!image || !feats || !patches || !ssq || !ok) return fail(SFM_EINVAL, "sfm_patch_extract: null pointer");
@@ -518,7 +656,9 @@ int sfm_pair_scores(int metric, const double* patches_a, int64_t stride_a, const
                     const uint8_t* ok_b, int64_t n_a, int64_t n_b, int window_elements, double* scores,
                     void* stream) {
     if (n_a < 0 || n_b < 0 || window_elements < 1) return fail(SFM_EINVAL, "sfm_pair_scores: bad size");
-    if (metric != SFM_MATCH_NCC && metric != SFM_MATCH_SSD) return fail(SFM_EINVAL, "sfm_pair_scores: unknown metric");
+    IntKind kind;
+    const int mode = decode_metric(metric, window_elements, &kind);
+    if (mode < 0) return fail(SFM_EINVAL, "sfm_pair_scores: unknown metric");
     if (n_a == 0 || n_b == 0) return SFM_OK;
     if (!patches_a || !patches_b || !ssq_a || !ssq_b || !ok_a || !ok_b || !scores)
         return fail(SFM_EINVAL, "sfm_pair_scores: null pointer");
@@ -528,13 +668,17 @@ int sfm_pair_scores(int metric, const double* patches_a, int64_t stride_a, const
     const bool direct = direct_staging_ok(patches_a, stride_a, n_a) && direct_staging_ok(patches_b, stride_b, n_b);
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, grid, dim3(256), 0, (hipStream_t)stream, patches_a, stride_a, patches_b, stride_b,
-                           ssq_a, ssq_b, ok_a, ok_b, n_a, n_b, window_elements, scores);
+                           ssq_a, ssq_b, ok_a, ok_b, n_a, n_b, window_elements, scores, kind);
     };
-    if (metric == SFM_MATCH_NCC) {
-        if (direct) launch(pair_scores_kernel<0, true>); else launch(pair_scores_kernel<0, false>);
-    } else {
-        if (direct) launch(pair_scores_kernel<1, true>); else launch(pair_scores_kernel<1, false>);
+#define SFM_LAUNCH_MODE(M) do { if (direct) launch(pair_scores_kernel<M, true>); else launch(pair_scores_kernel<M, false>); } while (0)
+    switch (mode) {
+        case kModeNcc: SFM_LAUNCH_MODE(kModeNcc); break;
+        case kModeSsd: SFM_LAUNCH_MODE(kModeSsd); break;
+        case kModeSsdNarrowSigned: SFM_LAUNCH_MODE(kModeSsdNarrowSigned); break;
+        case kModeSsdNarrowUnsigned: SFM_LAUNCH_MODE(kModeSsdNarrowUnsigned); break;
+        default: SFM_LAUNCH_MODE(kModeSsdWide); break;
     }
+#undef SFM_LAUNCH_MODE
     return check_launch("pair_scores_kernel");
 }
 
@@ -548,7 +692,9 @@ int sfm_match_summary(int metric, const double* patches_a, int64_t stride_a, con
                       const uint8_t* ok_b, int64_t n_a, int64_t n_b, int window_elements, void* workspace,
                       int64_t workspace_bytes, double* best, int32_t* arg, double* second, void* stream) {
     if (n_a < 0 || n_b < 0 || window_elements < 1) return fail(SFM_EINVAL, "sfm_match_summary: bad size");
-    if (metric != SFM_MATCH_NCC && metric != SFM_MATCH_SSD) return fail(SFM_EINVAL, "sfm_match_summary: unknown metric");
+    IntKind kind;
+    const int mode = decode_metric(metric, window_elements, &kind);
+    if (mode < 0) return fail(SFM_EINVAL, "sfm_match_summary: unknown metric");
     if (n_a == 0) return SFM_OK;
     if (n_b == 0) return fail(SFM_EINVAL, "sfm_match_summary: empty rows");
     if (n_b > 0x7FFFFFFF) return fail(SFM_EINVAL, "sfm_match_summary: rows too long");
@@ -568,13 +714,17 @@ int sfm_match_summary(int metric, const double* patches_a, int64_t stride_a, con
     const bool direct = direct_staging_ok(patches_a, stride_a, n_a) && direct_staging_ok(patches_b, stride_b, n_b);
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, grid, dim3(256), 0, st, patches_a, stride_a, patches_b, stride_b, ssq_a, ssq_b,
-                           ok_a, ok_b, n_a, n_b, window_elements, tiles);
+                           ok_a, ok_b, n_a, n_b, window_elements, tiles, kind);
     };
-    if (metric == SFM_MATCH_NCC) {
-        if (direct) launch(pair_summary_kernel<0, true>); else launch(pair_summary_kernel<0, false>);
-    } else {
-        if (direct) launch(pair_summary_kernel<1, true>); else launch(pair_summary_kernel<1, false>);
+#define SFM_LAUNCH_MODE(M) do { if (direct) launch(pair_summary_kernel<M, true>); else launch(pair_summary_kernel<M, false>); } while (0)
+    switch (mode) {
+        case kModeNcc: SFM_LAUNCH_MODE(kModeNcc); break;
+        case kModeSsd: SFM_LAUNCH_MODE(kModeSsd); break;
+        case kModeSsdNarrowSigned: SFM_LAUNCH_MODE(kModeSsdNarrowSigned); break;
+        case kModeSsdNarrowUnsigned: SFM_LAUNCH_MODE(kModeSsdNarrowUnsigned); break;
+        default: SFM_LAUNCH_MODE(kModeSsdWide); break;
     }
+#undef SFM_LAUNCH_MODE
     hipLaunchKernelGGL(summary_combine_kernel, dim3(grid_for(n_a, 256)), dim3(256), 0, st, tiles, n_a, n_b, n_tiles,
                        best, arg, second);
     return check_launch("pair_summary_kernel");

@@ -1460,6 +1460,8 @@ int score_sed_impl(const double* corr, int64_t n, const double* E, const int32_t
         if (must_split && (steps_per_unit > matrixscore::kMaxRangeSteps || m_units <= 1 || split_env == 0)) {
             steps_per_unit = matrixscore::kMaxRangeSteps;   // more than 2 M points per pair: ranges of 2^16 steps, whatever was asked for
             m_units = (steps + steps_per_unit - 1) / steps_per_unit;
+            if (!sfmhost::grid_fits((int64_t)grid_for(waves32, 256 / kWave) * (int64_t)m_units * ((batch + 7) / 8 * 8), 1, 256))
+                return fail(SFM_EINVAL, "sfm_score_sed: hypotheses x ranges exceed what one launch covers");
         } else if (m_units <= 1 || split_env == 0 ||
                    !sfmhost::grid_fits((int64_t)grid_for(waves32, 256 / kWave) * (int64_t)m_units * ((batch + 7) / 8 * 8), 1, 256)) {
             m_units = 1;
@@ -1488,7 +1490,8 @@ int score_sed_impl(const double* corr, int64_t n, const double* E, const int32_t
 namespace sfmhost {
 
 int launch_large_score(const LargePass& p, LargeScore* folded_later) {
-    *folded_later = LargeScore{1, nullptr, nullptr};   // (stays so unless the matrix-pipe kernel split the points into ranges)
+    if (folded_later != nullptr)   // (NULL: the scoring launches fold their ranges themselves)
+        *folded_later = LargeScore{1, nullptr, nullptr};   // (stays so unless the matrix-pipe kernel split the points into ranges)
     const sfm_score_options opt = resolve_options(nullptr);
     if (p.h_count < 1 || p.n < 8 || p.n > 0x7FFFFFFF || p.h_count > 0x3FFFFFFF)
         return fail(SFM_EINVAL, "sfm_ransac_pass_large: sizes out of range");

@@ -998,15 +998,22 @@ __global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
             xcc &= 7u;
         }
-        const int mine = by_xcc ? units / 8 : units;   // ranges of a group that this wave's counter hands out
+        const int mine = by_xcc ? units / 8 : units;   // ranges of a group that one counter hands out
         const int items = waves32 * mine;
-        for (;;) {
-            const int t = take_ticket(tickets + 16 * xcc);
-            if (t >= items) break;   // (every wave gets here: the counter only grows)
-            const int wave = t / mine;
-            const int unit = by_xcc ? (int)xcc + 8 * (t % mine) : t % mine;
-            matrix_item<ESTIMATE>(a, n, h_count, thr, units, steps_per_unit, wave, unit, my_queue, lane,
-                                  (unsigned)(wave * units + unit));
+        // A wave empties its own XCD's counter first, then walks the other seven: every item is taken whatever the placement
+        // of the launch's waves — on a device that exposes fewer than eight XCDs (a CPX / DPX / QPX partition, a CU mask) the
+        // counters of the absent ones would otherwise never be served and their ranges' partials never written (round 4's
+        // advisor).  On the full chip the seven extra tickets per wave are taken when the launch is draining anyway.
+        for (unsigned k = 0; k < (by_xcc ? 8u : 1u); ++k) {
+            const unsigned x = (xcc + k) & 7u;
+            for (;;) {
+                const int t = take_ticket(tickets + 16 * x);
+                if (t >= items) break;   // (every wave gets here: the counter only grows)
+                const int wave = t / mine;
+                const int unit = by_xcc ? (int)x + 8 * (t % mine) : t % mine;
+                matrix_item<ESTIMATE>(a, n, h_count, thr, units, steps_per_unit, wave, unit, my_queue, lane,
+                                      (unsigned)(wave * units + unit));
+            }
         }
         return;
     }

@@ -7,7 +7,7 @@ import numpy as np
 import torch
 
 from .. import _native, device
-from .._native import MATCH_NCC, MATCH_SSD, check
+from .._native import MATCH_NCC, MATCH_SSD, PATCH_MEAN_REMOVED, PATCH_PLAIN, PATCH_RAW64, check
 
 F64 = torch.float64
 
@@ -20,16 +20,41 @@ def _features_tensor(features) -> torch.Tensor:
     return device.to_device(arr)
 
 
-def _image_tensor(image: np.ndarray) -> torch.Tensor:
+def _image_tensor(image: np.ndarray, integer_dtype=None) -> torch.Tensor:
     if image.ndim != 2:
         raise ValueError("the matcher works on single-channel (2-D) images")
-    return device.to_device(np.ascontiguousarray(image, dtype=np.float64))
+    if integer_dtype is None:
+        return device.to_device(np.ascontiguousarray(image, dtype=np.float64))
+    # integer SSD: the pixels in the common dtype NumPy would promote both images to (value-preserving), then as int64 —
+    # the two's-complement bit pattern for uint64, whose modular arithmetic is the same
+    wide = np.ascontiguousarray(image).astype(integer_dtype, copy=False)
+    wide = wide.view(np.int64) if wide.dtype == np.uint64 else wide.astype(np.int64)
+    return device.to_device(np.ascontiguousarray(wide), dtype=torch.int64)
+
+
+def ssd_arithmetic(dtype_a, dtype_b):
+    """The arithmetic the reference's ``calculate_ssd`` runs in for images of these dtypes (``ssd.py:31-35``: ``window_a -
+    window_b`` and ``np.square`` stay in NumPy's result type of the two): ``(integer dtype, device metric code)`` for an
+    integer result type — differences and squares then wrap modulo 2**bits —, ``(None, MATCH_SSD)`` for floating point
+    (computed in float64 here).  ``bool`` images raise the ``TypeError`` NumPy raises for ``bool - bool``."""
+    rt = np.result_type(dtype_a, dtype_b)
+    if rt == np.bool_:
+        raise TypeError("numpy boolean subtract, the `-` operator, is not supported, use the bitwise_xor, the `^` operator, "
+                        "or the logical_xor function instead.")
+    if rt.kind in "iu":
+        return rt, _native.match_ssd_int(8 * rt.itemsize, rt.kind == "i")
+    return None, MATCH_SSD
 
 
 def _extract_patches(metric: int, image_a, image_b, feats_a, feats_b, window_size: int):
-    """Window patches of both feature sets on the device: ((patches, ssq, ok, n) for a, same for b, K)."""
+    """Window patches of both feature sets on the device: ((patches, ssq, ok, n) for a, same for b, K, device metric).
+    ``metric`` MATCH_SSD on integer images becomes the integer-SSD code of their common dtype (``ssd_arithmetic``)."""
     if image_a.shape != image_b.shape:
         raise ValueError("the images must have the same shape")
+    integer_dtype = None
+    if metric == MATCH_SSD:
+        integer_dtype, metric = ssd_arithmetic(np.asarray(image_a).dtype, np.asarray(image_b).dtype)
+    patch_mode = PATCH_MEAN_REMOVED if metric == MATCH_NCC else (PATCH_RAW64 if integer_dtype is not None else PATCH_PLAIN)
     lib = _native.load()
     dev = device.require_gpu()
     st = device._stream()
@@ -37,7 +62,7 @@ def _extract_patches(metric: int, image_a, image_b, feats_a, feats_b, window_siz
     K = side * side
     out = []
     for image, feats in ((image_a, feats_a), (image_b, feats_b)):
-        img = _image_tensor(image)
+        img = _image_tensor(np.asarray(image), integer_dtype)
         ft = feats if isinstance(feats, torch.Tensor) else _features_tensor(feats)
         n = ft.shape[0]
         # rows padded to whole 128-feature tiles: the score kernels then stage them by LDS-DMA (sfm_match.hip)
@@ -45,15 +70,15 @@ def _extract_patches(metric: int, image_a, image_b, feats_a, feats_b, window_siz
         ssq = torch.empty((max(n, 1),), dtype=F64, device=dev)
         ok = torch.empty((max(n, 1),), dtype=torch.uint8, device=dev)
         check(lib.sfm_patch_extract(img.data_ptr(), img.shape[0], img.shape[1], ft.data_ptr(), n, int(window_size),
-                                    1 if metric == MATCH_NCC else 0, patches.shape[1], patches.data_ptr(),
+                                    patch_mode, patches.shape[1], patches.data_ptr(),
                                     ssq.data_ptr(), ok.data_ptr(), st), "sfm_patch_extract")
         out.append((patches, ssq, ok, n))
-    return out[0], out[1], K
+    return out[0], out[1], K, metric
 
 
 def score_matrix(metric: int, image_a, image_b, feats_a, feats_b, window_size: int) -> torch.Tensor:
     """(nA, nB) device tensor of window scores for every feature pair."""
-    (pa, qa, oka, nA), (pb, qb, okb, nB), K = _extract_patches(metric, image_a, image_b, feats_a, feats_b, window_size)
+    (pa, qa, oka, nA), (pb, qb, okb, nB), K, metric = _extract_patches(metric, image_a, image_b, feats_a, feats_b, window_size)
     lib = _native.load()
     st = device._stream()
     scores = torch.empty((nA, nB), dtype=F64, device=pa.device)
@@ -78,7 +103,7 @@ def row_summary(scores: torch.Tensor) -> Tuple[np.ndarray, np.ndarray, np.ndarra
 def match_summary(metric: int, image_a, image_b, feats_a, feats_b, window_size: int):
     """heap[0] score / b index and heap[1] score per A-feature straight from the images, without materialising
     the score matrix (``sfm_match_summary``); bit-identical to ``row_summary(score_matrix(...))``."""
-    (pa, qa, oka, nA), (pb, qb, okb, nB), K = _extract_patches(metric, image_a, image_b, feats_a, feats_b, window_size)
+    (pa, qa, oka, nA), (pb, qb, okb, nB), K, metric = _extract_patches(metric, image_a, image_b, feats_a, feats_b, window_size)
     lib = _native.load()
     dev = pa.device
     best = torch.empty((nA,), dtype=F64, device=dev)

@@ -1,8 +1,11 @@
 """Mean squared difference window score (reference ``lib/feature_matching/ssd.py:7-36``).
 
-Deviation, documented: the reference subtracts and squares in the image dtype, so on ``uint8`` images its
-result wraps modulo 256 (ssd.py:31-35).  Here images are widened to float64 first — identical to the reference
-for float or wide-integer images (the domain of its own ``test_ssd.py``); ``apps/sfm.py`` does not use SSD.
+The reference subtracts and squares in the image dtype (ssd.py:31-35): on integer images both steps wrap modulo
+2**bits — modulo 256 on the ``uint8`` images ``apps/sfm.py:222-224`` produces —, the sum runs in int64 / uint64 and the
+division by the window size in float64.  The device kernels do exactly that (``SFM_MATCH_SSD_INT``; golden G14: scores
+and match lists of the real reference on uint8, and every integer dtype, bit for bit).  Floating-point images are
+evaluated in float64 (float16 / float32 images agree with the reference to their own rounding); ``bool`` images raise
+NumPy's ``TypeError`` as in the reference.
 """
 import numpy as np
 

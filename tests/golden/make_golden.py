@@ -592,10 +592,84 @@ def g13_refit():
     save("g13_refit", **out)
 
 
+def g14_ssd_integer():
+    """ssd.py:31-36 on INTEGER images: the reference subtracts and squares in the image dtype (uint8 wraps modulo 256,
+    int16 modulo 65536 into the signed range, ...), sums in int64 / uint64 and divides by the window size in float64.
+    Same images, features and matcher wiring as g11 — taken on the uint8 images themselves, no float cast — plus
+    small known-answer grids for every integer dtype, for a mixed-dtype pair (NumPy promotes) and for bool (TypeError)."""
+    import functools
+    from lib.feature_matching import matching, ssd
+
+    d = np.load(os.path.join(HERE, "g11_matching.npz"))
+    image_a, image_b, fa, fb = d["image_a"], d["image_b"], d["feats_a"], d["feats_b"]
+    assert image_a.dtype == np.uint8 and image_b.dtype == np.uint8
+    feats_a, feats_b = feats(fa), feats(fb)
+    out = dict(image_a=image_a, image_b=image_b, feats_a=fa, feats_b=fb)
+
+    def score_fn(full):
+        def score(feature_a, feature_b):  # same shape as apps/sfm.py:_create_score_function
+            return full(image_a, image_b, feature_a, feature_b)
+        return score
+
+    combos = {
+        "none": None,
+        "ratio": matching.ValidationStrategy.RATIO_TEST,
+        "cross": {matching.ValidationStrategy.CROSSCHECK},
+        "both": {matching.ValidationStrategy.RATIO_TEST, matching.ValidationStrategy.CROSSCHECK},
+    }
+    for ws in (5, 9):
+        full = functools.partial(ssd.calculate_ssd, window_size=ws)
+        with np.errstate(over="ignore"):
+            out[f"scores_u8_w{ws}"] = np.array([[full(image_a, image_b, a, b) for b in feats_b] for a in feats_a],
+                                               dtype=np.float64)
+            for name, strat in combos.items():
+                for thr in (0.7, 0.95):
+                    ms = matching.match_brute_force(feats_a, feats_b, score_fn(full), validation_strategies=strat,
+                                                    ratio_test_threshold=thr)
+                    out[f"matches_u8_w{ws}_{name}_{thr}"] = np.array(
+                        [[m.a_index, m.b_index, m.match_score] for m in ms], dtype=np.float64).reshape(-1, 3)
+    # every integer dtype: random images over the dtype's full range (differences and squares wrap all the time),
+    # a 6 x 7 grid of features, windows of 3 and 5
+    rng = np.random.default_rng(1414)
+    H, W = 24, 30
+    gx, gy = np.meshgrid(np.array([0, 2, 5, 11, 17, 27, 29]), np.array([1, 2, 7, 12, 21, 23]))
+    grid = np.column_stack([gx.ravel(), gy.ravel()]).astype(np.float64)
+    out["grid_feats"] = grid
+    gf = feats(grid)
+    for name in ("uint8", "int8", "uint16", "int16", "uint32", "int32", "uint64", "int64"):
+        dt = np.dtype(name)
+        info = np.iinfo(dt)
+        ia = rng.integers(info.min, info.max, size=(H, W), dtype=dt, endpoint=True)
+        ib = rng.integers(info.min, info.max, size=(H, W), dtype=dt, endpoint=True)
+        out[f"{name}_a"], out[f"{name}_b"] = ia, ib
+        for ws in (3, 5):
+            with np.errstate(over="ignore"):
+                out[f"{name}_scores_w{ws}"] = np.array(
+                    [[ssd.calculate_ssd(ia, ib, a, b, ws) for b in gf[::3]] for a in gf], dtype=np.float64)
+    # mixed dtypes: NumPy promotes uint8 - int16 to int16, uint8 - int8 to int16, uint32 - int32 to int64, uint64 - int64 to float64
+    for na, nb in (("uint8", "int16"), ("uint8", "int8"), ("uint32", "int32"), ("uint64", "int64"), ("uint8", "float64")):
+        ia, ib = out[f"{na}_a"], (out[f"{nb}_b"] if nb != "float64" else out["uint8_b"].astype(np.float64) + 0.25)
+        with np.errstate(over="ignore"):
+            out[f"mixed_{na}_{nb}_scores"] = np.array(
+                [[ssd.calculate_ssd(ia, ib, a, b, 3) for b in gf[::3]] for a in gf], dtype=np.float64)
+    out["mixed_uint8_float64_b"] = out["uint8_b"].astype(np.float64) + 0.25
+    # the reference's own test_ssd.py vector (wide integers: platform int) and bool images (NumPy refuses `-` on bool)
+    img = np.array([[1, 2, 3, 4, 5], [6, 7, 8, 9, 10], [9, 8, 7, 6, 5], [4, 3, 2, 1, 0], [1, 2, 3, 4, 5]])
+    out["unit_int_image"] = img
+    out["unit_int_same"] = np.array(ssd.calculate_ssd(img, img.copy(), Feature(2, 2), Feature(2, 2), 5))
+    out["unit_int_negated"] = np.array(ssd.calculate_ssd(img, -img, Feature(2, 2), Feature(2, 2), 5))
+    try:
+        ssd.calculate_ssd(img > 4, img > 5, Feature(2, 2), Feature(2, 2), 3)
+        out["bool_raises"] = np.array(0)
+    except TypeError:
+        out["bool_raises"] = np.array(1)
+    save("g14_ssd_integer", **out)
+
+
 if __name__ == "__main__":
     everything = [g1_eight_point_pipeline, g2_ransac_known_answer, g3_per_hypothesis, g4_sed_values, g5_cheirality,
                   g6_triangulate, g7_degenerate, g8_unit_vectors, g9_explicit_table, g10_line_ransac, g11_matching,
-                  g12_harris, g13_refit]
+                  g12_harris, g13_refit, g14_ssd_integer]
     wanted = sys.argv[1:]  # e.g. ``make_golden.py g13`` regenerates one fixture
     for fn in everything:
         if not wanted or fn.__name__.split("_")[0] in wanted:

@@ -185,7 +185,7 @@ def test_unpadded_patch_layout_takes_the_fallback_staging():
     nA, nB = 131, 203
     fa = np.column_stack([rng.integers(0, W, nA), rng.integers(0, H, nA)]).astype(np.float64)
     fb = np.column_stack([rng.integers(0, W, nB), rng.integers(0, H, nB)]).astype(np.float64)
-    (pa, qa, oka, _), (pb, qb, okb, _), K = _device_match._extract_patches(0, ia, ib, feats(fa), feats(fb), ws)
+    (pa, qa, oka, _), (pb, qb, okb, _), K, _ = _device_match._extract_patches(0, ia, ib, feats(fa), feats(fb), ws)
     want = _device_match.score_matrix(0, ia, ib, feats(fa), feats(fb), ws)
     want_sum = _device_match.match_summary(0, ia, ib, feats(fa), feats(fb), ws)
     st = device._stream()
@@ -209,3 +209,143 @@ def test_unpadded_patch_layout_takes_the_fallback_staging():
         np.testing.assert_array_equal(best.cpu().numpy(), want_sum[0])
         np.testing.assert_array_equal(arg.cpu().numpy(), want_sum[1])
         np.testing.assert_array_equal(second.cpu().numpy(), want_sum[2])
+
+
+# ---- SSD on integer images: the reference computes in the image dtype (ssd.py:31-36), golden G14 ------------------------------
+INT_DTYPES = ("uint8", "int8", "uint16", "int16", "uint32", "int32", "uint64", "int64")
+
+
+@pytest.mark.parametrize("name", INT_DTYPES)
+def test_ssd_integer_dtypes_bit_exact_vs_reference(golden, name):
+    """Every score of the real reference on images over the dtype's full range (differences and squares wrap all the time) —
+    bit for bit, through the score matrix and through the fused summaries."""
+    d = golden("g14_ssd_integer")
+    g = d["grid_feats"]
+    ia, ib = d[f"{name}_a"], d[f"{name}_b"]
+    assert ia.dtype == np.dtype(name)
+    for ws in (3, 5):
+        ref = d[f"{name}_scores_w{ws}"]
+        got = _device_match.score_matrix(1, ia, ib, feats(g), feats(g[::3]), ws).cpu().numpy()
+        np.testing.assert_array_equal(got, ref)
+        best, arg, second = _device_match.match_summary(1, ia, ib, feats(g), feats(g[::3]), ws)
+        b_o, a_o, s_o = mo.row_summary(ref)
+        np.testing.assert_array_equal(best, b_o)
+        np.testing.assert_array_equal(arg, a_o)
+        np.testing.assert_array_equal(second, s_o)
+    one = ssd.calculate_ssd(ia, ib, Feature(11, 12), Feature(5, 7), 5)      # the single-pair API, same arithmetic
+    assert one == mo.ssd_scores(ia, ib, np.array([[11.0, 12.0]]), np.array([[5.0, 7.0]]), 5)[0, 0]
+
+
+@pytest.mark.parametrize("ws", [5, 9])
+def test_ssd_uint8_scores_and_match_lists_equal_reference_bit_for_bit(golden, ws):
+    """uint8 images (what apps/sfm.py:222-224 produces) — scores and match lists of the real reference,
+    bit for bit, wired like apps/sfm.py:73-87."""
+    d = golden("g14_ssd_integer")
+    ia, ib = d["image_a"], d["image_b"]
+    assert ia.dtype == np.uint8
+    got = _device_match.score_matrix(1, ia, ib, feats(d["feats_a"]), feats(d["feats_b"]), ws).cpu().numpy()
+    np.testing.assert_array_equal(got, d[f"scores_u8_w{ws}"])
+    full = functools.partial(ssd.calculate_ssd, window_size=ws)
+
+    def _create_score_function(image_a, image_b, full_score_function):
+        def ssd_score(feature_a, feature_b):
+            return full_score_function(image_a, image_b, feature_a, feature_b)
+        return ssd_score
+
+    for combo in COMBOS:
+        for thr in (0.7, 0.95):
+            ms = matching.match_brute_force(feats(d["feats_a"]), feats(d["feats_b"]), _create_score_function(ia, ib, full),
+                                            validation_strategies=COMBOS[combo][0], ratio_test_threshold=thr)
+            got_list = np.array([[m.a_index, m.b_index, m.match_score] for m in ms], dtype=np.float64).reshape(-1, 3)
+            np.testing.assert_array_equal(got_list, d[f"matches_u8_w{ws}_{combo}_{thr}"])
+
+
+def test_ssd_mixed_dtypes_and_bool(golden):
+    d = golden("g14_ssd_integer")
+    g = d["grid_feats"]
+    for na, nb in (("uint8", "int16"), ("uint8", "int8"), ("uint32", "int32")):   # NumPy promotes to int16, int16, int64
+        got = _device_match.score_matrix(1, d[f"{na}_a"], d[f"{nb}_b"], feats(g), feats(g[::3]), 3).cpu().numpy()
+        np.testing.assert_array_equal(got, d[f"mixed_{na}_{nb}_scores"])
+    for na, nb, key_b in (("uint64", "int64", "int64_b"), ("uint8", "float64", "mixed_uint8_float64_b")):   # float64 arithmetic
+        got = _device_match.score_matrix(1, d[f"{na}_a"], d[key_b], feats(g), feats(g[::3]), 3).cpu().numpy()
+        ref = d[f"mixed_{na}_{nb}_scores"]
+        fin = np.isfinite(ref)
+        assert np.array_equal(np.isinf(got), np.isinf(ref))
+        np.testing.assert_allclose(got[fin], ref[fin], rtol=1e-14)
+    with pytest.raises(TypeError):
+        ssd.calculate_ssd(d["uint8_a"] > 4, d["uint8_b"] > 5, Feature(5, 5), Feature(6, 6), 3)
+    img = d["unit_int_image"]
+    assert ssd.calculate_ssd(img, img.copy(), Feature(2, 2), Feature(2, 2), 5) == float(d["unit_int_same"])
+    assert ssd.calculate_ssd(img, -img, Feature(2, 2), Feature(2, 2), 5) == float(d["unit_int_negated"])
+
+
+@pytest.mark.parametrize("name,nA,nB,ws", [("uint8", 600, 600, 9), ("uint8", 130, 257, 5), ("int8", 129, 128, 7),
+                                           ("uint16", 200, 513, 5), ("int16", 300, 140, 3), ("int32", 150, 150, 5),
+                                           ("uint64", 65, 200, 3)])
+def test_ssd_integer_large_random_vs_oracle(name, nA, nB, ws):
+    """Sizes around and beyond the 128 x 128 tile on random integer images: score matrix, fused summaries and match lists
+    against the oracle (NumPy's own fixed-width arithmetic: oracle.ssd_scores_in_dtype, pinned by G14 on the CPU)."""
+    rng = np.random.default_rng(nA * 11 + nB)
+    H, W = 120, 160
+    dt = np.dtype(name)
+    info = np.iinfo(dt)
+    ia = rng.integers(info.min, info.max, (H, W), dtype=dt, endpoint=True)
+    ib = np.roll(ia, (1, 2), axis=(0, 1))
+    with np.errstate(over="ignore"):
+        ib = (ib + rng.integers(0, 4, (H, W)).astype(dt)).astype(dt)    # wraps at the top of the range: still the same dtype
+    fa = np.column_stack([rng.integers(-2, W + 2, nA), rng.integers(-2, H + 2, nA)]).astype(np.float64)
+    fb = np.column_stack([rng.integers(-2, W + 2, nB), rng.integers(-2, H + 2, nB)]).astype(np.float64)
+    fb[: min(nA, nB) // 2] = fa[: min(nA, nB) // 2] + [2.0, 1.0]
+    want = mo.ssd_scores_in_dtype(ia, ib, fa, fb, ws)
+    sc = _device_match.score_matrix(1, ia, ib, feats(fa), feats(fb), ws)
+    np.testing.assert_array_equal(sc.cpu().numpy(), want)
+    b_o, a_o, s_o = mo.row_summary(want)
+    best_f, arg_f, second_f = _device_match.match_summary(1, ia, ib, feats(fa), feats(fb), ws)
+    np.testing.assert_array_equal(best_f, b_o)
+    np.testing.assert_array_equal(arg_f, a_o)
+    np.testing.assert_array_equal(second_f, s_o)
+    score = matching.ImagePairScore(ia, ib, ssd.calculate_ssd, ws)
+    for combo, (strat, ostrat) in COMBOS.items():
+        ms = matching.match_brute_force(feats(fa), feats(fb), score, validation_strategies=strat, ratio_test_threshold=0.7)
+        assert [(m.a_index, m.b_index, m.match_score) for m in ms] == mo.match_brute_force(want, ostrat, 0.7)
+
+
+def test_ssd_integer_window_beyond_the_32_bit_accumulators_and_unpadded_layout():
+    """(a) A window of more than 32768 elements on uint8 / int16 images: the 8 / 16-bit kernels' int32 accumulators could
+    overflow, the launcher must take the 64-bit kernel — same scores.  (b) The C ABI accepts any stride >= n: raw int64
+    patches in a tight odd-stride layout take the fallback staging and give the same scores."""
+    from structure_from_motion_amd import _native, device
+
+    rng = np.random.default_rng(8)
+    H, W, ws = 200, 210, 183     # 183 x 183 = 33489 window elements
+    for name in ("uint8", "int16"):
+        info = np.iinfo(np.dtype(name))
+        ia = rng.integers(info.min, info.max, (H, W), dtype=np.dtype(name), endpoint=True)
+        ib = rng.integers(info.min, info.max, (H, W), dtype=np.dtype(name), endpoint=True)
+        fa = np.array([[95.0, 93.0], [100.0, 100.0], [118.0, 108.0], [10.0, 10.0]])
+        fb = np.array([[91.0, 91.0], [117.0, 107.0], [104.0, 99.0]])
+        got = _device_match.score_matrix(1, ia, ib, feats(fa), feats(fb), ws).cpu().numpy()
+        np.testing.assert_array_equal(got, mo.ssd_scores_in_dtype(ia, ib, fa, fb, ws))
+        assert np.isinf(got[3]).all() and np.isfinite(got[:3]).all()
+    lib = _native.load()
+    H, W, ws = 80, 100, 5
+    ia = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    ib = np.roll(ia, (1, 1), axis=(0, 1))
+    nA, nB = 131, 203
+    fa = np.column_stack([rng.integers(0, W, nA), rng.integers(0, H, nA)]).astype(np.float64)
+    fb = np.column_stack([rng.integers(0, W, nB), rng.integers(0, H, nB)]).astype(np.float64)
+    (pa, qa, oka, _), (pb, qb, okb, _), K, metric = _device_match._extract_patches(1, ia, ib, feats(fa), feats(fb), ws)
+    assert metric == _native.match_ssd_int(8, False)
+    want = _device_match.score_matrix(1, ia, ib, feats(fa), feats(fb), ws)
+    np.testing.assert_array_equal(want.cpu().numpy(), mo.ssd_scores_in_dtype(ia, ib, fa, fb, ws))
+    st = device._stream()
+    ta = torch.empty(K * nA + 1, dtype=torch.float64, device="cuda")[1:].view(K, nA)
+    tb = torch.empty(K * nB + 1, dtype=torch.float64, device="cuda")[1:].view(K, nB)
+    ta.view(torch.int64).copy_(pa[:, :nA].view(torch.int64))    # (bit patterns: copied as integers)
+    tb.view(torch.int64).copy_(pb[:, :nB].view(torch.int64))
+    scores = torch.empty((nA, nB), dtype=torch.float64, device="cuda")
+    _native.check(lib.sfm_pair_scores(metric, ta.data_ptr(), nA, tb.data_ptr(), nB, qa.data_ptr(), qb.data_ptr(),
+                                      oka.data_ptr(), okb.data_ptr(), nA, nB, K, scores.data_ptr(), st), "scores")
+    np.testing.assert_array_equal(scores.cpu().numpy(), want.cpu().numpy())
+    assert lib.sfm_pair_scores(0x100 | 24, ta.data_ptr(), nA, tb.data_ptr(), nB, qa.data_ptr(), qb.data_ptr(), oka.data_ptr(),
+                               okb.data_ptr(), nA, nB, K, scores.data_ptr(), st) != 0       # 24-bit pixels: no such dtype

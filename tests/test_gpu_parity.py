@@ -910,6 +910,40 @@ def test_large_pass_entry_on_sizes_of_the_other_kernels(dev, n, h):
         np.testing.assert_array_equal(getattr(a, key).cpu().numpy().view(np.int64), getattr(b, key).cpu().numpy().view(np.int64))
 
 
+@pytest.mark.parametrize("n,h", [(20_000, 1_000), (9_000, 2_000), (33_000, 700)])
+def test_large_pass_forced_matrix_kernel_without_room_for_the_selection_state(dev, n, h):
+    """Round 4's advisor: below ~2064 hypotheses the selection state of the fused pass does not fit its place in the workspace,
+    sfm_ransac_pass_large falls back to the stand-alone selection and mask — and with the matrix-pipe kernel forced
+    (process-wide options) and the points cut into ranges it still deferred the fold of the ranges to a selection launch that
+    never came: the winner was picked from the pre-pass' cost estimates.  Outputs equal to the separate calls', and a model
+    is found."""
+    from structure_from_motion_amd._native import AGG_RMS
+
+    _, _, _, corr = scene(n, seed=12)
+    corr_d = dev.to_device(corr).reshape(1, n, 4)
+    thr, min_extra = 1.5e-6, 10
+    saved = dev.default_score_options()
+    try:
+        dev.set_default_score_options(_options(kernel="matrix"))
+        a, b = dev.RansacWorkspace(1, n, h), dev.RansacWorkspace(1, n, h)
+        dev.ransac_pass_large(corr_d, a.S, a.E, a.flags, a.cnt, a.s1, a.s2, a.result, a.mask, a.score_ws, thr, min_extra,
+                              AGG_RMS, philox=(9, 100))
+        dev.sample_fit_philox(corr_d, 9, 100, b.S, b.E, b.flags, 1)
+        dev.score_sed(corr_d, b.E, b.S, thr, b.cnt, b.s1, b.s2, workspace=b.score_ws)
+        dev.select_best(b.cnt, b.s1, b.s2, b.flags, min_extra, AGG_RMS, 0, b.result)
+        dev.inlier_mask(corr_d, b.E, b.S, b.result, thr, b.mask)
+        torch.cuda.synchronize()
+    finally:
+        dev.set_default_score_options(saved)
+    for key in ("S", "E", "flags", "cnt", "result", "mask"):
+        np.testing.assert_array_equal(getattr(a, key).cpu().numpy(), getattr(b, key).cpu().numpy(), err_msg=key)
+    for key in ("s1", "s2"):
+        np.testing.assert_array_equal(getattr(a, key).cpu().numpy().view(np.int64), getattr(b, key).cpu().numpy().view(np.int64))
+    exact = dev.score_sed(corr_d, a.E, a.S, thr, exact_only=True)
+    np.testing.assert_array_equal(exact[0].cpu().numpy(), a.cnt.cpu().numpy())   # counts, not cost estimates
+    assert a.outcome(0).best_h >= 0
+
+
 def test_fused_small_pass_random_sizes(dev, monkeypatch):
     """The lean small pass against the separate calls on 40 random (points, hypotheses) sizes over its whole range — every
     hypotheses-per-wave choice, loop remainder, partial last block, with and without the block barrier: counts, flags, masks
@@ -1252,8 +1286,12 @@ def test_matrix_filter_error_bound_margin(dev):
     """not only the outcome of the matrix-pipe filter but the MARGIN of its error bound, per (point,
     hypothesis), on (i) 10^6 pairs of the bench scene, (ii) pixel-unit coordinates, (iii) wide pixel coordinates with points
     within 3 % of the threshold (round 3's advisor: the fp16 split's subnormal tail), (iv) crafted cancellation cases.  On
-    every set: |r''_mfma - r''| <= delta'' / 2 (3 / 4 on the wide coordinates, where the absolute term of the subnormal split
-    is most of delta''), the accumulated denominator is an upper bound of the exact one, and no pair with sed <= thr is rejected.  The worst ratios are printed (pytest -s) and recorded in DESIGN.md."""
+    every set: |r''_mfma - r''| / delta'' stays under a CEILING of its coordinate regime — about 1.3 x what round 4 measured
+    (profiles/r04/filter_margin_report.txt: bench scene 0.036, pixel units 0.29, +-1000 0.32, +-4000 0.47, +-10 000 0.57,
+    +-30 000 0.55, crafted 0.06), never above 0.7 — so that a slow drift of the margin (the bound's accumulation term prices
+    probed, not specified, truncation behaviour of the matrix unit) fails loudly instead of only being printed —, the
+    accumulated denominator is an upper bound of the exact one, and no pair with sed <= thr is rejected.  The worst ratios are
+    printed (pytest -s) and recorded in DESIGN.md."""
     report, failures = [], []
 
     def check(name, corr, E, thr, max_ratio=0.5):
@@ -1268,21 +1306,22 @@ def test_matrix_filter_error_bound_margin(dev):
     _, _, _, corr = scene(n)
     S = orc.philox_sample_table(5, 0, h, n)
     E, _, _ = orc.fit_hypotheses(corr, S)
-    check("bench scene 1000 x 1024, thr 1.5e-6", corr, E, 1.5e-6)
-    check("bench scene 1000 x 1024, thr 1e-3", corr, E, 1e-3)
+    check("bench scene 1000 x 1024, thr 1.5e-6", corr, E, 1.5e-6, max_ratio=0.06)
+    check("bench scene 1000 x 1024, thr 1e-3", corr, E, 1e-3, max_ratio=0.06)
     # (ii) pixel units
     pa, pb, K, _ = scene(3000)
     pix = orc.pack_correspondences(pa, pb)
     Sp = orc.philox_sample_table(19, 0, 256, 3000)
     F, _, _ = orc.fit_hypotheses(pix, Sp)
     for thr in (1.0, 1e-2, 100.0):
-        check(f"pixel units 3000 x 256, thr {thr:g}", pix, F, thr)
+        check(f"pixel units 3000 x 256, thr {thr:g}", pix, F, thr, max_ratio=0.4)
     # (iii) wide coordinates, points within 3 % of the threshold
     for coord in (1000.0, 4000.0, 10000.0, 30000.0):
         for thr in (1e-2, 1.0, 100.0):
             cw, Fw = _epipolar_scene_wide(4096, 64, coord, thr, seed=int(coord) + int(thr * 100))
             # (here the absolute term of the subnormal split dominates delta''; the advisor's emulation saw 0.38 .. 0.58 of it used)
-            check(f"coordinates +-{coord:g}, 4096 x 64, thr {thr:g}", cw, Fw, thr, max_ratio=0.75)
+            check(f"coordinates +-{coord:g}, 4096 x 64, thr {thr:g}", cw, Fw, thr,
+                  max_ratio={1000.0: 0.45, 4000.0: 0.6}.get(coord, 0.7))
     # (iv) crafted: products of alternating sign at the top of the fp16 range; one large + many small addends; mantissas of
     # all ones (worst case of the hi / mid split); entries 2^-20 .. 1 apart (the subnormal tail)
     rng = np.random.default_rng(77)
@@ -1299,7 +1338,7 @@ def test_matrix_filter_error_bound_margin(dev):
     Ec[h // 2: 3 * h // 4, 0, 0] = 1.0                                   # one large + eight small
     Ec[3 * h // 4:] = rng.normal(size=(h - 3 * h // 4, 3, 3)) * 10.0 ** rng.integers(-6, 1, size=(h - 3 * h // 4, 3, 3))
     for thr in (1e-4, 1.0):
-        check(f"crafted cancellation 512 x 256, thr {thr:g}", pts, Ec, thr)
+        check(f"crafted cancellation 512 x 256, thr {thr:g}", pts, Ec, thr, max_ratio=0.12)
     print("\n" + "\n".join(report))
     assert not failures, "\n".join(failures)
 
@@ -1415,6 +1454,24 @@ def test_matrix_kernel_beyond_65536_points(dev, n, h):
         _assert_same_scores(exact, ranged)
 
 
+def test_matrix_kernel_beyond_two_million_points(dev):
+    """More than 2^16 steps of 32 points (2 097 152 points) cannot be one range — a queue entry keeps its step relative to the
+    range in 16 bits — so the launcher must cut the points into ranges of at most 65 536 steps whatever was asked for
+    (split = 0 included): a relative step of 65 535 and 32-bit byte offsets up to 2^26 are executed here.  Counts equal to the
+    all-fp64 kernel's, sums to summation order."""
+    n, h = 2_097_152 + 48, 64
+    _, _, _, corr = scene(n)
+    S = orc.philox_sample_table(3, 0, h, n)
+    E, _, _ = orc.fit_hypotheses(corr, S)
+    exact, auto = _score_both(dev, corr, E, S, 1.5e-6, _options(kernel="matrix"))
+    _assert_same_scores(exact, auto)
+    _, unsplit = _score_both(dev, corr, E, S, 1.5e-6, _options(kernel="matrix", split=0))
+    _assert_same_scores(exact, unsplit)
+    _, persistent = _score_both(dev, corr, E, S, 1.5e-6, _options(kernel="matrix", split=0, persistent=1))
+    _assert_same_scores(exact, persistent)
+    assert exact[0].max() > 1_000_000     # the fitted scene: the best hypotheses keep most of the 70 % inliers
+
+
 def test_score_kernel_size_rule_picks_the_matrix_kernel(dev):
     """Left to itself (options.kernel = auto) a single-pair launch of at least 8192 points, 4096 hypotheses and 5 x 10^8
     evaluations runs the matrix-pipe kernel: same counts as the all-fp64 kernel, and as the VALU-filter kernel forced by
@@ -1511,7 +1568,7 @@ def test_c5_batched_pipeline_full_size(dev, tmp_path, c_oracle_lib):
     mask = pipe.ws.mask.cpu().numpy()
     assert all(r.status == batched.OK for r in results)
     for b, res in enumerate(results):
-        err = orc.aggregate(cnt[b], s2[b], s2[b], orc.RMS)
+        err = orc.aggregate(cnt[b], s1[b], s2[b], orc.RMS)
         best, _ = orc.select_best(err, cnt[b], min_extra)
         assert res.best_h == best, b
         assert int((mask[b] == 1).sum()) == cnt[b, best] and int((mask[b] == 2).sum()) == 8, b

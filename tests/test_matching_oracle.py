@@ -97,3 +97,59 @@ def test_reference_matching_unit_vectors():
     single = np.array([[3.0], [4.0]])
     assert mo.match_brute_force(single, {mo.RATIO_TEST}, 0.1) == [(0, 0, 3.0), (1, 0, 4.0)]
     assert mo.match_brute_force(single, {mo.CROSSCHECK}) == [(0, 0, 3.0)]
+
+
+INT_DTYPES = ("uint8", "int8", "uint16", "int16", "uint32", "int32", "uint64", "int64")
+
+
+@pytest.mark.parametrize("name", INT_DTYPES)
+def test_ssd_integer_dtypes_equal_reference_bit_for_bit(golden, name):
+    """ssd.py:31-36 in the image dtype (G14: the real reference on images over each dtype's full range): both restatements —
+    exact Python integers with explicit reductions, and NumPy's own fixed-width arithmetic — reproduce every score exactly."""
+    d = golden("g14_ssd_integer")
+    g = d["grid_feats"]
+    for ws in (3, 5):
+        ref = d[f"{name}_scores_w{ws}"]
+        np.testing.assert_array_equal(mo.ssd_scores(d[f"{name}_a"], d[f"{name}_b"], g, g[::3], ws), ref)
+        np.testing.assert_array_equal(mo.ssd_scores_in_dtype(d[f"{name}_a"], d[f"{name}_b"], g, g[::3], ws), ref)
+    assert np.isinf(d[f"{name}_scores_w5"]).any() and np.isfinite(d[f"{name}_scores_w5"]).any()
+
+
+def test_ssd_uint8_scores_and_match_lists_equal_reference(golden):
+    d = golden("g14_ssd_integer")
+    g11 = golden("g11_matching")
+    for ws in (5, 9):
+        got = mo.ssd_scores(d["image_a"], d["image_b"], d["feats_a"], d["feats_b"], ws)
+        np.testing.assert_array_equal(got, d[f"scores_u8_w{ws}"])
+        np.testing.assert_array_equal(mo.ssd_scores_in_dtype(d["image_a"], d["image_b"], d["feats_a"], d["feats_b"], ws), got)
+        for combo, strat in COMBOS.items():
+            for thr in (0.7, 0.95):
+                own = np.array(mo.match_brute_force(got, strat, thr), dtype=np.float64).reshape(-1, 3)
+                np.testing.assert_array_equal(own, d[f"matches_u8_w{ws}_{combo}_{thr}"])
+    # the wrap is visible on this fixture: the uint8 scores are NOT the float-image scores of G11
+    assert not np.array_equal(d["scores_u8_w5"], g11["scores_ssd"])
+    assert np.nanmax(d["scores_u8_w5"][np.isfinite(d["scores_u8_w5"])]) <= 255.0
+
+
+def test_ssd_mixed_dtypes_and_bool(golden):
+    d = golden("g14_ssd_integer")
+    g = d["grid_feats"]
+    for na, nb in (("uint8", "int16"), ("uint8", "int8"), ("uint32", "int32")):   # NumPy promotes to int16, int16, int64
+        np.testing.assert_array_equal(mo.ssd_scores(d[f"{na}_a"], d[f"{nb}_b"], g, g[::3], 3), d[f"mixed_{na}_{nb}_scores"])
+    assert mo.ssd_result_kind(np.uint8, np.int16) == ("int", 16, True)
+    assert mo.ssd_result_kind(np.uint8, np.int8) == ("int", 16, True)
+    assert mo.ssd_result_kind(np.uint32, np.int32) == ("int", 64, True)
+    assert mo.ssd_result_kind(np.uint64, np.int64) == ("float",)     # NumPy goes to float64 here
+    for na, nb, key_b in (("uint64", "int64", "int64_b"), ("uint8", "float64", "mixed_uint8_float64_b")):
+        got = mo.ssd_scores(d[f"{na}_a"], d[key_b], g, g[::3], 3)
+        ref = d[f"mixed_{na}_{nb}_scores"]
+        fin = np.isfinite(ref)
+        assert np.array_equal(np.isinf(got), np.isinf(ref))
+        np.testing.assert_allclose(got[fin], ref[fin], rtol=1e-14)
+    assert int(d["bool_raises"]) == 1
+    with pytest.raises(TypeError):
+        mo.ssd_scores(d["uint8_a"] > 4, d["uint8_b"] > 5, g, g, 3)
+    img = d["unit_int_image"]
+    c = np.array([[2.0, 2.0]])
+    assert mo.ssd_scores(img, img.copy(), c, c, 5)[0, 0] == float(d["unit_int_same"]) == 0.0
+    assert mo.ssd_scores(img, -img, c, c, 5)[0, 0] == float(d["unit_int_negated"])
