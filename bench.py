@@ -339,17 +339,16 @@ def other_configs(torch, device, distributed, synthetic, agg):
         return (time.perf_counter() - t0) / reps
 
     def scoring_kernel_ms(fn):
-        """One more invocation of `fn` with its scoring kernel bracketed by HIP events recorded inside the library,
-        immediately around that kernel on its launch stream (sfm_score_set_timing_events)."""
+        """One more invocation of `fn` with its scoring kernel bracketed by HIP events that travel in the call's launch options
+        (sfm_score_options.timing_before / _after): recorded inside the library, immediately around that kernel on its launch
+        stream.  `fn(rep, options)` passes the options on to its engine."""
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         b.record()
         torch.cuda.synchronize()
         times = []
         for rep in range(3):
-            device.score_timing_events(a, b)
-            fn(rep)
-            device.score_timing_events(None, None)
+            fn(rep, device.default_score_options().with_timing(a, b))
             torch.cuda.synchronize()
             times.append(a.elapsed_time(b))
         return float(np.median(times))
@@ -391,7 +390,16 @@ def other_configs(torch, device, distributed, synthetic, agg):
     groups = [wall(lambda r, g=g: eng.step(1000 + 20 * g + r), 20) for g in range(10)]
     us = float(np.median(groups)) * 1e6
     res = eng.outcome()
-    k_ms = scoring_kernel_ms(lambda r: eng.step(2000 + r))
+    def timed(step):
+        def call(r, options):
+            eng.score_options = options
+            try:
+                step(2000 + r)
+            finally:
+                eng.score_options = None
+        return call
+
+    k_ms = scoring_kernel_ms(timed(eng.step))
     exact = int(eng.ws.cnt.sum().item()) + 8 * h
     out["c2_5000x10000"] = {"pass_us": us, "evals_per_s": n * h / us * 1e6, "passes": 200, "best_h": res.best_h,
                             "inliers": int((res.mask != 0).sum()),
@@ -404,7 +412,7 @@ def other_configs(torch, device, distributed, synthetic, agg):
     eng = distributed.ShardedRansac(corr, None, THR, MIN_EXTRA, agg, rank=0, world=world, total_hypotheses=total)
     wall(lambda r: eng.step_local(50 + r), 3)
     sec = wall(lambda r: eng.step_local(1000 + r), 10)
-    k_ms = scoring_kernel_ms(lambda r: eng.step_local(2000 + r))
+    k_ms = scoring_kernel_ms(timed(eng.step_local))
     exact = int(eng.ws.cnt.sum().item()) + 8 * eng.h
     out["c4_shard_125000x50000"] = {"ms": sec * 1e3, "evals_per_s": n * eng.h / sec,
                                     "note": "rank 0 of 8: local pass over its 125 000 hypotheses of the 1 M stream",
@@ -418,11 +426,12 @@ def other_configs(torch, device, distributed, synthetic, agg):
     pix_a = device.to_device(np.stack([base[b % 16][0] for b in range(B)]))
     pix_b = device.to_device(np.stack([base[b % 16][1] for b in range(B)]))
     pipe = batched.TwoViewBatch(B, n, h)
-    run = lambda r: pipe.run(pix_a, pix_b, base[0][2], seed=70 + 1000 * r, thr=THR, min_extra=MIN_EXTRA, aggregation=agg)
+    run = lambda r, options=None: pipe.run(pix_a, pix_b, base[0][2], seed=70 + 1000 * r, thr=THR, min_extra=MIN_EXTRA,
+                                           aggregation=agg, score_options=options)
     wall(run, 2)
     sec = wall(run, 5)
     ok = sum(r.status == batched.OK for r in pipe.results())
-    k_ms = scoring_kernel_ms(lambda r: run(100 + r))
+    k_ms = scoring_kernel_ms(lambda r, options: run(100 + r, options))
     exact = int(pipe.ws.cnt.sum().item()) + 8 * h * B
     out["c5_256x10000x2000"] = {"batch_ms": sec * 1e3, "evals_per_s": B * n * h / sec, "pairs_per_s": B / sec,
                                 "pairs_ok": ok, "note": "E estimation + pose vote + triangulation, one enqueue",
@@ -536,15 +545,15 @@ def main():
     device.score_sed = timed_score
 
     def timed_step(i, seed):
-        """One engine step with the scoring kernel of that step bracketed by kernel_ev[i]: the events are recorded
-        inside the library immediately around the scoring kernel, on its launch stream — by sfm_score_sed and by the
-        scoring launch of sfm_ransac_pass_small alike."""
+        """One engine step with the scoring kernel of that step bracketed by kernel_ev[i]: the events travel in the step's
+        launch options and are recorded inside the library immediately around the scoring kernel, on its launch stream — by
+        sfm_score_sed_ex and by the scoring launch of sfm_ransac_pass_small / _large alike."""
         state["i"] = i
-        if i >= 0:
-            device.score_timing_events(*kernel_ev[i])
-        engine.step(seed)
-        if i >= 0:
-            device.score_timing_events(None, None)
+        engine.score_options = device.default_score_options().with_timing(*kernel_ev[i]) if i >= 0 else None
+        try:
+            engine.step(seed)
+        finally:
+            engine.score_options = None
         state["i"] = -1
 
     def barrier():

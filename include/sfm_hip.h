@@ -161,13 +161,19 @@ typedef struct sfm_score_options {
     int32_t persistent;    /* matrix-pipe kernel, single pair: 1 = persistent waves taking (hypothesis group, range) items from
                               per-XCD counters; -1 / 0 = one block per four items, placed by the hardware dispatcher (default:
                               measured equal at 5e9 evaluations and faster below — the 4096 first tickets cost ~45 us) */
+    /* Measurement hook of THIS call (ABI 11; until then process-global state behind sfm_score_set_timing_events): hipEvent_t
+     * handles (either may be NULL) recorded on the launch stream immediately before / after the scoring kernel itself — not the
+     * workspace preparation or the ordering pre-pass — so that a benchmark times exactly the kernel a profiler reports.  Never
+     * part of the process-wide defaults (sfm_score_set_default_options clears them). */
+    void* timing_before;
+    void* timing_after;
 } sfm_score_options;
-#define SFM_SCORE_OPTIONS_DEFAULT {SFM_SCORE_KERNEL_AUTO, 0, -1, -1, -1, -1, -1, -1}
+#define SFM_SCORE_OPTIONS_DEFAULT {SFM_SCORE_KERNEL_AUTO, 0, -1, -1, -1, -1, -1, -1, 0, 0}
 int sfm_score_sed_ex(const double* corr, int64_t n, const double* E, const int32_t* S, int64_t h_count,
                      int64_t batch, double thr, int32_t* cnt, double* s1, double* s2, void* workspace,
                      int64_t workspace_bytes, void* stream, const sfm_score_options* options);
-/* Process-wide defaults for calls without options (sfm_score_sed, sfm_ransac_pass_small, sfm_score_sed_ex(..., NULL));
- * NULL restores SFM_SCORE_OPTIONS_DEFAULT.  _get copies the current set out. */
+/* Process-wide defaults for calls without options (sfm_score_sed, sfm_ransac_pass_small / _large and sfm_score_sed_ex with
+ * options == NULL); NULL restores SFM_SCORE_OPTIONS_DEFAULT.  _get copies the current set out. */
 int sfm_score_set_default_options(const sfm_score_options* options);
 int sfm_score_get_default_options(sfm_score_options* out);
 /* Which kernel a call would launch for these sizes with a workspace: SFM_SCORE_KERNEL_FILTERED or SFM_SCORE_KERNEL_MATRIX;
@@ -190,12 +196,13 @@ int sfm_score_kernel_choice_ex(int64_t n, int64_t h_count, int64_t batch, const 
  * A small pass is a chain of dependent, latency-bound launches: what shortens it is fewer and leaner ones.
  * h_offset as in sfm_select_best (the record carries global indices = local + h_offset); the mask is always the
  * winner's, whatever h_offset: the kernels index E and S with the local winner.
- * workspace: sfm_score_workspace_bytes(n, h_count, 1) bytes, 16-byte aligned. */
+ * workspace: sfm_score_workspace_bytes(n, h_count, 1) bytes, 16-byte aligned.  options: launch options of the scoring launch
+ * (NULL = the process-wide defaults). */
 int sfm_ransac_pass_small(uint64_t seed, const uint64_t* seed_dev, int use_philox, int64_t h_begin, const double* corr,
                           int64_t n, int64_t h_count, double thr, double min_extra, int aggregation, int64_t h_offset,
                           int32_t* S, double* E, int32_t* flags, int32_t* cnt, double* s1, double* s2,
                           sfm_select_result* result, uint8_t* mask, void* workspace, int64_t workspace_bytes,
-                          void* stream);
+                          void* stream, const sfm_score_options* options);
 
 /* Diagnostic of the matrix-pipe reject filter (tests measure the margin of its error bound with it; not on the product
  * path): prepares the operand tables of one pair exactly as sfm_score_sed does and evaluates tier 1 — the three 16-bit
@@ -224,13 +231,7 @@ int sfm_ransac_pass_large(uint64_t seed, const uint64_t* seed_dev, int use_philo
                           int64_t n, int64_t h_count, double thr, double min_extra, int aggregation, int64_t h_offset,
                           int32_t* S, double* E, int32_t* flags, int32_t* cnt, double* s1, double* s2,
                           sfm_select_result* result, uint8_t* mask, void* workspace, int64_t workspace_bytes,
-                          void* stream);
-
-/* Measurement hook: the next sfm_score_sed calls of the calling thread record the hipEvent_t `before` / `after`
- * (passed as void*, either may be NULL) on the launch stream immediately around the scoring kernel itself — not the
- * workspace preparation or the ordering pre-pass — so that a benchmark can time exactly the kernel a profiler
- * reports.  (NULL, NULL) switches it off. */
-int sfm_score_set_timing_events(void* before, void* after);
+                          void* stream, const sfm_score_options* options);
 
 /* Model selection (ransac.py:75-86): lowest aggregated error among hypotheses with
  * cnt >= min_extra, strict <, earliest index wins, NaN/inf never win.  result: dev [batch]. */

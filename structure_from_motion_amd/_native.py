@@ -39,8 +39,10 @@ class SelectResult(C.Structure):
 
 
 class ScoreOptions(C.Structure):
-    """struct sfm_score_options (32 bytes): launch options of the two-tier scoring kernels — they change how a call is
-    launched, never its counts or decisions (include/sfm_hip.h)."""
+    """struct sfm_score_options (48 bytes): launch options of the two-tier scoring kernels — they change how a call is
+    launched, never its counts or decisions (include/sfm_hip.h) — and the call's measurement hook: ``timing=(before, after)``,
+    two ``torch.cuda.Event`` (recorded once already: torch creates the hipEvent lazily) or raw hipEvent_t handles that the
+    library records immediately around the scoring kernel of THIS call."""
 
     _fields_ = [
         ("kernel", C.c_int32),         # SCORE_KERNEL_AUTO / _FILTERED / _MATRIX
@@ -51,13 +53,23 @@ class ScoreOptions(C.Structure):
         ("xcd_map", C.c_int32),        # batches: -1 / 1 XCD-aware block map (default), 0 plain grid
         ("block_sync", C.c_int32),     # small pass: -1 = by size, k = barrier every k iterations, 0 never
         ("persistent", C.c_int32),     # matrix-pipe kernel, one pair: 1 persistent waves, -1 / 0 one block per 4 items (default)
+        ("timing_before", C.c_void_p),  # hipEvent_t recorded right before the scoring kernel of this call (NULL: none)
+        ("timing_after", C.c_void_p),   # ... and right after it
     ]
 
-    def __init__(self, kernel=0, hyps_per_wave=0, split=-1, order=-1, one_sided=-1, xcd_map=-1, block_sync=-1, persistent=-1):
+    def __init__(self, kernel=0, hyps_per_wave=0, split=-1, order=-1, one_sided=-1, xcd_map=-1, block_sync=-1, persistent=-1,
+                 timing=None):
         if isinstance(kernel, str):
             kernel = {"auto": SCORE_KERNEL_AUTO, "filtered": SCORE_KERNEL_FILTERED, "matrix": SCORE_KERNEL_MATRIX}[kernel]
+        before, after = timing if timing is not None else (None, None)
+        handle = lambda e: None if e is None else (e if isinstance(e, int) else e.cuda_event)  # noqa: E731
         super().__init__(int(kernel), int(hyps_per_wave), int(split), int(order), int(one_sided), int(xcd_map),
-                         int(block_sync), int(persistent))
+                         int(block_sync), int(persistent), handle(before), handle(after))
+
+    def with_timing(self, before, after) -> "ScoreOptions":
+        """A copy of these options that has the library record ``before`` / ``after`` around the scoring kernel."""
+        return ScoreOptions(self.kernel, self.hyps_per_wave, self.split, self.order, self.one_sided, self.xcd_map,
+                            self.block_sync, self.persistent, timing=(before, after))
 
 
 SCORE_KERNEL_AUTO, SCORE_KERNEL_FILTERED, SCORE_KERNEL_MATRIX = 0, 1, 2
@@ -112,11 +124,10 @@ SIGNATURES = {
     "sfm_score_get_default_options": [_P],
     "sfm_score_kernel_choice_ex": [_I64, _I64, _I64, _P],
     "sfm_debug_matrix_filter": [_P, _I64, _P, _I64, _D, _P, _I64, _P, _P, _P, _P],
-    "sfm_score_set_timing_events": [_P, _P],
     "sfm_ransac_pass_small": [_U64, _P, C.c_int, _I64, _P, _I64, _I64, _D, _D, C.c_int, _I64, _P, _P, _P, _P, _P, _P,
-                              _P, _P, _P, _I64, _P],
+                              _P, _P, _P, _I64, _P, _P],
     "sfm_ransac_pass_large": [_U64, _P, C.c_int, _I64, _P, _I64, _I64, _D, _D, C.c_int, _I64, _P, _P, _P, _P, _P, _P,
-                              _P, _P, _P, _I64, _P],
+                              _P, _P, _P, _I64, _P, _P],
     "sfm_select_best": [_P, _P, _P, _P, _I64, _I64, _D, C.c_int, _I64, _P, _P],
     "sfm_fold_select_records": [_P, _I64, _I64, _P, _P, _P, _P],
     "sfm_fold_select_records_host": [_P, _I64, _I64, _P, _P, _P],

@@ -62,18 +62,19 @@ class TwoViewBatch:
 
     def run(self, pix_a: torch.Tensor, pix_b: torch.Tensor, K, seed: int, thr: float, min_extra: float,
             aggregation: int, distance_threshold: float = 50.0, seed_stride: int = 1,
-            local_optimisation: int = 0) -> None:
+            local_optimisation: int = 0, score_options=None) -> None:
         """Enqueue the whole pipeline.  pix_a, pix_b: [B,N,2] f64 device tensors (pixel coordinates);
         pair b samples with Philox seed ``seed + b*seed_stride``.  ``local_optimisation=k`` (extension, off by
         default) refits every winner on all its inliers up to k times before pose recovery; the inlier lists
-        then come back in index order (a refined model has no sample to put first)."""
+        then come back in index order (a refined model has no sample to put first).  ``score_options``: launch options of
+        the scoring launch of this call (``device.ScoreOptions``, timing events included)."""
         lib = _native.load()
         B, N = self.batch, self.n
         st = device._stream()
         ws = self.ws
         self._pix, self._K = (pix_a, pix_b), np.ascontiguousarray(K, dtype=np.float64)
         device.normalize_correspondences(pix_a, pix_b, K, out=self.corr)
-        ws.run(self.corr, thr, min_extra, aggregation, philox=(seed, 0, seed_stride))
+        ws.run(self.corr, thr, min_extra, aggregation, philox=(seed, 0, seed_stride), options=score_options)
         # winner's E and first sample index per pair (torch indexing = device memory plumbing only)
         best = ws.result[:, 1].clamp(min=0)
         rows = torch.arange(B, device=best.device)

@@ -70,6 +70,7 @@ struct SmallPass {
     uint8_t* mask;  // may be NULL
     unsigned char* workspace;
     hipStream_t stream;
+    const sfm_score_options* options;   // launch options of the scoring launch (NULL: the process-wide defaults)
 };
 double small_pass_a_scale(double thr);   // factor the prepared a-side coordinates carry for this threshold
 // where the fit launch leaves the scoring order of the pass, or NULL when the pass is too small for an order to matter
@@ -97,8 +98,10 @@ struct LargePass {
     int64_t workspace_bytes;
     unsigned* select_state;    // 16 words the scoring launches zero for the selection launch (NULL: none)
     hipStream_t stream;
+    const sfm_score_options* options;   // launch options (NULL: the process-wide defaults)
 };
 int launch_large_score(const LargePass& pass, LargeScore* folded_later);
+bool score_options_valid(const sfm_score_options* options);   // NULL (the process-wide defaults) is valid
 
 }  // namespace sfmhost
 

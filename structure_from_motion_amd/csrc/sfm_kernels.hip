@@ -1033,7 +1033,7 @@ int sfm_ransac_pass_small(uint64_t seed, const uint64_t* seed_dev, int use_philo
                           int64_t n, int64_t h_count, double thr, double min_extra, int aggregation, int64_t h_offset,
                           int32_t* S, double* E, int32_t* flags, int32_t* cnt, double* s1, double* s2,
                           sfm_select_result* result, uint8_t* mask, void* workspace, int64_t workspace_bytes,
-                          void* stream) {
+                          void* stream, const sfm_score_options* options) {
     if (n < 8 || n > sfmws::kSmallMaxPoints)
         return fail(SFM_EINVAL, "sfm_ransac_pass_small: need 8 <= n <= 8192 (larger point sets: the separate calls)");
     if (h_count < 1 || h_count > 32 * 1024)
@@ -1043,6 +1043,7 @@ int sfm_ransac_pass_small(uint64_t seed, const uint64_t* seed_dev, int use_philo
         return fail(SFM_EINVAL, "sfm_ransac_pass_small: unknown aggregation");
     if (!corr || !S || !E || !flags || !cnt || !s1 || !s2 || !result || !workspace)
         return fail(SFM_EINVAL, "sfm_ransac_pass_small: null pointer");
+    if (!sfmhost::score_options_valid(options)) return fail(SFM_EINVAL, "sfm_ransac_pass_small: an option is out of range");
     if (workspace_bytes < sfm_score_workspace_bytes(n, h_count, 1))
         return fail(SFM_EINVAL, "sfm_ransac_pass_small: workspace smaller than sfm_score_workspace_bytes(n, h_count, 1)");
     if ((reinterpret_cast<uintptr_t>(workspace) & 15u) != 0)
@@ -1061,7 +1062,7 @@ int sfm_ransac_pass_small(uint64_t seed, const uint64_t* seed_dev, int use_philo
     // launch 2: SED scoring
     const int rc2 = sfmhost::launch_small_score(sfmhost::SmallPass{corr, n, E, S, flags, h_count, thr, min_extra, aggregation,
                                                                    h_offset, cnt, s1, s2, result, mask,
-                                                                   static_cast<unsigned char*>(workspace), st});
+                                                                   static_cast<unsigned char*>(workspace), st, options});
     if (rc2 != SFM_OK) return rc2;
     // launch 3: selection spread over up to 32 blocks x 256 threads x 4 hypotheses, folded by the block that arrives last
     // (a single block needs 14 us at 10 000 and 35 us at 30 000 hypotheses), and — behind them in the same launch — the
@@ -1086,7 +1087,7 @@ int sfm_ransac_pass_large(uint64_t seed, const uint64_t* seed_dev, int use_philo
                           int64_t n, int64_t h_count, double thr, double min_extra, int aggregation, int64_t h_offset,
                           int32_t* S, double* E, int32_t* flags, int32_t* cnt, double* s1, double* s2,
                           sfm_select_result* result, uint8_t* mask, void* workspace, int64_t workspace_bytes,
-                          void* stream) {
+                          void* stream, const sfm_score_options* options) {
     if (n < 8 || n > 0x7FFFFFFF) return fail(SFM_EINVAL, "sfm_ransac_pass_large: need 8 <= n < 2^31");
     if (h_count < 1 || h_count > 0x3FFFFFFF) return fail(SFM_EINVAL, "sfm_ransac_pass_large: need 1 <= h_count < 2^30");
     if (h_begin < 0) return fail(SFM_EINVAL, "sfm_ransac_pass_large: negative h_begin");
@@ -1094,6 +1095,7 @@ int sfm_ransac_pass_large(uint64_t seed, const uint64_t* seed_dev, int use_philo
         return fail(SFM_EINVAL, "sfm_ransac_pass_large: unknown aggregation");
     if (!corr || !S || !E || !flags || !cnt || !s1 || !s2 || !result || !workspace)
         return fail(SFM_EINVAL, "sfm_ransac_pass_large: null pointer");
+    if (!sfmhost::score_options_valid(options)) return fail(SFM_EINVAL, "sfm_ransac_pass_large: an option is out of range");
     if (workspace_bytes < sfm_score_workspace_bytes(n, h_count, 1))
         return fail(SFM_EINVAL, "sfm_ransac_pass_large: workspace smaller than sfm_score_workspace_bytes(n, h_count, 1)");
     if ((reinterpret_cast<uintptr_t>(workspace) & 15u) != 0)
@@ -1116,7 +1118,7 @@ int sfm_ransac_pass_large(uint64_t seed, const uint64_t* seed_dev, int use_philo
     // (without room for the selection state the scoring call folds its ranges itself — folded_later = NULL —: the separate
     // selection below reads cnt / s1 / s2.  Round 4 deferred the fold in that case too, and selected from unfolded partials.)
     rc = sfmhost::launch_large_score(sfmhost::LargePass{corr, n, E, S, h_count, thr, cnt, s1, s2, ws, workspace_bytes,
-                                                         state_fits ? reinterpret_cast<unsigned*>(state) : nullptr, st},
+                                                         state_fits ? reinterpret_cast<unsigned*>(state) : nullptr, st, options},
                                      state_fits ? &folded_later : nullptr);
     if (rc != SFM_OK) return rc;
     if (!state_fits) {   // a few hundred hypotheses: the separate selection and mask launches

@@ -973,11 +973,8 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
 #endif
 }
 
-// Optional HIP events recorded on the launch stream immediately before / after the dominant kernel of the next
-// sfm_score_sed calls of this thread (bench.py brackets exactly the scoring kernel with them, without the pre-pass).
-thread_local hipEvent_t g_event_before = nullptr;
-thread_local hipEvent_t g_event_after = nullptr;
-
+// (The HIP events a benchmark brackets exactly the scoring kernel with travel in the call's sfm_score_options — timing_before /
+// timing_after — since ABI 11; until then they were thread-local state set by sfm_score_set_timing_events.)
 struct FilteredLaunch {
     const Corr* corr;
     unsigned char* ws;
@@ -1001,6 +998,7 @@ struct FilteredLaunch {
     bool persistent = true;       // matrix-pipe kernel, single pair: persistent waves (options.persistent)
     unsigned* select_state = nullptr;          // fused pass: state words of its selection launch, zeroed with everything else
     sfmhost::LargeScore* deferred = nullptr;   // fused pass: leave the ranges' partials to the selection launch, report them here
+    hipEvent_t event_before = nullptr, event_after = nullptr;   // options.timing_before / _after: recorded around the scoring kernel
 };
 
 template <int HPW>
@@ -1035,7 +1033,7 @@ int launch_filtered(const FilteredLaunch& a) {
         flat = dim3(grid.x * (unsigned)a.units);   // (sfm_score_sed checked that this grid fits one launch)
         split = a.ws + ws_split_offset(a.n, a.h_count);
     }
-    if (g_event_before) (void)hipEventRecord(g_event_before, a.st);
+    if (a.event_before) (void)hipEventRecord(a.event_before, a.st);
     if (a.one_sided)
         hipLaunchKernelGGL((score_sed_filtered_kernel<HPW, true>), flat, dim3(256), 0, a.st, a.corr, a.ws, a.n, a.E, a.S,
                            a.h_count, a.thr, a.a_scale, order_arg, a.cnt, a.s1, a.s2, (int)a.batch, blocks_per_pair, 0, 0,
@@ -1044,7 +1042,7 @@ int launch_filtered(const FilteredLaunch& a) {
         hipLaunchKernelGGL((score_sed_filtered_kernel<HPW, false>), flat, dim3(256), 0, a.st, a.corr, a.ws, a.n, a.E, a.S,
                            a.h_count, a.thr, a.a_scale, order_arg, a.cnt, a.s1, a.s2, (int)a.batch, blocks_per_pair, 0, 0,
                            a.units, a.chunks_per_unit, split);
-    if (g_event_after) (void)hipEventRecord(g_event_after, a.st);
+    if (a.event_after) (void)hipEventRecord(a.event_after, a.st);
     if (a.units > 1)
         hipLaunchKernelGGL(matrixscore::matrix_fold_kernel, dim3(grid_stride(a.h_count, 256, 1024), 1), dim3(256), 0, a.st, split,
                            (const unsigned char*)nullptr, a.units, a.h_count, a.cnt, a.s1, a.s2);
@@ -1158,7 +1156,11 @@ int launch_matrix(const FilteredLaunch& a) {
         const int e_steps = estimate_steps(a.n);
         // a single pair: four ranges of the pre-pass's steps — or, recording, the first steps of each of the scoring launch's ranges
         // (a single pair: half as many units in the launch, each wave takes two of the ranges; a batch: one unit, all ranges — see the kernel)
-        const int e_units = record != nullptr ? (a.batch == 1 ? a.units / 2 : 1) : (a.batch == 1 && e_steps >= 128 ? 4 : 1);
+#ifndef SFM_MATRIX_RECORD_RANGES_PER_WAVE
+#define SFM_MATRIX_RECORD_RANGES_PER_WAVE 2   // recording pre-pass, single pair: ranges of the scoring launch one wave scans (1, 2, 4 or 8 of the 8)
+#endif
+        const int e_units = record != nullptr ? (a.batch == 1 ? std::max(1, a.units / SFM_MATRIX_RECORD_RANGES_PER_WAVE) : 1)
+                                              : (a.batch == 1 && e_steps >= 128 ? 4 : 1);
         if ((e_units > 1 || record != nullptr) && !fused_setup)   // (the ranges of the pre-pass add into `cnt`: zeroed by matrix_setup_kernel otherwise)
             hipLaunchKernelGGL(score_split_reset_kernel, dim3(grid_stride((int64_t)a.h_count * a.batch, 256, 1024)), dim3(256), 0, a.st,
                                a.cnt, (int64_t)a.h_count * a.batch);
@@ -1176,13 +1178,13 @@ int launch_matrix(const FilteredLaunch& a) {
     }
     unsigned char* split = nullptr;   // partials of the ranges: [range][hypothesis], folded by matrix_fold_kernel behind the launch
     if (a.units > 1) split = a.ws + (a.batch > 1 ? ws_batch_split_offset(a.n, a.h_count, a.batch) : ws_split_offset(a.n, a.h_count));
-    if (g_event_before) (void)hipEventRecord(g_event_before, a.st);
+    if (a.event_before) (void)hipEventRecord(a.event_before, a.st);
     const int64_t item_blocks = (int64_t)flat * a.units;
     const unsigned grid_blocks = persistent ? (unsigned)std::min<int64_t>(item_blocks, resident_blocks) : (unsigned)item_blocks;
     hipLaunchKernelGGL(score_sed_matrix_kernel<false>, dim3(grid_blocks), dim3(256), 0, a.st, a.corr, hyp_table, table, a.n,
                        a.E, a.h_count, a.thr, order_arg, a.cnt, a.s1, a.s2, a.units, a.chunks_per_unit, split, fix,
                        (int)a.batch, blocks_per_pair * a.units, persistent ? a.buckets + kTicketWords : (int32_t*)nullptr, record, 0, 0);
-    if (g_event_after) (void)hipEventRecord(g_event_after, a.st);
+    if (a.event_after) (void)hipEventRecord(a.event_after, a.st);
     if (a.deferred != nullptr) {   // a fused pass folds the ranges inside its selection launch
         *a.deferred = sfmhost::LargeScore{a.units, split, fix};
     } else if (a.units > 1) {
@@ -1196,6 +1198,8 @@ int launch_matrix(const FilteredLaunch& a) {
 
 namespace sfmhost {
 
+bool score_options_valid(const sfm_score_options* options) { return options == nullptr || valid_options(*options); }
+
 double small_pass_a_scale(double thr) { return one_sided_scale(thr); }
 
 int32_t* small_pass_order(unsigned char* workspace, int64_t n, int64_t h_count) {
@@ -1208,7 +1212,7 @@ int launch_small_score(const SmallPass& p) {
     // hypotheses per wave: at most 32768 hypotheses are a few generations of waves at best, where two per wave (7
     // waves per SIMD) beat four (5 per SIMD; measured at 20 000 and 30 000 hypotheses: 80 vs 85 and 186 vs 198 us per
     // pass) and one per wave wins as long as two would leave the chip short of waves (profiles/r02/small_pass_hpw.log)
-    const sfm_score_options opt = resolve_options(nullptr);   // a small pass runs with the process-wide defaults
+    const sfm_score_options opt = resolve_options(p.options);   // (NULL: the process-wide defaults)
     int hpw = (p.h_count + 1) / 2 >= 5120 ? 2 : 1;
     if (opt.hyps_per_wave != 0) hpw = opt.hyps_per_wave;
     const int64_t waves = (p.h_count + hpw - 1) / hpw;
@@ -1220,7 +1224,7 @@ int launch_small_score(const SmallPass& p) {
     // measured (profiles/r03/small_pass/block_barrier.log): every 1..4 iterations alike, -2 % at 5000 x 10000, -5 % at 7000..8000
     // points (L1 -> L2 requests -41 %), nothing below ~4000 points; options.block_sync overrides
     const int sync_every = opt.block_sync >= 0 ? opt.block_sync : (hpw == 1 && p.n >= 4096 ? 2 : 0);
-    if (g_event_before) (void)hipEventRecord(g_event_before, p.stream);
+    if (opt.timing_before) (void)hipEventRecord((hipEvent_t)opt.timing_before, p.stream);
 #define SFM_LAUNCH_FUSED(H)                                                                                          \
     hipLaunchKernelGGL((score_sed_filtered_kernel<H, true, true>), grid, dim3(256), 0, p.stream, (const Corr*)p.corr, \
                        p.workspace, (int)p.n, p.E, p.S, (int)p.h_count, p.thr, one_sided_scale(p.thr),               \
@@ -1232,7 +1236,7 @@ int launch_small_score(const SmallPass& p) {
         default: SFM_LAUNCH_FUSED(4); break;
     }
 #undef SFM_LAUNCH_FUSED
-    if (g_event_after) (void)hipEventRecord(g_event_after, p.stream);
+    if (opt.timing_after) (void)hipEventRecord((hipEvent_t)opt.timing_after, p.stream);
     return check_launch("score_sed_filtered_kernel (fused small pass)");
 }
 
@@ -1287,7 +1291,9 @@ int sfm_score_set_default_options(const sfm_score_options* options) {
     if (options && !valid_options(*options)) return fail(SFM_EINVAL, "sfm_score_set_default_options: a field is out of range");
     // (earlier sets stay allocated: a call that loaded the pointer just before may still be reading one; they are 32 bytes each
     // and set once per process in practice)
-    const sfm_score_options* next = options ? new sfm_score_options(*options) : &kBuiltinOptions;
+    sfm_score_options* copy = options ? new sfm_score_options(*options) : nullptr;
+    if (copy) copy->timing_before = copy->timing_after = nullptr;   // events belong to one call, never to the defaults
+    const sfm_score_options* next = copy ? copy : &kBuiltinOptions;
     g_default_options.store(next, std::memory_order_release);
     return SFM_OK;
 }
@@ -1327,12 +1333,6 @@ int sfm_debug_matrix_filter(const double* corr, int64_t n, const double* E, int6
     return check_launch("matrix_filter_dump_kernel");
 }
 
-int sfm_score_set_timing_events(void* before, void* after) {
-    g_event_before = (hipEvent_t)before;
-    g_event_after = (hipEvent_t)after;
-    return SFM_OK;
-}
-
 int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t* S, int64_t h_count,
                   int64_t batch, double thr, int32_t* cnt, double* s1, double* s2, void* workspace,
                   int64_t workspace_bytes, void* stream) {
@@ -1364,10 +1364,10 @@ int score_sed_impl(const double* corr, int64_t n, const double* E, const int32_t
     SFM_REQUIRE_GRID("sfm_score_sed", waves, 256 / kWave, 256, batch);
     const dim3 grid(grid_for(waves, 256 / kWave), (unsigned)batch);
     if (workspace == nullptr) {
-        if (g_event_before) (void)hipEventRecord(g_event_before, st);
+        if (opt.timing_before) (void)hipEventRecord((hipEvent_t)opt.timing_before, st);
         hipLaunchKernelGGL(score_sed_exact_kernel<kHypPerWave>, grid, dim3(256), 0, st, (const Corr*)corr, (int)n,
                            E, S, (int)h_count, thr, cnt, s1, s2);
-        if (g_event_after) (void)hipEventRecord(g_event_after, st);
+        if (opt.timing_after) (void)hipEventRecord((hipEvent_t)opt.timing_after, st);
         return check_launch("score_sed_exact_kernel");
     }
     if (workspace_bytes < sfm_score_workspace_bytes(n, h_count, batch))
@@ -1469,7 +1469,8 @@ int score_sed_impl(const double* corr, int64_t n, const double* E, const int32_t
         }
         const FilteredLaunch margs{(const Corr*)corr, ws, (int)n, E, S, (int)h_count, thr, order_env != 0 && h_count > (batch > 1 ? 64 : 2047), cnt, s1, s2,
                                    buckets, order, batch, st, true, a_scale, m_units, steps_per_unit, true, opt.persistent > 0,
-                                   fused_setup ? select_state : nullptr, fused_setup ? deferred : nullptr};
+                                   fused_setup ? select_state : nullptr, fused_setup ? deferred : nullptr,
+                                   (hipEvent_t)opt.timing_before, (hipEvent_t)opt.timing_after};
         if (select_state != nullptr && !fused_setup)
             hipLaunchKernelGGL(score_split_reset_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<int32_t*>(select_state), (int64_t)16);
         return launch_matrix(margs);
@@ -1477,7 +1478,8 @@ int score_sed_impl(const double* corr, int64_t n, const double* E, const int32_t
     if (select_state != nullptr)
         hipLaunchKernelGGL(score_split_reset_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<int32_t*>(select_state), (int64_t)16);
     const FilteredLaunch args{(const Corr*)corr, ws, (int)n, E, S, (int)h_count, thr, use_order, cnt, s1, s2,
-                              buckets, order, batch, st, one_sided, a_scale, units, chunks_per_unit, opt.xcd_map != 0};
+                              buckets, order, batch, st, one_sided, a_scale, units, chunks_per_unit, opt.xcd_map != 0, true, nullptr,
+                              nullptr, (hipEvent_t)opt.timing_before, (hipEvent_t)opt.timing_after};
     switch (hpw) {
         case 1: return launch_filtered<1>(args);
         case 2: return launch_filtered<2>(args);
@@ -1492,7 +1494,8 @@ namespace sfmhost {
 int launch_large_score(const LargePass& p, LargeScore* folded_later) {
     if (folded_later != nullptr)   // (NULL: the scoring launches fold their ranges themselves)
         *folded_later = LargeScore{1, nullptr, nullptr};   // (stays so unless the matrix-pipe kernel split the points into ranges)
-    const sfm_score_options opt = resolve_options(nullptr);
+    const sfm_score_options opt = resolve_options(p.options);
+    if (!valid_options(opt)) return fail(SFM_EINVAL, "sfm_ransac_pass_large: an option is out of range");
     if (p.h_count < 1 || p.n < 8 || p.n > 0x7FFFFFFF || p.h_count > 0x3FFFFFFF)
         return fail(SFM_EINVAL, "sfm_ransac_pass_large: sizes out of range");
     return score_sed_impl(p.corr, p.n, p.E, p.S, p.h_count, 1, p.thr, p.cnt, p.s1, p.s2, p.workspace, p.workspace_bytes, p.stream, opt,

@@ -128,6 +128,10 @@ constexpr int kPops = SFM_MATRIX_POPS;
 #endif
 static_assert(SFM_MATRIX_AHEAD >= 1 && kHigh + SFM_MATRIX_AHEAD <= kCap, "a group of kAhead + 1 steps must fit behind kHigh - 1 entries");
 constexpr int kAhead = SFM_MATRIX_AHEAD;   // steps of operand loads in flight behind the one being processed (register stages: kAhead + 1)
+#ifndef SFM_MATRIX_ESTIMATE_AHEAD
+#define SFM_MATRIX_ESTIMATE_AHEAD 1   // the same for the cost pre-pass (tier 1 alone: no exact tier competes for its registers); 1 or 3
+#endif
+static_assert(SFM_MATRIX_ESTIMATE_AHEAD == 1 || SFM_MATRIX_ESTIMATE_AHEAD == 3, "the recording pre-pass packs steps in pairs; the table is padded to four steps");
 #ifndef SFM_MATRIX_BUFFER_LOADS
 #define SFM_MATRIX_BUFFER_LOADS 1   // operand refills of the step loop as buffer loads (0: global loads with a 64-bit vector add per step)
 #endif
@@ -712,7 +716,7 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
 
     unsigned survivors = 0;   // ESTIMATE
     unsigned rec[4] = {0u, 0u, 0u, 0u}, rec_low = 0u;   // ESTIMATE, recording: the reject words of the last eight steps
-    static_assert(kAhead + 1 == 2 || !SFM_MATRIX_REPLAY, "the recording pre-pass packs the two steps of a loop group into one dword");
+    static_assert((kAhead + 1) % 2 == 0 || !SFM_MATRIX_REPLAY, "the recording pre-pass packs the steps of a loop group two to a dword");
     const int first_step = step_begin + (replaying ? kReplaySteps : 0);   // (the host replays only when every range has that many steps)
     if (step_begin < step_end) {
         const uint4* __restrict__ src = table + lane;
@@ -726,7 +730,7 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
         // step, and a copy out of a register a load is still writing makes the wave wait for ALL its loads (s_waitcnt
         // vmcnt(0) at the top of every step), i.e. the loop ran one memory latency per step whatever the depth — tier 1 of a
         // light wave took ~450 cycles per step and SIMD against ~220 of issue for that reason.
-        constexpr int kStages = kAhead + 1;
+        constexpr int kStages = (ESTIMATE ? SFM_MATRIX_ESTIMATE_AHEAD : kAhead) + 1;
         uint4 A[kStages][kBlocks];
         // (the first fill in stage order, oldest first, like every refill: the wait in front of stage 0 at the loop's head is ONE
         // instruction for the entry and the back edge — entered with stage 0's loads as the youngest it would be vmcnt(0) forever)

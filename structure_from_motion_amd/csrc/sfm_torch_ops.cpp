@@ -246,7 +246,7 @@ std::tuple<Tensor, Tensor, Tensor> score_sed_meta(const Tensor& corr, const Tens
 // ---- fused small pass (two launches: fit + workspace preparation, scoring + selection + mask) -------------------
 using PassEntry = int (*)(uint64_t, const uint64_t*, int, int64_t, const double*, int64_t, int64_t, double, double, int, int64_t,
                           int32_t*, double*, int32_t*, int32_t*, double*, double*, sfm_select_result*, uint8_t*, void*, int64_t,
-                          void*);
+                          void*, const sfm_score_options*);
 template <PassEntry ENTRY>
 void ransac_pass_out(const char* name, const Tensor& corr, int64_t seed, const std::optional<Tensor>& seed_dev, bool use_philox,
                      int64_t h_begin, double thr, double min_extra, int64_t aggregation, int64_t h_offset,
@@ -275,7 +275,7 @@ void ransac_pass_out(const char* name, const Tensor& corr, int64_t seed, const s
              h_begin, ptr<double>(corr), d.n, d.h, thr, min_extra, (int)aggregation, h_offset,
              ptr<int32_t>(S), ptr<double>(E), ptr<int32_t>(flags), ptr<int32_t>(cnt), ptr<double>(s1),
              ptr<double>(s2), reinterpret_cast<sfm_select_result*>(ptr<int64_t>(result)),
-             ptr<uint8_t>(mask), ptr<unsigned char>(workspace), workspace.numel(), current_stream()),
+             ptr<uint8_t>(mask), ptr<unsigned char>(workspace), workspace.numel(), current_stream(), nullptr),
        name);
 }
 void ransac_pass_small_out(const Tensor& corr, int64_t seed, const std::optional<Tensor>& seed_dev, bool use_philox,

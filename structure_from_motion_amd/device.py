@@ -201,20 +201,22 @@ def score_sed(corr: torch.Tensor, E: torch.Tensor, S: torch.Tensor, thr: float, 
     B, N, _ = corr.shape
     H = E.shape[1]
     exact = exact_only or os.environ.get("SFM_SCORE_KERNEL", "filtered") == "exact"
-    if options is not None and not exact:
+    if options is not None:   # per-call launch options (and timing events): straight through the C ABI
         if cnt is None:
             cnt = torch.empty((B, H), dtype=torch.int32, device=corr.device)
         if s1 is None:
             s1 = torch.empty((B, H), dtype=F64, device=corr.device)
         if s2 is None:
             s2 = torch.empty((B, H), dtype=F64, device=corr.device)
-        if workspace is None:
+        if exact:
+            workspace = None   # NULL selects the all-fp64 kernel
+        elif workspace is None:
             workspace = score_workspace(N, H, B, corr.device)
         assert S.dtype == torch.int32 and corr.dtype == F64 and E.dtype == F64
         with torch.cuda.device(corr.device):
             check(_native.load().sfm_score_sed_ex(_ptr(corr), N, _ptr(E), _ptr(S), H, B, float(thr), _ptr(cnt), _ptr(s1),
-                                                  _ptr(s2), _ptr(workspace), workspace.numel(), _stream(), C.byref(options)),
-                  "sfm_score_sed_ex")
+                                                  _ptr(s2), _ptr(workspace), workspace.numel() if workspace is not None else 0,
+                                                  _stream(), C.byref(options)), "sfm_score_sed_ex")
         return cnt, s1, s2
     if cnt is None and s1 is None and s2 is None and (exact or workspace is None):
         return op.score_sed(corr, E, S, float(thr), exact)
@@ -246,16 +248,6 @@ def set_default_score_options(options: Optional[ScoreOptions]) -> None:
           "sfm_score_set_default_options")
 
 
-def score_timing_events(before: Optional[torch.cuda.Event], after: Optional[torch.cuda.Event]) -> None:
-    """Have the following ``score_sed`` calls record ``before`` / ``after`` immediately around the scoring kernel
-    (``sfm_score_set_timing_events``); ``(None, None)`` switches it off.  The events must have been recorded once
-    before (torch creates the underlying hipEvent lazily)."""
-    lib = _native.load()
-    check(lib.sfm_score_set_timing_events(before.cuda_event if before is not None else None,
-                                          after.cuda_event if after is not None else None),
-          "sfm_score_set_timing_events")
-
-
 SMALL_PASS_MAX_POINTS, SMALL_PASS_MAX_HYPOTHESES = 8192, 32768
 
 
@@ -268,23 +260,40 @@ def small_pass_eligible(batch: int, n: int, h: int) -> bool:
             and os.environ.get("SFM_SCORE_KERNEL", "filtered") != "exact")
 
 
+def _pass_with_options(entry: str, corr, seed, seed_dev, use_philox, h_begin, thr, min_extra, aggregation, h_offset, S, E, flags,
+                       cnt, s1, s2, result, mask, workspace, options: ScoreOptions) -> None:
+    """A fused pass with per-call launch options (``sfm_ransac_pass_small`` / ``_large`` through the C ABI: the torch ops carry
+    no options argument and run with the process-wide defaults)."""
+    assert corr.shape[0] == 1, "one image pair per call"
+    n, h = corr.shape[1], S.shape[1]
+    with torch.cuda.device(corr.device):
+        check(getattr(_native.load(), entry)(seed & (2**64 - 1), _ptr(seed_dev), 1 if use_philox else 0, h_begin, _ptr(corr), n, h,
+                                             float(thr), float(min_extra), int(aggregation), h_offset, _ptr(S), _ptr(E),
+                                             _ptr(flags), _ptr(cnt), _ptr(s1), _ptr(s2), _ptr(result), _ptr(mask),
+                                             _ptr(workspace), workspace.numel(), _stream(), C.byref(options)), entry)
+
+
 def ransac_pass_small(corr, S, E, flags, cnt, s1, s2, result, mask, workspace, thr: float, min_extra: float,
-                      aggregation: int, h_offset: int = 0, philox=None) -> None:
+                      aggregation: int, h_offset: int = 0, philox=None, options: Optional[ScoreOptions] = None) -> None:
     """One whole pass of a small problem with lean launches (fit + workspace preparation, scoring, sharded selection, mask).
     ``philox=(seed, h_begin)``: samples drawn in the kernel (``seed`` an int or an int64 device tensor), else the
-    table already in ``S``.  Same outputs as the separate calls."""
+    table already in ``S``.  Same outputs as the separate calls.  ``options``: launch options of this call (default: the
+    process-wide set)."""
     if philox is None:
         seed, seed_dev, use_philox, h_begin = 0, None, False, 0
     else:
         seed, h_begin = philox
         on_device = isinstance(seed, torch.Tensor)
         seed, seed_dev, use_philox = (0, seed, True) if on_device else (_as_int64(seed), None, True)
+    if options is not None:
+        return _pass_with_options("sfm_ransac_pass_small", corr, seed, seed_dev, use_philox, h_begin, thr, min_extra, aggregation,
+                                  h_offset, S, E, flags, cnt, s1, s2, result, mask, workspace, options)
     ops.load().ransac_pass_small_(corr, seed, seed_dev, use_philox, h_begin, float(thr), float(min_extra),
                                   int(aggregation), h_offset, S, E, flags, cnt, s1, s2, result, mask, workspace)
 
 
 def ransac_pass_large(corr, S, E, flags, cnt, s1, s2, result, mask, workspace, thr: float, min_extra: float,
-                      aggregation: int, h_offset: int = 0, philox=None) -> None:
+                      aggregation: int, h_offset: int = 0, philox=None, options: Optional[ScoreOptions] = None) -> None:
     """One whole pass of a large problem (one pair) in eight launches instead of eighteen (``sfm_ransac_pass_large``): fit,
     partial maxima + zeroing, both operand tables, cost pre-pass, class histogram, scan + scatter, the scoring kernel, fold of
     the point ranges + selection + mask.  Arguments and outputs as ``ransac_pass_small``."""
@@ -294,6 +303,9 @@ def ransac_pass_large(corr, S, E, flags, cnt, s1, s2, result, mask, workspace, t
         seed, h_begin = philox
         on_device = isinstance(seed, torch.Tensor)
         seed, seed_dev, use_philox = (0, seed, True) if on_device else (_as_int64(seed), None, True)
+    if options is not None:
+        return _pass_with_options("sfm_ransac_pass_large", corr, seed, seed_dev, use_philox, h_begin, thr, min_extra, aggregation,
+                                  h_offset, S, E, flags, cnt, s1, s2, result, mask, workspace, options)
     ops.load().ransac_pass_large_(corr, seed, seed_dev, use_philox, h_begin, float(thr), float(min_extra),
                                   int(aggregation), h_offset, S, E, flags, cnt, s1, s2, result, mask, workspace)
 
@@ -490,28 +502,29 @@ class RansacWorkspace:
         self.score_ws = score_workspace(n, h, batch, dev)
 
     def run(self, corr: torch.Tensor, thr: float, min_extra: float, aggregation: int,
-            h_offset: int = 0, with_mask: bool = True, philox=None) -> None:
+            h_offset: int = 0, with_mask: bool = True, philox=None, options: Optional[ScoreOptions] = None) -> None:
         """fit + score + select (+ mask) for the sample table currently in ``self.S`` — or, with
         ``philox=(seed, h_begin, seed_stride)``, for Philox samples drawn inside the fit kernel (which also fills
-        ``self.S``); ``seed`` may be an int64 device tensor (read at kernel run time)."""
+        ``self.S``); ``seed`` may be an int64 device tensor (read at kernel run time).  ``options``: launch options of the
+        scoring launch of THIS pass (timing events included); default: the process-wide set."""
         if small_pass_eligible(self.batch, self.n, self.h):
             # workspace preparation rides in the fit launch, selection over 32 blocks (seed_stride only matters for batches)
             ransac_pass_small(corr, self.S, self.E, self.flags, self.cnt, self.s1, self.s2, self.result,
                               self.mask if with_mask else None, self.score_ws, thr, min_extra, aggregation, h_offset,
-                              None if philox is None else (philox[0], philox[1]))
+                              None if philox is None else (philox[0], philox[1]), options)
             return
         if large_pass_eligible(self.batch, self.n, self.h) and (not with_mask or h_offset == 0):
             # eight launches instead of eighteen: setup and tables fused, the ranges folded inside the selection launch
             ransac_pass_large(corr, self.S, self.E, self.flags, self.cnt, self.s1, self.s2, self.result,
                               self.mask if with_mask else None, self.score_ws, thr, min_extra, aggregation, h_offset,
-                              None if philox is None else (philox[0], philox[1]))
+                              None if philox is None else (philox[0], philox[1]), options)
             return
         if philox is None:
             fit_eight_point(corr, self.S, self.E, self.flags)
         else:
             seed, h_begin, seed_stride = philox
             sample_fit_philox(corr, seed, h_begin, self.S, self.E, self.flags, seed_stride)
-        score_sed(corr, self.E, self.S, thr, self.cnt, self.s1, self.s2, workspace=self.score_ws)
+        score_sed(corr, self.E, self.S, thr, self.cnt, self.s1, self.s2, workspace=self.score_ws, options=options)
         select_best(self.cnt, self.s1, self.s2, self.flags, min_extra, aggregation, h_offset,
                     self.result)
         if with_mask:

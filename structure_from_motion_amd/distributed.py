@@ -166,6 +166,7 @@ class ShardedRansac:
             self.win_flags = torch.empty((1, 1), dtype=torch.int32, device=dev)
         self.graph = None
         self.seed_dev = None
+        self.score_options = None   # launch options of the local pass' scoring launch (device.ScoreOptions; None: process defaults)
 
     def _local_pass(self, seed) -> None:
         """sample -> fit -> score -> select on this rank's shard (+ mask when the winner is local).
@@ -174,10 +175,10 @@ class ShardedRansac:
         if not self.exchange:
             # single GPU: the winner is local — mask straight from the shard's own E / S
             self.ws.run(self.corr, self.thr, self.min_extra, self.aggregation, h_offset=0, with_mask=True,
-                        philox=source)
+                        philox=source, options=self.score_options)
         else:
             self.ws.run(self.corr, self.thr, self.min_extra, self.aggregation, h_offset=self.h_begin,
-                        with_mask=False, philox=source)
+                        with_mask=False, philox=source, options=self.score_options)
 
     def capture(self) -> None:
         """Record the local pass once into a HIP graph; later ``step`` calls rewrite one seed word in device

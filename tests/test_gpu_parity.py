@@ -1469,7 +1469,7 @@ def test_matrix_kernel_beyond_two_million_points(dev):
     _assert_same_scores(exact, unsplit)
     _, persistent = _score_both(dev, corr, E, S, 1.5e-6, _options(kernel="matrix", split=0, persistent=1))
     _assert_same_scores(exact, persistent)
-    assert exact[0].max() > 1_000_000     # the fitted scene: the best hypotheses keep most of the 70 % inliers
+    assert exact[0].max() > 500_000       # the fitted scene: the best hypotheses keep a large share of the 70 % inliers
 
 
 def test_score_kernel_size_rule_picks_the_matrix_kernel(dev):

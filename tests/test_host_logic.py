@@ -77,7 +77,7 @@ def test_score_options_are_set_by_the_caller_not_read_from_the_environment(nativ
     from structure_from_motion_amd import _native
 
     from_env = _native.score_options_from_env
-    fields = [f[0] for f in _native.ScoreOptions._fields_]
+    fields = [f[0] for f in _native.ScoreOptions._fields_ if not f[0].startswith("timing_")]
 
     def values(o):
         return [getattr(o, f) for f in fields]
@@ -87,16 +87,23 @@ def test_score_options_are_set_by_the_caller_not_read_from_the_environment(nativ
            "SFM_SCORE_ONE_SIDED": "0", "SFM_SCORE_XCD": "0", "SFM_SCORE_SYNC": "4", "SFM_SCORE_PERSISTENT": "0"}
     assert values(from_env(env)) == [2, 2, 3, 0, 0, 0, 4, 0]
     assert values(from_env({"SFM_SCORE_MATRIX": "0", "SFM_SCORE_HPW": "3", "SFM_SCORE_SPLIT": "x"})) == [1, 0, -1, -1, -1, -1, -1, -1]
-    assert C.sizeof(_native.ScoreOptions) == 32
+    assert C.sizeof(_native.ScoreOptions) == 48   # eight int32 + the call's two timing events (ABI 11)
+    # the timing events belong to ONE call: they are never part of the process-wide defaults
+    timed = _native.ScoreOptions(kernel="filtered", timing=(0x1234, 0x5678))
+    assert (timed.timing_before, timed.timing_after) == (0x1234, 0x5678)
+    assert timed.with_timing(None, None).timing_before is None and timed.with_timing(None, None).kernel == 1
     before = _native.ScoreOptions()
     assert native_lib.sfm_score_get_default_options(C.byref(before)) == 0
     try:
         monkeypatch.setenv("SFM_SCORE_MATRIX", "0")                      # ignored: the library does not look
         if before.kernel == 0:
             assert native_lib.sfm_score_kernel_choice(50_000, 100_000, 1) == 2
-        forced = _native.ScoreOptions(kernel="filtered")
+        forced = _native.ScoreOptions(kernel="filtered", timing=(0x1234, 0x5678))
         assert native_lib.sfm_score_set_default_options(C.byref(forced)) == 0
         assert native_lib.sfm_score_kernel_choice(50_000, 100_000, 1) == 1
+        stored = _native.ScoreOptions()
+        native_lib.sfm_score_get_default_options(C.byref(stored))
+        assert stored.kernel == 1 and stored.timing_before is None and stored.timing_after is None   # cleared on the way in
         assert native_lib.sfm_score_kernel_choice_ex(50_000, 100_000, 1, C.byref(_native.ScoreOptions())) == 2   # per call wins
         bad = _native.ScoreOptions(split=-5)
         assert native_lib.sfm_score_set_default_options(C.byref(bad)) == -1

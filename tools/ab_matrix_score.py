@@ -1,5 +1,6 @@
-"""Diagnostic: the scoring call of the bench workload with whatever SFM_SCORE_MATRIX / SFM_SCORE_SPLIT say (the library reads
-them once per process: run it once per setting), checked against the all-fp64 kernel: counts bit-equal, sums to 1e-12."""
+"""Diagnostic: the scoring call of the bench workload (N, H, THR from the environment) under the launch options the SFM_SCORE_*
+variables spell (translated once, when the library is loaded: run it once per setting), checked against the all-fp64 kernel:
+counts bit-equal, sums to 1e-12; kernel time by HIP events carried in the call's options (sfm_score_options.timing_*)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -15,9 +16,9 @@ ref = dev.score_sed(corr, E, S, thr, exact_only=True)
 out = [torch.empty((1, h), dtype=torch.int32, device="cuda"), torch.empty((1, h), dtype=torch.float64, device="cuda"), torch.empty((1, h), dtype=torch.float64, device="cuda")]
 before, after = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 before.record(); after.record(); torch.cuda.synchronize()
-dev.score_timing_events(before, after)
+timed = dev.default_score_options().with_timing(before, after)
 for _ in range(2):
-    dev.score_sed(corr, E, S, thr, *out, workspace=ws)
+    dev.score_sed(corr, E, S, thr, *out, workspace=ws, options=timed)
 torch.cuda.synchronize()
 bad = int((out[0] != ref[0]).sum().item())
 ok = torch.isfinite(ref[1])
@@ -32,7 +33,7 @@ kernel, call = [], []
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for _ in range(int(os.environ.get("REPS", 10))):
     a.record()
-    dev.score_sed(corr, E, S, thr, *out, workspace=ws)
+    dev.score_sed(corr, E, S, thr, *out, workspace=ws, options=timed)
     b.record()
     torch.cuda.synchronize()
     kernel.append(before.elapsed_time(after))

@@ -1,4 +1,5 @@
-"""Diagnostic (needs a build with -DSFM_MATRIX_STAMPS=1): where a wave of the matrix-pipe scoring kernel spends its time —
+"""Diagnostic (needs a build with -DSFM_MATRIX_STAMPS=1 — e.g. `python tools/ab.py prepare stamps --flags=-DSFM_MATRIX_STAMPS=1`
+and PYTHONPATH=tools/tmp/trees/stamps): where a wave of the matrix-pipe scoring kernel spends its time —
 s_memrealtime stamps (100 MHz: 10 ns ticks) at wave start, operands loaded, step loop done, queues drained, sample points
 fixed, results handed off — and how the waves are spread over time and over the chip.  N, H, THR, SFM_SCORE_SPLIT from the
 environment."""
@@ -9,7 +10,9 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get("SFM_TREE"):   # a tree prepared by tools/ab.py
+    sys.path.insert(0, os.path.abspath(os.environ["SFM_TREE"]))
 from structure_from_motion_amd import _native, device as dev, synthetic  # noqa: E402
 
 n, h = int(os.environ.get("N", 50000)), int(os.environ.get("H", 100000))
@@ -23,9 +26,8 @@ E, flags = dev.fit_eight_point(corr, S)
 ws = dev.score_workspace(n, h, 1, corr.device)
 before, after = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 before.record(); after.record(); torch.cuda.synchronize()
-dev.score_timing_events(before, after)
 for _ in range(3):
-    cnt, s1, s2 = dev.score_sed(corr, E, S, thr, workspace=ws)
+    cnt, s1, s2 = dev.score_sed(corr, E, S, thr, workspace=ws, options=dev.default_score_options().with_timing(before, after))
 torch.cuda.synchronize()
 kernel_ms = before.elapsed_time(after)
 st = np.zeros((65536, 10), dtype=np.uint64)
