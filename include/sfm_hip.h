@@ -218,20 +218,35 @@ int sfm_debug_matrix_filter(const double* corr, int64_t n, const double* E, int6
                             int64_t workspace_bytes, float* r_out, float* d_out, float* bound_out, void* stream);
 
 /* The same for a LARGE problem (one image pair, any n and h_count the separate calls take): sfm_sample_fit_philox /
- * sfm_fit_eight_point -> sfm_score_sed -> sfm_select_best -> sfm_inlier_mask in EIGHT launches instead of eighteen where the
+ * sfm_fit_eight_point -> sfm_score_sed -> sfm_select_best -> sfm_inlier_mask in SEVEN launches instead of eighteen where the
  * matrix-pipe scoring kernel applies, with the same outputs (S, E, flags, cnt, result, mask bit for bit; s1 / s2 bit for
  * bit too: the ranges of the scoring launch are added in the same order):
- *   1  the eight-point fits;  2  partial maxima of the points + every zeroing the pass needs;  3  both operand tables of the
- *   scoring kernel + the hypotheses' sample corrections;  4  cost pre-pass;  5  class histogram;  6  scan + scatter (the
- *   heaviest-first order);  7  the scoring kernel;  8  fold of the point ranges + selection (ransac.py:75-86) over up to 256
+ *   1  partial maxima of the points + every zeroing the pass needs;  2  the eight-point fits — every lane also writes its
+ *   hypothesis' rows of the scoring kernel's operand table and its sample correction (E and the sample are in registers there),
+ *   blocks behind the fit blocks write the point operand table;  3  cost pre-pass;  4  class histogram;  5  scan + scatter (the
+ *   heaviest-first order);  6  the scoring kernel;  7  fold of the point ranges + selection (ransac.py:75-86) over up to 256
  *   blocks + the blocks that write the winner's inlier mask.
- * Sizes for which sfm_score_sed picks another kernel run that call's launches followed by launch 8.  Arguments as for
+ * Sizes for which sfm_score_sed picks another kernel run the fit, that call's launches and launch 7.  Arguments as for
  * sfm_ransac_pass_small. */
 int sfm_ransac_pass_large(uint64_t seed, const uint64_t* seed_dev, int use_philox, int64_t h_begin, const double* corr,
                           int64_t n, int64_t h_count, double thr, double min_extra, int aggregation, int64_t h_offset,
                           int32_t* S, double* E, int32_t* flags, int32_t* cnt, double* s1, double* s2,
                           sfm_select_result* result, uint8_t* mask, void* workspace, int64_t workspace_bytes,
                           void* stream, const sfm_score_options* options);
+
+/* The same for a BATCH of independent image pairs (BASELINE configs[4]: 256 pairs x 10 000 x 2 000; every array with a leading
+ * pair dimension as in the separate calls, pair b sampling from Philox(seed + b * seed_stride, h_begin + h)): where the batch takes
+ * the matrix-pipe scoring kernel (sfm_score_kernel_choice(n, h_count, batch)) —
+ *   1  partial maxima of every pair's points + every zeroing;  2  the pairs' point operand tables;  3  the eight-point fits,
+ *   whose lanes also write their hypothesis' operand rows and sample correction;  4  cost pre-pass;  5  class histogram;
+ *   6  scan + scatter;  7  the scoring kernel;  8  per pair one block: fold of the point ranges + selection + inlier mask
+ * — instead of the fifteen launches of sfm_sample_fit_philox -> sfm_score_sed -> sfm_select_best -> sfm_inlier_mask, with the same
+ * outputs bit for bit.  Other sizes: the fit, that scoring call's own launches, and launch 8.  result: dev [batch]; mask: dev
+ * uint8 [batch, n] or NULL. */
+int sfm_ransac_pass_batch(uint64_t seed, const uint64_t* seed_dev, uint64_t seed_stride, int use_philox, int64_t h_begin,
+                          const double* corr, int64_t n, int64_t h_count, int64_t batch, double thr, double min_extra, int aggregation,
+                          int32_t* S, double* E, int32_t* flags, int32_t* cnt, double* s1, double* s2, sfm_select_result* result,
+                          uint8_t* mask, void* workspace, int64_t workspace_bytes, void* stream, const sfm_score_options* options);
 
 /* Model selection (ransac.py:75-86): lowest aggregated error among hypotheses with
  * cnt >= min_extra, strict <, earliest index wins, NaN/inf never win.  result: dev [batch]. */

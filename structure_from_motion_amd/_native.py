@@ -128,6 +128,8 @@ SIGNATURES = {
                               _P, _P, _P, _I64, _P, _P],
     "sfm_ransac_pass_large": [_U64, _P, C.c_int, _I64, _P, _I64, _I64, _D, _D, C.c_int, _I64, _P, _P, _P, _P, _P, _P,
                               _P, _P, _P, _I64, _P, _P],
+    "sfm_ransac_pass_batch": [_U64, _P, _U64, C.c_int, _I64, _P, _I64, _I64, _I64, _D, _D, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                              _I64, _P, _P],
     "sfm_select_best": [_P, _P, _P, _P, _I64, _I64, _D, C.c_int, _I64, _P, _P],
     "sfm_fold_select_records": [_P, _I64, _I64, _P, _P, _P, _P],
     "sfm_fold_select_records_host": [_P, _I64, _I64, _P, _P, _P],

@@ -99,8 +99,25 @@ struct LargePass {
     unsigned* select_state;    // 16 words the scoring launches zero for the selection launch (NULL: none)
     hipStream_t stream;
     const sfm_score_options* options;   // launch options (NULL: the process-wide defaults)
+    int64_t batch = 1;          // image pairs (sfm_ransac_pass_batch; every array with a leading pair dimension)
+    bool tables_ready = false;  // launch_large_setup + the fit launch of the pass have prepared maxima, zeroing and both operand tables
 };
 int launch_large_score(const LargePass& pass, LargeScore* folded_later);
+// First launch of a fused pass whose scoring call will take the matrix-pipe kernel: per-block partial maxima of the points and
+// every zeroing the pass needs (matrix_setup_kernel).  Fills `tables` with what the fit launch of the pass needs to write both
+// operand tables and the sample corrections itself (the MatrixPrep argument of fit_eight_point_kernel); tables->matrix = false
+// (and nothing launched) where the scoring call takes another kernel.
+struct MatrixTables {
+    bool matrix;
+    const float4* partial;
+    int partials;
+    double a_scale;
+    uint4* hyp_table;
+    unsigned char* fix;
+    uint4* table;
+    int step_blocks;   // blocks of four steps that write the point table inside the fit launch (one pair); 0: a launch of its own (batches)
+};
+int launch_large_setup(const LargePass& pass, MatrixTables* tables);
 bool score_options_valid(const sfm_score_options* options);   // NULL (the process-wide defaults) is valid
 
 }  // namespace sfmhost

@@ -19,6 +19,7 @@
 #include "sfm_math.h"
 #include "sfm_fit.h"
 #include "sfm_score_ws.h"
+#include "sfm_matrix_tables.h"
 #include "sfm_select.h"
 
 namespace sfmhost {
@@ -131,18 +132,45 @@ struct SmallPrep {
     int32_t* order;   // scoring order of the pass that follows (see fit_eight_point_kernel), or NULL
 };
 
-template <bool TRACE>
+// Fused LARGE / batched pass (sfm_ransac_pass_large, sfm_ransac_pass_batch) where the matrix-pipe scoring kernel follows: the fit
+// lanes — which hold their hypothesis' E and sample in registers — also write the hypothesis' rows of that kernel's operand table
+// and its sample correction (sfm_matrix_tables.h: what matrix_tables_kernel's hypothesis half does from E and S re-read), and
+// `step_blocks` extra blocks behind the fit blocks write the point operand table, four steps each (single pair; the chip is
+// mostly idle under the fit's one wave of 256 registers per 64 hypotheses).  Both need the data-set maxima of the points:
+// every wave folds the partial maxima matrix_setup_kernel left in the launch before.  partial == NULL: plain fit.
+struct MatrixPrep {
+    const float4* partial;     // [batch][partials] partial coordinate maxima
+    int partials;
+    double a_scale, thr;
+    uint4* hyp_table;          // [batch][h_count][2][3] x 16 bytes
+    unsigned char* fix;        // [batch] x sfmws::matrix_fix_bytes(h_count)
+    uint4* table;              // point operand table of the pair (step_blocks > 0)
+    int step_blocks;
+};
+
+template <bool TRACE, bool MATRIX = false>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) void fit_eight_point_kernel(
     const Corr* __restrict__ corr, int64_t n, int32_t* __restrict__ S, int64_t h_count,
     double* __restrict__ E, int32_t* __restrict__ flags, double* __restrict__ lambda2,
-    double* __restrict__ trace, PhiloxSource philox, SmallPrep prep) {
+    double* __restrict__ trace, PhiloxSource philox, SmallPrep prep, MatrixPrep matrix) {
     const int64_t b = blockIdx.y;
     if (prep.blocks > 0 && blockIdx.x >= gridDim.x - prep.blocks) {  // block-uniform; batch == 1 in this mode
         sfmws::prepare_small_block(corr, (int)n, prep.a_scale, prep.ws, (int)(blockIdx.x - (gridDim.x - prep.blocks)));
         return;
     }
+    uint32_t maxima[4] = {0u, 0u, 0u, 0u};
+    if constexpr (MATRIX) {   // (an instantiation of its own: the plain fit keeps its register allocation)
+        matrixscore::fold_partial_maxima(matrix.partial + b * matrix.partials, matrix.partials, (int)threadIdx.x, maxima);
+        if (blockIdx.x >= gridDim.x - matrix.step_blocks) {  // block-uniform: a block of the point operand table (batch == 1)
+            const int first = (int)(blockIdx.x - (gridDim.x - matrix.step_blocks)) * 4;
+            const int steps = (int)matrixscore::table_steps(n);
+            for (int t = first; t < first + 4 && t < steps; ++t)
+                matrixscore::prepare_step(corr, (int)n, matrix.a_scale, maxima, matrix.table, t, (int)threadIdx.x);
+            return;
+        }
+    }
     const int64_t h_raw = (int64_t)blockIdx.x * kWave + threadIdx.x;
-    const bool active = h_raw < h_count;
+    const bool active = h_raw < h_count;   // (a launch with table blocks has h_count covered by the blocks in front of them)
     // inactive tail lanes redo the last hypothesis so the wave-uniform Jacobi loops stay convergent
     const int64_t h = active ? h_raw : h_count - 1;
     const Corr* pts = corr + b * n;
@@ -251,12 +279,21 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     double e[9];
     unnormalise(fr, t1, t2, e);
     const double e22 = e[8];
+    double en[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) en[k] = e[k] / e22;
     if (active) {
         double* out = E + (b * h_count + h) * 9;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) out[k] = e[k] / e22;
+        for (int k = 0; k < 9; ++k) out[k] = en[k];
         flags[b * h_count + h] = flag;
         if (lambda2 != nullptr) lambda2[b * h_count + h] = second;
+    }
+    if constexpr (MATRIX) {
+        // this hypothesis' operand rows + sample correction, from the E just stored
+        matrixscore::prepare_hypothesis_lane(maxima, en, sample, h, (int)h_count, matrix.a_scale, matrix.thr, pts,
+                                                 matrix.hyp_table + b * h_count * 2 * matrixscore::kBlocks,
+                                             matrix.fix + b * sfmws::matrix_fix_bytes(h_count), active);
     }
 }
 
@@ -759,6 +796,52 @@ __global__ __launch_bounds__(256) void select_large_kernel(
     }
 }
 
+// Last launch of a fused BATCHED pass (sfm_ransac_pass_batch): one 1024-thread block per image pair folds the ranges of its
+// pair's scoring launch (matrix_fold_kernel's sums, bit for bit: range order, then the sample correction), selects
+// (ransac.py:75-86) and writes the winner's inlier mask — three launches of the separate calls in one, and no cross-block
+// hand-off: a pair's hypotheses (a few thousand) and points (~10 000) are one block's work.
+__global__ __launch_bounds__(kSelectBlock) void select_fold_mask_batch_kernel(
+    int32_t* __restrict__ cnt, double* __restrict__ s1, double* __restrict__ s2, const int32_t* __restrict__ flags, int64_t h_count,
+    double min_extra, int aggregation, sfm_select_result* __restrict__ result, int units, const unsigned char* __restrict__ split,
+    const unsigned char* __restrict__ fix, const Corr* __restrict__ corr, int64_t n, const double* __restrict__ E,
+    const int32_t* __restrict__ S, double thr, uint8_t* __restrict__ mask) {
+    __shared__ sfmsel::SelectScratch<kSelectBlock> scratch;
+    __shared__ int64_t winner;
+    const int64_t b = blockIdx.x;
+    cnt += b * h_count;
+    s1 += b * h_count;
+    s2 += b * h_count;
+    if (units > 1) {
+        const int64_t hp = sfmws::split_padded(h_count);
+        const unsigned char* sp = split + b * sfmws::split_bytes(h_count);
+        const unsigned char* fx = fix + b * sfmws::matrix_fix_bytes(h_count);
+        const int32_t* part_c = reinterpret_cast<const int32_t*>(sp) + hp;
+        const double* part_a1 = reinterpret_cast<const double*>(part_c + sfmws::kSplitMaxUnits * hp);
+        const double* part_a2 = part_a1 + sfmws::kSplitMaxUnits * hp;
+        const int32_t* fix_c = reinterpret_cast<const int32_t*>(fx);
+        const double* fix_a1 = reinterpret_cast<const double*>(fx + 4 * hp);
+        // (thread t folds hypotheses t, t + 1024, ... — the ones block_select has it read back below)
+        for (int64_t h = threadIdx.x; h < h_count; h += kSelectBlock) {
+            int total = part_c[h];
+            double t1 = part_a1[h], t2 = part_a2[h];
+            for (int u = 1; u < units; ++u) {
+                total += part_c[u * hp + h];
+                t1 += part_a1[u * hp + h];
+                t2 += part_a2[u * hp + h];
+            }
+            cnt[h] = total + fix_c[h];
+            s1[h] = t1 + fix_a1[h];
+            s2[h] = t2 + fix_a1[hp + h];
+        }
+        __syncthreads();
+    }
+    const int64_t best = sfmsel::block_select<kSelectBlock>(cnt, s1, s2, flags != nullptr ? flags + b * h_count : nullptr, h_count, 0,
+                                                            min_extra, aggregation, result + b, scratch, &winner);
+    if (mask != nullptr)
+        sfmsel::write_inlier_mask<4>(corr + b * n, n, E + b * h_count * 9, S + b * h_count * 8, h_count, best, thr, mask + b * n,
+                                     threadIdx.x, kSelectBlock);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Inlier mask of the winner (ransac.py:70-76): 1 = surviving non-sample point, 2 = sample point.
 // ------------------------------------------------------------------------------------------------
@@ -1010,7 +1093,7 @@ int sfm_fit_eight_point(const double* corr, int64_t n, const int32_t* S, int64_t
     SFM_REQUIRE_GRID("sfm_fit_eight_point", h_count, kWave, kWave, batch);
     hipLaunchKernelGGL(fit_eight_point_kernel<false>, dim3(grid_for(h_count, kWave), (unsigned)batch),
                        dim3(kWave), 0, (hipStream_t)stream, (const Corr*)corr, n, const_cast<int32_t*>(S), h_count, E,
-                       flags, lambda2, (double*)nullptr, PhiloxSource{nullptr, 0, 0, 0, 0}, SmallPrep{nullptr, 0.0, 0, nullptr});
+                       flags, lambda2, (double*)nullptr, PhiloxSource{nullptr, 0, 0, 0, 0}, SmallPrep{nullptr, 0.0, 0, nullptr}, MatrixPrep{nullptr, 0, 0.0, 0.0, nullptr, nullptr, nullptr, 0});
     return check_launch("fit_eight_point_kernel");
 }
 
@@ -1025,7 +1108,7 @@ int sfm_sample_fit_philox(uint64_t seed, const uint64_t* seed_dev, uint64_t seed
     hipLaunchKernelGGL(fit_eight_point_kernel<false>, dim3(grid_for(h_count, kWave), (unsigned)batch),
                        dim3(kWave), 0, (hipStream_t)stream, (const Corr*)corr, n, S, h_count, E, flags,
                        (double*)nullptr, (double*)nullptr, PhiloxSource{seed_dev, seed, seed_stride, h_begin, 1},
-                       SmallPrep{nullptr, 0.0, 0, nullptr});
+                       SmallPrep{nullptr, 0.0, 0, nullptr}, MatrixPrep{nullptr, 0, 0.0, 0.0, nullptr, nullptr, nullptr, 0});
     return check_launch("fit_eight_point_kernel (philox)");
 }
 
@@ -1056,7 +1139,8 @@ int sfm_ransac_pass_small(uint64_t seed, const uint64_t* seed_dev, int use_philo
                        (const Corr*)corr, n, S, h_count, E, flags, (double*)nullptr, (double*)nullptr,
                        PhiloxSource{seed_dev, seed, 0, h_begin, use_philox ? 1 : 0},
                        SmallPrep{static_cast<unsigned char*>(workspace), sfmhost::small_pass_a_scale(thr), prep_blocks,
-                                 sfmhost::small_pass_order(static_cast<unsigned char*>(workspace), n, h_count)});
+                                 sfmhost::small_pass_order(static_cast<unsigned char*>(workspace), n, h_count)},
+                       MatrixPrep{nullptr, 0, 0.0, 0.0, nullptr, nullptr, nullptr, 0});
     const int rc = check_launch("fit_eight_point_kernel (fused small pass)");
     if (rc != SFM_OK) return rc;
     // launch 2: SED scoring
@@ -1103,23 +1187,40 @@ int sfm_ransac_pass_large(uint64_t seed, const uint64_t* seed_dev, int use_philo
     SFM_REQUIRE_GRID("sfm_ransac_pass_large", h_count, kWave, kWave, 1);
     SFM_REQUIRE_GRID("sfm_ransac_pass_large (mask)", n, 256, 256);
     hipStream_t st = (hipStream_t)stream;
-    // launch 1: the eight-point fits (Philox samples drawn in the kernel, or the caller's table in S)
-    hipLaunchKernelGGL(fit_eight_point_kernel<false>, dim3(grid_for(h_count, kWave), 1u), dim3(kWave), 0, st, (const Corr*)corr, n, S,
-                       h_count, E, flags, (double*)nullptr, (double*)nullptr,
-                       PhiloxSource{seed_dev, seed, 0, h_begin, use_philox ? 1 : 0}, SmallPrep{nullptr, 0.0, 0, nullptr});
-    int rc = check_launch("fit_eight_point_kernel (fused large pass)");
-    if (rc != SFM_OK) return rc;
-    // launches 2 .. 7: sfm_score_sed's — partial maxima + zeroing, both operand tables, cost pre-pass, class count, scan +
-    // scatter, the scoring kernel — with the ranges' partials left unfolded
     unsigned char* ws = static_cast<unsigned char*>(workspace);
     unsigned char* state = ws + sfmws::ws_split_offset(n, h_count);   // the unused head of the range-split region
     const bool state_fits = 4 * sfmws::split_padded(h_count) >= sfmws::kFusedPartialOffset + kLargeSelectBlocks * (int64_t)sizeof(PartialSelect);
+    sfmhost::LargePass pass{corr, n, E, S, h_count, thr, cnt, s1, s2, ws, workspace_bytes,
+                            state_fits ? reinterpret_cast<unsigned*>(state) : nullptr, st, options};
+    // launch 1 (where the matrix-pipe scoring kernel will run): partial maxima of the points + every zeroing the pass needs
+    sfmhost::MatrixTables tables;
+    int rc = sfmhost::launch_large_setup(pass, &tables);
+    if (rc != SFM_OK) return rc;
+    // launch 2: the eight-point fits (Philox samples drawn in the kernel, or the caller's table in S); with the matrix-pipe
+    // kernel ahead, every fit lane also writes its hypothesis' operand rows and sample correction, and blocks behind the fit
+    // blocks the point operand table (MatrixPrep)
+    const MatrixPrep prep = tables.matrix ? MatrixPrep{tables.partial, tables.partials, tables.a_scale, thr, tables.hyp_table, tables.fix,
+                                                       tables.table, tables.step_blocks}
+                                          : MatrixPrep{nullptr, 0, 0.0, 0.0, nullptr, nullptr, nullptr, 0};
+    if (!sfmhost::grid_fits((int64_t)grid_for(h_count, kWave) + prep.step_blocks, 1, kWave))
+        return fail(SFM_EINVAL, "sfm_ransac_pass_large: size exceeds what one launch covers");
+    if (tables.matrix)
+        hipLaunchKernelGGL((fit_eight_point_kernel<false, true>), dim3(grid_for(h_count, kWave) + (unsigned)prep.step_blocks, 1u), dim3(kWave),
+                           0, st, (const Corr*)corr, n, S, h_count, E, flags, (double*)nullptr, (double*)nullptr,
+                           PhiloxSource{seed_dev, seed, 0, h_begin, use_philox ? 1 : 0}, SmallPrep{nullptr, 0.0, 0, nullptr}, prep);
+    else
+        hipLaunchKernelGGL((fit_eight_point_kernel<false, false>), dim3(grid_for(h_count, kWave), 1u), dim3(kWave), 0, st, (const Corr*)corr,
+                           n, S, h_count, E, flags, (double*)nullptr, (double*)nullptr,
+                           PhiloxSource{seed_dev, seed, 0, h_begin, use_philox ? 1 : 0}, SmallPrep{nullptr, 0.0, 0, nullptr}, prep);
+    rc = check_launch("fit_eight_point_kernel (fused large pass)");
+    if (rc != SFM_OK) return rc;
+    pass.tables_ready = tables.matrix;
+    // then sfm_score_sed's launches — cost pre-pass, class count, scan + scatter, the scoring kernel (other sizes: that call's
+    // own preparation first) — with the ranges' partials left unfolded
     sfmhost::LargeScore folded_later{1, nullptr, nullptr};
     // (without room for the selection state the scoring call folds its ranges itself — folded_later = NULL —: the separate
     // selection below reads cnt / s1 / s2.  Round 4 deferred the fold in that case too, and selected from unfolded partials.)
-    rc = sfmhost::launch_large_score(sfmhost::LargePass{corr, n, E, S, h_count, thr, cnt, s1, s2, ws, workspace_bytes,
-                                                         state_fits ? reinterpret_cast<unsigned*>(state) : nullptr, st, options},
-                                     state_fits ? &folded_later : nullptr);
+    rc = sfmhost::launch_large_score(pass, state_fits ? &folded_later : nullptr);
     if (rc != SFM_OK) return rc;
     if (!state_fits) {   // a few hundred hypotheses: the separate selection and mask launches
         rc = sfm_select_best(cnt, s1, s2, flags, h_count, 1, min_extra, aggregation, h_offset, result, stream);
@@ -1136,6 +1237,57 @@ int sfm_ransac_pass_large(uint64_t seed, const uint64_t* seed_dev, int use_philo
     return check_launch("select_large_kernel");
 }
 
+int sfm_ransac_pass_batch(uint64_t seed, const uint64_t* seed_dev, uint64_t seed_stride, int use_philox, int64_t h_begin,
+                          const double* corr, int64_t n, int64_t h_count, int64_t batch, double thr, double min_extra, int aggregation,
+                          int32_t* S, double* E, int32_t* flags, int32_t* cnt, double* s1, double* s2, sfm_select_result* result,
+                          uint8_t* mask, void* workspace, int64_t workspace_bytes, void* stream, const sfm_score_options* options) {
+    if (n < 8 || n > 0x7FFFFFFF) return fail(SFM_EINVAL, "sfm_ransac_pass_batch: need 8 <= n < 2^31");
+    if (h_count < 1 || h_count > 0x3FFFFFFF) return fail(SFM_EINVAL, "sfm_ransac_pass_batch: need 1 <= h_count < 2^30");
+    if (batch < 0 || batch > 65535) return fail(SFM_EINVAL, "sfm_ransac_pass_batch: need 0 <= batch <= 65535");
+    if (h_begin < 0) return fail(SFM_EINVAL, "sfm_ransac_pass_batch: negative h_begin");
+    if (aggregation < SFM_AGG_SUM || aggregation > SFM_AGG_RMS) return fail(SFM_EINVAL, "sfm_ransac_pass_batch: unknown aggregation");
+    if (batch == 0) return SFM_OK;
+    if (!corr || !S || !E || !flags || !cnt || !s1 || !s2 || !result || !workspace)
+        return fail(SFM_EINVAL, "sfm_ransac_pass_batch: null pointer");
+    if (!sfmhost::score_options_valid(options)) return fail(SFM_EINVAL, "sfm_ransac_pass_batch: an option is out of range");
+    if (workspace_bytes < sfm_score_workspace_bytes(n, h_count, batch))
+        return fail(SFM_EINVAL, "sfm_ransac_pass_batch: workspace smaller than sfm_score_workspace_bytes(n, h_count, batch)");
+    if ((reinterpret_cast<uintptr_t>(workspace) & 15u) != 0)
+        return fail(SFM_EINVAL, "sfm_ransac_pass_batch: workspace must be 16-byte aligned");
+    SFM_REQUIRE_GRID("sfm_ransac_pass_batch", h_count, kWave, kWave, batch);
+    hipStream_t st = (hipStream_t)stream;
+    unsigned char* ws = static_cast<unsigned char*>(workspace);
+    sfmhost::LargePass pass{corr, n, E, S, h_count, thr, cnt, s1, s2, ws, workspace_bytes, nullptr, st, options, batch};
+    // launches 1-2 (where the matrix-pipe scoring kernel will run): partial maxima + zeroing, the pairs' point operand tables
+    sfmhost::MatrixTables tables;
+    int rc = sfmhost::launch_large_setup(pass, &tables);
+    if (rc != SFM_OK) return rc;
+    // launch 3: the eight-point fits; with the matrix-pipe kernel ahead every lane also writes its hypothesis' operand rows and
+    // sample correction
+    const PhiloxSource source{seed_dev, seed, seed_stride, h_begin, use_philox ? 1 : 0};
+    const dim3 fit_grid(grid_for(h_count, kWave), (unsigned)batch);
+    if (tables.matrix)
+        hipLaunchKernelGGL((fit_eight_point_kernel<false, true>), fit_grid, dim3(kWave), 0, st, (const Corr*)corr, n, S, h_count, E, flags,
+                           (double*)nullptr, (double*)nullptr, source, SmallPrep{nullptr, 0.0, 0, nullptr},
+                           MatrixPrep{tables.partial, tables.partials, tables.a_scale, thr, tables.hyp_table, tables.fix, nullptr, 0});
+    else
+        hipLaunchKernelGGL((fit_eight_point_kernel<false, false>), fit_grid, dim3(kWave), 0, st, (const Corr*)corr, n, S, h_count, E, flags,
+                           (double*)nullptr, (double*)nullptr, source, SmallPrep{nullptr, 0.0, 0, nullptr},
+                           MatrixPrep{nullptr, 0, 0.0, 0.0, nullptr, nullptr, nullptr, 0});
+    rc = check_launch("fit_eight_point_kernel (batched pass)");
+    if (rc != SFM_OK) return rc;
+    pass.tables_ready = tables.matrix;
+    // sfm_score_sed's launches (matrix-pipe kernel: cost pre-pass, class count, scan + scatter, scoring — the ranges left unfolded)
+    sfmhost::LargeScore folded_later{1, nullptr, nullptr};
+    rc = sfmhost::launch_large_score(pass, &folded_later);
+    if (rc != SFM_OK) return rc;
+    // last launch: fold of the ranges + selection + mask, one block per pair
+    hipLaunchKernelGGL(select_fold_mask_batch_kernel, dim3((unsigned)batch), dim3(kSelectBlock), 0, st, cnt, s1, s2, (const int32_t*)flags,
+                       h_count, min_extra, aggregation, result, folded_later.units, (const unsigned char*)folded_later.split,
+                       folded_later.fix, (const Corr*)corr, n, (const double*)E, (const int32_t*)S, thr, mask);
+    return check_launch("select_fold_mask_batch_kernel");
+}
+
 int sfm_fit_trace_doubles(void) { return kTraceDoubles; }
 
 int sfm_fit_eight_point_traced(const double* corr, int64_t n, const int32_t* S, int64_t h_count, int64_t batch,
@@ -1147,7 +1299,7 @@ int sfm_fit_eight_point_traced(const double* corr, int64_t n, const int32_t* S, 
     SFM_REQUIRE_GRID("sfm_fit_eight_point_traced", h_count, kWave, kWave, batch);
     hipLaunchKernelGGL(fit_eight_point_kernel<true>, dim3(grid_for(h_count, kWave), (unsigned)batch),
                        dim3(kWave), 0, (hipStream_t)stream, (const Corr*)corr, n, const_cast<int32_t*>(S), h_count, E,
-                       flags, (double*)nullptr, trace, PhiloxSource{nullptr, 0, 0, 0, 0}, SmallPrep{nullptr, 0.0, 0, nullptr});
+                       flags, (double*)nullptr, trace, PhiloxSource{nullptr, 0, 0, 0, 0}, SmallPrep{nullptr, 0.0, 0, nullptr}, MatrixPrep{nullptr, 0, 0.0, 0.0, nullptr, nullptr, nullptr, 0});
     return check_launch("fit_eight_point_kernel<trace>");
 }
 

@@ -999,6 +999,7 @@ struct FilteredLaunch {
     unsigned* select_state = nullptr;          // fused pass: state words of its selection launch, zeroed with everything else
     sfmhost::LargeScore* deferred = nullptr;   // fused pass: leave the ranges' partials to the selection launch, report them here
     hipEvent_t event_before = nullptr, event_after = nullptr;   // options.timing_before / _after: recorded around the scoring kernel
+    bool tables_ready = false;    // fused pass: maxima, zeroing and both operand tables of the matrix-pipe kernel are there already
 };
 
 template <int HPW>
@@ -1107,22 +1108,19 @@ int launch_matrix(const FilteredLaunch& a) {
     static_assert(kBlocks * 2 * 16 == 96, "sfm_score_ws.h sizes the tables: 3 blocks");
     const uint4* hyp_table = reinterpret_cast<const uint4*>(a.ws + ws_matrix_hyp_offset(a.n, a.h_count, a.batch));
     unsigned char* fix = a.ws + ws_matrix_fix_offset(a.n, a.h_count, a.batch);   // the sample corrections, per pair
-    const bool fused_setup = a.batch == 1;
-    if (fused_setup) {
-        // partial maxima (in the workspace's fp32-point region, which this kernel does not use) + all zeroing, then both tables
-        float4* partial = reinterpret_cast<float4*>(a.ws + ws_points_offset(1));
+    // partial maxima (in the workspace's fp32-point region, which this kernel does not use: one float4 per setup block and pair) +
+    // all zeroing, then both tables — unless a fused pass has done all of that already (tables_ready: launch_large_setup in front of
+    // its fit launch, whose lanes wrote the hypotheses' rows and sample corrections; the point table by blocks of the fit launch
+    // for one pair, by a points-only launch of matrix_tables_kernel for a batch)
+    if (!a.tables_ready) {
+        float4* partial = reinterpret_cast<float4*>(a.ws + ws_points_offset(a.batch));
         const unsigned setup_blocks = grid_stride(a.n, 1024, kSetupBlocks);
-        hipLaunchKernelGGL(matrix_setup_kernel, dim3(setup_blocks), dim3(256), 0, a.st, a.corr, a.n, a.a_scale, partial, a.buckets,
+        hipLaunchKernelGGL(matrix_setup_kernel, dim3(setup_blocks, pairs), dim3(256), 0, a.st, a.corr, a.n, a.a_scale, partial, a.buckets,
                            a.cnt, a.h_count, a.select_state);
         const int step_blocks = (int)((table_steps(a.n) + 3) / 4);
-        hipLaunchKernelGGL(matrix_tables_kernel, dim3((unsigned)step_blocks + grid_for(2 * (int64_t)a.h_count, 256)), dim3(256), 0, a.st,
+        hipLaunchKernelGGL(matrix_tables_kernel, dim3((unsigned)step_blocks + grid_for(2 * (int64_t)a.h_count, 256), pairs), dim3(256), 0, a.st,
                            a.corr, a.n, a.a_scale, (const float4*)partial, (int)setup_blocks, const_cast<uint4*>(table), step_blocks, a.E,
                            a.h_count, const_cast<uint4*>(hyp_table), a.S, a.thr, fix);
-    } else {
-        hipLaunchKernelGGL(matrix_prepare_kernel, dim3((unsigned)((table_steps(a.n) + 3) / 4), pairs), dim3(256), 0, a.st, a.corr, a.n,
-                           a.a_scale, a.ws, const_cast<uint4*>(table));
-        hipLaunchKernelGGL(matrix_hypothesis_kernel, dim3(grid_for(2 * (int64_t)a.h_count, 256), pairs), dim3(256), 0, a.st, a.ws, a.E,
-                           a.h_count, a.a_scale, const_cast<uint4*>(hyp_table), (float*)nullptr, a.corr, a.n, a.S, a.thr, fix);
     }
     // a single pair: persistent waves — as many blocks as the chip holds at once, every wave takes (group of 32 hypotheses,
     // range) items from a per-XCD counter (see the kernel); the counters were zeroed with the class counters
@@ -1161,9 +1159,7 @@ int launch_matrix(const FilteredLaunch& a) {
 #endif
         const int e_units = record != nullptr ? (a.batch == 1 ? std::max(1, a.units / SFM_MATRIX_RECORD_RANGES_PER_WAVE) : 1)
                                               : (a.batch == 1 && e_steps >= 128 ? 4 : 1);
-        if ((e_units > 1 || record != nullptr) && !fused_setup)   // (the ranges of the pre-pass add into `cnt`: zeroed by matrix_setup_kernel otherwise)
-            hipLaunchKernelGGL(score_split_reset_kernel, dim3(grid_stride((int64_t)a.h_count * a.batch, 256, 1024)), dim3(256), 0, a.st,
-                               a.cnt, (int64_t)a.h_count * a.batch);
+        // (the ranges of the pre-pass add into `cnt`: zeroed by matrix_setup_kernel)
         hipLaunchKernelGGL(score_sed_matrix_kernel<true>, dim3(flat * (unsigned)e_units), dim3(256), 0, a.st, a.corr, hyp_table, table,
                            a.n, a.E, a.h_count, a.thr, (const int32_t*)nullptr, a.cnt, a.s1, a.s2, e_units,
                            record != nullptr ? kReplaySteps : e_steps / e_units,
@@ -1266,7 +1262,7 @@ extern "C" int sfm_debug_read_wave_stamps(unsigned long long* out, int64_t waves
 namespace {
 int score_sed_impl(const double* corr, int64_t n, const double* E, const int32_t* S, int64_t h_count, int64_t batch, double thr,
                    int32_t* cnt, double* s1, double* s2, void* workspace, int64_t workspace_bytes, void* stream,
-                   const sfm_score_options& opt, unsigned* select_state, sfmhost::LargeScore* deferred);
+                   const sfm_score_options& opt, unsigned* select_state, sfmhost::LargeScore* deferred, bool tables_ready = false);
 }
 
 extern "C" {
@@ -1353,7 +1349,7 @@ namespace {
 
 int score_sed_impl(const double* corr, int64_t n, const double* E, const int32_t* S, int64_t h_count, int64_t batch, double thr,
                    int32_t* cnt, double* s1, double* s2, void* workspace, int64_t workspace_bytes, void* stream,
-                   const sfm_score_options& opt, unsigned* select_state, sfmhost::LargeScore* deferred) {
+                   const sfm_score_options& opt, unsigned* select_state, sfmhost::LargeScore* deferred, bool tables_ready) {
     if (h_count < 0 || batch < 0 || n < 0) return fail(SFM_EINVAL, "sfm_score_sed: negative size");
     if (n > 0x7FFFFFFF || h_count > 0x3FFFFFFF) return fail(SFM_EINVAL, "sfm_score_sed: size too large");
     if (h_count == 0 || batch == 0) return SFM_OK;
@@ -1403,9 +1399,10 @@ int score_sed_impl(const double* corr, int64_t n, const double* E, const int32_t
     // options.one_sided = 0 switches tier 1 of the VALU filter back to the two-sided test (ablation)
     const bool one_sided = opt.one_sided != 0;
     const double a_scale = matrix ? matrixscore::scale_for(thr) : (one_sided ? one_sided_scale(thr) : 1.0);
-    // (one pair on the matrix-pipe kernel: launch_matrix prepares everything itself in two launches — partial maxima + zeroing,
-    // then both operand tables — instead of reset / prepare / point table / hypothesis table / estimate zeroing)
-    const bool fused_setup = matrix && batch == 1;
+    // (the matrix-pipe kernel: launch_matrix prepares everything itself in two launches — partial maxima + zeroing, then both
+    // operand tables — instead of reset / prepare / point table / hypothesis table / estimate zeroing; batches too since round 5:
+    // until then they went through score_prepare_kernel, which also wrote fp32 points that kernel never reads)
+    const bool fused_setup = matrix;
     if (!fused_setup) {
         if (use_order || matrix || prepare_blocks > 1)
             hipLaunchKernelGGL(score_reset_kernel, dim3((unsigned)batch), dim3(256), 0, st, ws, buckets);
@@ -1469,10 +1466,7 @@ int score_sed_impl(const double* corr, int64_t n, const double* E, const int32_t
         }
         const FilteredLaunch margs{(const Corr*)corr, ws, (int)n, E, S, (int)h_count, thr, order_env != 0 && h_count > (batch > 1 ? 64 : 2047), cnt, s1, s2,
                                    buckets, order, batch, st, true, a_scale, m_units, steps_per_unit, true, opt.persistent > 0,
-                                   fused_setup ? select_state : nullptr, fused_setup ? deferred : nullptr,
-                                   (hipEvent_t)opt.timing_before, (hipEvent_t)opt.timing_after};
-        if (select_state != nullptr && !fused_setup)
-            hipLaunchKernelGGL(score_split_reset_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<int32_t*>(select_state), (int64_t)16);
+                                   select_state, deferred, (hipEvent_t)opt.timing_before, (hipEvent_t)opt.timing_after, tables_ready};
         return launch_matrix(margs);
     }
     if (select_state != nullptr)
@@ -1498,8 +1492,37 @@ int launch_large_score(const LargePass& p, LargeScore* folded_later) {
     if (!valid_options(opt)) return fail(SFM_EINVAL, "sfm_ransac_pass_large: an option is out of range");
     if (p.h_count < 1 || p.n < 8 || p.n > 0x7FFFFFFF || p.h_count > 0x3FFFFFFF)
         return fail(SFM_EINVAL, "sfm_ransac_pass_large: sizes out of range");
-    return score_sed_impl(p.corr, p.n, p.E, p.S, p.h_count, 1, p.thr, p.cnt, p.s1, p.s2, p.workspace, p.workspace_bytes, p.stream, opt,
-                          p.select_state, folded_later);
+    return score_sed_impl(p.corr, p.n, p.E, p.S, p.h_count, p.batch, p.thr, p.cnt, p.s1, p.s2, p.workspace, p.workspace_bytes, p.stream,
+                          opt, p.select_state, folded_later, p.tables_ready);
+}
+
+int launch_large_setup(const LargePass& p, MatrixTables* t) {
+    *t = MatrixTables{false, nullptr, 0, 0.0, nullptr, nullptr, nullptr, 0};
+    const sfm_score_options opt = resolve_options(p.options);
+    if (!valid_options(opt) || p.h_count < 1 || p.batch < 1 || p.n < 8 || p.n > 0x7FFFFFFF || p.h_count > 0x3FFFFFFF)
+        return SFM_OK;   // (the scoring call reports it)
+    if (!use_matrix_kernel(p.n, p.h_count, p.batch, opt)) return SFM_OK;
+    using namespace matrixscore;
+    const unsigned setup_blocks = grid_stride(p.n, 1024, kSetupBlocks);
+    float4* partial = reinterpret_cast<float4*>(p.workspace + ws_points_offset(p.batch));
+    int32_t* buckets = reinterpret_cast<int32_t*>(p.workspace + ws_buckets_offset(p.n, p.batch));
+    t->matrix = true;
+    t->partial = partial;
+    t->partials = (int)setup_blocks;
+    t->a_scale = scale_for(p.thr);
+    t->hyp_table = reinterpret_cast<uint4*>(p.workspace + ws_matrix_hyp_offset(p.n, p.h_count, p.batch));
+    t->fix = p.workspace + ws_matrix_fix_offset(p.n, p.h_count, p.batch);
+    t->table = reinterpret_cast<uint4*>(p.workspace + ws_matrix_offset(p.n, p.h_count, p.batch));
+    t->step_blocks = p.batch == 1 ? (int)((table_steps(p.n) + 3) / 4) : 0;
+    hipLaunchKernelGGL(matrix_setup_kernel, dim3(setup_blocks, (unsigned)p.batch), dim3(256), 0, p.stream, (const Corr*)p.corr, (int)p.n,
+                       t->a_scale, partial, buckets, p.cnt, (int)p.h_count, p.select_state);
+    if (p.batch > 1) {   // the point tables of a batch: a launch of their own, four steps per 256-thread block
+        const int step_blocks = (int)((table_steps(p.n) + 3) / 4);
+        hipLaunchKernelGGL(matrix_tables_kernel, dim3((unsigned)step_blocks, (unsigned)p.batch), dim3(256), 0, p.stream, (const Corr*)p.corr,
+                           (int)p.n, t->a_scale, (const float4*)partial, (int)setup_blocks, t->table, step_blocks, (const double*)nullptr, 0,
+                           (uint4*)nullptr, (const int32_t*)nullptr, p.thr, (unsigned char*)nullptr);
+    }
+    return check_launch("matrix_setup_kernel");
 }
 
 }  // namespace sfmhost

@@ -310,6 +310,33 @@ def ransac_pass_large(corr, S, E, flags, cnt, s1, s2, result, mask, workspace, t
                                   int(aggregation), h_offset, S, E, flags, cnt, s1, s2, result, mask, workspace)
 
 
+def ransac_pass_batch(corr, S, E, flags, cnt, s1, s2, result, mask, workspace, thr: float, min_extra: float, aggregation: int,
+                      philox=None, options: Optional[ScoreOptions] = None) -> None:
+    """One whole pass of a BATCH of image pairs (``sfm_ransac_pass_batch``): corr [B,N,4], every other array with the leading
+    pair dimension.  ``philox=(seed, h_begin, seed_stride)``: pair b draws from Philox(seed + b * seed_stride) inside the fit
+    kernel (``seed`` an int or an int64 device tensor), else the tables already in ``S``.  Same outputs as the separate calls."""
+    B, N, _ = corr.shape
+    H = S.shape[1]
+    if philox is None:
+        seed, seed_dev, use_philox, h_begin, seed_stride = 0, None, False, 0, 0
+    else:
+        seed, h_begin, seed_stride = philox
+        on_device = isinstance(seed, torch.Tensor)
+        seed, seed_dev, use_philox = (0, seed, True) if on_device else (seed & (2**64 - 1), None, True)
+    with torch.cuda.device(corr.device):
+        check(_native.load().sfm_ransac_pass_batch(seed, _ptr(seed_dev), seed_stride, 1 if use_philox else 0, h_begin, _ptr(corr), N, H, B,
+                                                   float(thr), float(min_extra), int(aggregation), _ptr(S), _ptr(E), _ptr(flags),
+                                                   _ptr(cnt), _ptr(s1), _ptr(s2), _ptr(result), _ptr(mask), _ptr(workspace),
+                                                   workspace.numel(), _stream(), None if options is None else C.byref(options)),
+              "sfm_ransac_pass_batch")
+
+
+def batch_pass_eligible(batch: int) -> bool:
+    """Whether ``RansacWorkspace.run`` takes the fused batched pass (several pairs; ``SFM_LARGE_PASS=0`` keeps the separate calls)."""
+    return (batch > 1 and os.environ.get("SFM_LARGE_PASS", "1") != "0"
+            and os.environ.get("SFM_SCORE_KERNEL", "filtered") != "exact")
+
+
 def large_pass_eligible(batch: int, n: int, h: int) -> bool:
     """Whether ``RansacWorkspace.run`` takes the fused large pass: one pair whose scoring call would launch the matrix-pipe
     kernel (the size rule of ``sfm_score_kernel_choice``).  ``SFM_LARGE_PASS=0`` keeps the separate calls."""
@@ -518,6 +545,12 @@ class RansacWorkspace:
             ransac_pass_large(corr, self.S, self.E, self.flags, self.cnt, self.s1, self.s2, self.result,
                               self.mask if with_mask else None, self.score_ws, thr, min_extra, aggregation, h_offset,
                               None if philox is None else (philox[0], philox[1]), options)
+            return
+        if batch_pass_eligible(self.batch) and h_offset == 0:
+            # a batch of pairs: partial maxima + zeroing, point tables, fits (+ the hypotheses' operand rows), pre-pass, sort,
+            # scoring, and per pair one block that folds the ranges, selects and writes the mask
+            ransac_pass_batch(corr, self.S, self.E, self.flags, self.cnt, self.s1, self.s2, self.result,
+                              self.mask if with_mask else None, self.score_ws, thr, min_extra, aggregation, philox, options)
             return
         if philox is None:
             fit_eight_point(corr, self.S, self.E, self.flags)

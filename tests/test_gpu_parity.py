@@ -853,10 +853,11 @@ def test_fused_small_pass_equals_separate_calls(dev, monkeypatch, n, h, philox):
 @pytest.mark.parametrize("n,h,philox,h_offset", [(10_000, 50_000, True, 0), (9_000, 70_001, False, 0), (50_000, 20_000, True, 0),
                                                  (8_192, 65_000, True, 1_000_000), (16_384, 33_000, False, 0)])
 def test_fused_large_pass_equals_separate_calls(dev, monkeypatch, n, h, philox, h_offset):
-    """sfm_ransac_pass_large — eight launches: fit, partial maxima + zeroing, both operand tables, cost pre-pass, class
-    histogram, scan + scatter, the matrix-pipe scoring kernel, fold of the point ranges + selection over up to 256 blocks +
-    mask — against the separate calls (SFM_LARGE_PASS=0: eighteen launches) on the same inputs: samples, E, flags, counts,
-    both sums, the winner record and the mask identical bit for bit (the ranges are added in the same order)."""
+    """sfm_ransac_pass_large — seven launches: partial maxima + zeroing, the fits whose lanes also write the hypotheses' operand
+    rows and sample corrections (+ blocks that write the point table), cost pre-pass, class histogram, scan + scatter, the
+    matrix-pipe scoring kernel, fold of the point ranges + selection over up to 256 blocks + mask — against the separate calls
+    (SFM_LARGE_PASS=0: eighteen launches) on the same inputs: samples, E, flags, counts, both sums, the winner record and the
+    mask identical bit for bit (the same fit code, the same table routines, the ranges added in the same order)."""
     from structure_from_motion_amd._native import AGG_RMS, AGG_SUM
 
     _, _, _, corr = scene(n, seed=40 + n % 7)
@@ -883,6 +884,55 @@ def test_fused_large_pass_equals_separate_calls(dev, monkeypatch, n, h, philox, 
     if h_offset == 0:
         assert set(np.unique(fused["mask"]).tolist()) <= {0, 1, 2} and (fused["mask"] == 2).sum() == 8
     # ... and the counts are the all-fp64 kernel's
+    exact = dev.score_sed(corr_d, dev.to_device(fused["E"]), dev.to_device(fused["S"], torch.int32), thr, exact_only=True)
+    np.testing.assert_array_equal(exact[0].cpu().numpy(), fused["cnt"])
+
+
+@pytest.mark.parametrize("batch,n,h,kernel,philox", [(64, 10_000, 2_000, None, True), (17, 2_100, 40, "matrix", True),
+                                                     (9, 8_300, 1_100, "matrix", False), (5, 700, 70, None, True),
+                                                     (3, 4_099, 300, "filtered", False), (40, 9_000, 2_064, "matrix", True)])
+def test_fused_batch_pass_equals_separate_calls(dev, monkeypatch, batch, n, h, kernel, philox):
+    """sfm_ransac_pass_batch — partial maxima + zeroing, the pairs' point tables, the fits whose lanes also write the hypotheses'
+    operand rows and sample corrections, pre-pass, sort, scoring, one block per pair for fold + selection + mask — against the
+    separate calls (SFM_LARGE_PASS=0) on the same inputs: samples, E, flags, counts, both sums, records and masks bit for bit,
+    with the matrix-pipe kernel (by size or forced) and with the VALU-filter kernel; counts equal to the all-fp64 kernel's."""
+    from structure_from_motion_amd._native import AGG_RMS, AGG_SUM
+
+    corr = np.stack([scene(n, seed=50 + b)[3] for b in range(min(batch, 6))])
+    corr = np.ascontiguousarray(corr[np.arange(batch) % len(corr)])
+    corr_d = dev.to_device(corr)
+    thr, min_extra = 1.5e-6, 10
+    saved = dev.default_score_options()
+    outs = []
+    try:
+        if kernel is not None:
+            dev.set_default_score_options(_options(kernel=kernel))
+        from structure_from_motion_amd import _native
+        want = {None: None, "matrix": 2, "filtered": 1}[kernel]
+        if want is not None:
+            assert _native.load().sfm_score_kernel_choice(n, h, batch) == want
+        for fused in ("1", "0"):
+            monkeypatch.setenv("SFM_LARGE_PASS", fused)
+            assert dev.batch_pass_eligible(batch) == (fused == "1")
+            ws = dev.RansacWorkspace(batch, n, h)
+            ws.mask.fill_(7)
+            if philox:
+                ws.run(corr_d, thr, min_extra, AGG_RMS, philox=(9, 100, 3))
+            else:
+                ws.S.copy_(dev.sample_philox(11, 5, h, n, batch=batch, seed_stride=2))
+                ws.run(corr_d, thr, min_extra, AGG_SUM)
+            torch.cuda.synchronize()
+            outs.append({k: getattr(ws, k).cpu().numpy().copy() for k in ("S", "E", "flags", "cnt", "s1", "s2", "result", "mask")})
+    finally:
+        dev.set_default_score_options(saved)
+    fused, plain = outs
+    for key in ("S", "E", "flags", "cnt", "result", "mask"):
+        np.testing.assert_array_equal(fused[key], plain[key], err_msg=key)
+    for key in ("s1", "s2"):
+        np.testing.assert_array_equal(fused[key].view(np.int64), plain[key].view(np.int64), err_msg=key)
+    assert set(np.unique(fused["mask"]).tolist()) <= {0, 1, 2}
+    found = fused["result"][:, 1] >= 0
+    assert found.sum() >= batch // 2 and np.all((fused["mask"][found] == 2).sum(axis=1) == 8)
     exact = dev.score_sed(corr_d, dev.to_device(fused["E"]), dev.to_device(fused["S"], torch.int32), thr, exact_only=True)
     np.testing.assert_array_equal(exact[0].cpu().numpy(), fused["cnt"])
 

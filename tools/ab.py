@@ -27,6 +27,7 @@ import subprocess
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+THR = None
 TREES = os.path.join(REPO, "tools", "tmp", "trees")
 KEEP = ("structure_from_motion_amd", "include", "lib", "oracle", "apps")   # what a tree needs to be imported and built
 
@@ -73,6 +74,8 @@ def measure(tree, config, steps, options):
     cmd = [sys.executable, os.path.join(REPO, "tools", "steptime.py"), "--config", config, "--tree", tree_dir(tree), "--steps", str(steps)]
     if options:
         cmd += ["--options", options]
+    if THR is not None:
+        cmd += ["--thr", THR]
     done = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     for line in done.stdout.splitlines():
         if line.startswith("{"):
@@ -115,6 +118,8 @@ def profile(args):
            os.path.join(REPO, "tools", "steptime.py"), "--config", args.config, "--tree", tree_dir(args.tree), "--steps", str(args.steps)]
     if args.options:
         cmd += ["--options", args.options]
+    if THR is not None:
+        cmd += ["--thr", THR]
     env = dict(os.environ, TMPDIR="/tmp")
     done = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=900)
     stats = glob.glob(os.path.join(work, "**", "*kernel_stats.csv"), recursive=True)
@@ -157,5 +162,7 @@ if __name__ == "__main__":
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--options", default="")
     p.add_argument("--out", required=True)
+    ap.add_argument("--thr", default=None, help="inlier threshold passed to tools/steptime.py (1e-14: tier 1 alone)")
     a = ap.parse_args()
+    THR = a.thr
     {"prepare": prepare, "run": run, "profile": profile}[a.cmd](a)

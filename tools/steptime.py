@@ -21,6 +21,7 @@ ap.add_argument("--tree", default=None, help="root of the source tree to import 
 ap.add_argument("--steps", type=int, default=50)
 ap.add_argument("--warmup", type=int, default=5)
 ap.add_argument("--options", default="", help="process-wide scoring options, e.g. kernel=matrix,split=8,persistent=1")
+ap.add_argument("--thr", type=float, default=1.5e-6, help="inlier threshold (1e-14: nothing survives tier 1 — the filter alone)")
 args = ap.parse_args()
 root = os.path.abspath(args.tree) if args.tree else os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
@@ -31,7 +32,7 @@ import torch  # noqa: E402
 from structure_from_motion_amd import batched, device, distributed, synthetic  # noqa: E402
 from structure_from_motion_amd._native import AGG_RMS  # noqa: E402
 
-THR, MIN_EXTRA = 1.5e-6, 10
+THR, MIN_EXTRA = args.thr, 10
 device.require_gpu()
 if args.options:
     fields = {}
