@@ -133,21 +133,25 @@ SFM_DEVICE void prepare_step(const Corr* __restrict__ corr, int n, double c, con
 #pragma unroll
         for (int j = 0; j < 12; ++j) q[j] = (float)(qq[j] * (sp * sp));
     }
+    // (the slot a lane stores depends on its half: BOTH candidates are named with compile-time indices and one is selected —
+    // indexing the arrays with `8 * half + j` put them into scratch memory, 208 bytes a lane, and the kernel that writes the
+    // point tables of a batch took 190 us for 246 MB)
+    const bool upper = half != 0;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         f16x8 v;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (_Float16)point_slot_r(mh, mm, 16 * b + 8 * half + j);
+        for (int j = 0; j < 8; ++j)
+            v[j] = (_Float16)(upper ? point_slot_r(mh, mm, 16 * b + 8 + j) : point_slot_r(mh, mm, 16 * b + j));
         table[((size_t)t * kBlocks + b) * 64 + l] = __builtin_bit_cast(uint4, v);
     }
+    const float inside_sign = (i < n) ? (float)(sp * sp) : -(float)(sp * sp);   // rows past the points: always rejected (a negative "denominator")
     bf16x8 v;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int s = 8 * half + j;
-        float x = 0.0f;
-        if (s < 12) x = bf_round(q[s]);
-        else if (s == 12) x = (i < n) ? (float)(sp * sp) : -(float)(sp * sp);   // rows past the points: always rejected (a negative "denominator")
-        v[j] = (__bf16)x;
+        const float lower_x = bf_round(q[j]);                                                    // slots 0..7
+        const float upper_x = (8 + j < 12) ? bf_round(q[(8 + j < 12) ? 8 + j : 0]) : ((8 + j == 12) ? inside_sign : 0.0f);   // slots 8..15
+        v[j] = (__bf16)(upper ? upper_x : lower_x);
     }
     table[((size_t)t * kBlocks + 2) * 64 + l] = __builtin_bit_cast(uint4, v);
 }
@@ -220,18 +224,19 @@ SFM_DEVICE HypothesisRow hypothesis_row(const uint32_t* maxima, const double (&e
 SFM_DEVICE void emit_hypothesis_half(const HypothesisRow& row, int half, uint4 (&out)[kBlocks]) {
     f16x8 B0, B1;
     bf16x8 B2;
+    const bool upper = half != 0;   // (compile-time array indices, one select per slot: see prepare_step)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        B0[j] = (_Float16)(row.armed ? hyp_slot_r(row.eh, row.em, 8 * half + j) : 0.0f);
-        B1[j] = (_Float16)(row.armed ? hyp_slot_r(row.eh, row.em, 16 + 8 * half + j) : 0.0f);
+        const float b0 = upper ? hyp_slot_r(row.eh, row.em, 8 + j) : hyp_slot_r(row.eh, row.em, j);
+        const float b1 = upper ? hyp_slot_r(row.eh, row.em, 24 + j) : hyp_slot_r(row.eh, row.em, 16 + j);
+        B0[j] = (_Float16)(row.armed ? b0 : 0.0f);
+        B1[j] = (_Float16)(row.armed ? b1 : 0.0f);
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int s = 8 * half + j;
-        float x = 0.0f;
-        if (s < 12) x = row.armed ? row.gs[s] : 0.0f;
-        else if (s == 12) x = row.slot12;
-        B2[j] = (__bf16)x;
+        const float lower_x = row.armed ? row.gs[j] : 0.0f;                                                                   // slots 0..7
+        const float upper_x = (8 + j < 12) ? (row.armed ? row.gs[(8 + j < 12) ? 8 + j : 0] : 0.0f) : ((8 + j == 12) ? row.slot12 : 0.0f);   // slots 8..15
+        B2[j] = (__bf16)(upper ? upper_x : lower_x);
     }
     out[0] = __builtin_bit_cast(uint4, B0);
     out[1] = __builtin_bit_cast(uint4, B1);

@@ -18,8 +18,7 @@ using sfmhost::grid_for;
 // Cheirality test (eight_point.py:449-488) of every correspondence of every pair under its 4 candidate
 // poses.  Points whose inlier mask is 0 are reported as not passing — and cost nothing: each wave first compacts
 // the inliers of its 512-point chunk (ballot + prefix count into an LDS list), then runs the DLT solves only on
-// full 64-lane groups of inliers, all four poses per loaded point.  With the usual 30-40 % inliers that is ~3
-// passes per chunk instead of 8 per pose.
+// full 64-lane groups of inliers.  With the usual 30-40 % inliers that is ~3 passes per chunk instead of 8 per pose.
 constexpr int kChunkPoints = 512;
 
 __global__ __launch_bounds__(256) void cheirality_batched_kernel(
@@ -32,16 +31,25 @@ __global__ __launch_bounds__(256) void cheirality_batched_kernel(
     if (base >= n) return;  // whole wave; no block-level barrier below
     const uint8_t* m = mask != nullptr ? mask + b * n : nullptr;
     uint8_t* out = pass + b * 4 * n;
-    // poses are split over gridDim.z blocks (more waves in flight; the compaction is cheap enough to repeat)
-    const int poses_per_block = 4 / (int)gridDim.z;
-    const int pose_begin = (int)blockIdx.z * poses_per_block, pose_end = pose_begin + poses_per_block;
+    // The four candidates come in two antipodal pairs, (R, t) and (R, -t) (eight_point.py:210-212; sfm_decompose_essential writes
+    // them so): with P1 = [I | 0] the DLT null vector of (R, -t) is that of (R, t) with its last component negated — X' = -X —
+    // and R X' - t = -(R X + t), so both depths change sign and the norm stays: ONE solve decides both poses.  Taken only when
+    // the second pose of a pair IS the first with t negated, bit for bit (block-uniform); any other pose table is solved pose
+    // by pose.  One pair of poses per block in z (more waves in flight; the compaction is cheap enough to repeat).
+    const int pose_begin = 2 * (int)blockIdx.z;
+    const double* rt0 = pose_rt + (b * 4 + pose_begin) * 12;
+    const double* rt1 = rt0 + 12;
+    bool antipodal = true;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) antipodal = antipodal && (k < 9 ? rt1[k] == rt0[k] : rt1[k] == -rt0[k]);
     int total = 0;  // wave-uniform
     for (int s = 0; s < kChunkPoints; s += kWave) {
         const int64_t i = base + s + lane;
         const bool inside = i < n;
         const bool act = inside && (m == nullptr || m[i] != 0);
         if (inside && !act) {
-            for (int pose = pose_begin; pose < pose_end; ++pose) out[pose * n + i] = 0;
+            out[pose_begin * n + i] = 0;
+            out[(pose_begin + 1) * n + i] = 0;
         }
         const unsigned long long votes = __ballot(act);
         const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(votes >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)votes, 0));
@@ -54,8 +62,8 @@ __global__ __launch_bounds__(256) void cheirality_batched_kernel(
         // tail lanes redo the group's first point so the wave-uniform Jacobi loops see valid data
         const int64_t i = base + list[wave][active ? j + lane : j];
         const Corr p = corr[b * n + i];
-        for (int pose = pose_begin; pose < pose_end; ++pose) {
-            const double* rt = pose_rt + (b * 4 + pose) * 12;
+        for (int k = 0; k < (antipodal ? 1 : 2); ++k) {
+            const double* rt = k == 0 ? rt0 : rt1;
             double P2[12];
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
@@ -69,7 +77,11 @@ __global__ __launch_bounds__(256) void cheirality_batched_kernel(
             const double z2 = ((P2[8] * X[0] + P2[9] * X[1]) + P2[10] * X[2]) + P2[11];
             const double norm = sqrt((X[0] * X[0] + X[1] * X[1]) + X[2] * X[2]);
             const bool ok = (X[2] >= -1e-8) && (z2 >= -1e-8) && (norm <= distance_threshold);
-            if (active) out[pose * n + i] = ok ? 1 : 0;
+            if (active) out[(pose_begin + k) * n + i] = ok ? 1 : 0;
+            if (antipodal) {   // the mirrored pose: -X, -z2, the same norm (NaN fails both, as it does when solved)
+                const bool mirrored = (-X[2] >= -1e-8) && (-z2 >= -1e-8) && (norm <= distance_threshold);
+                if (active) out[(pose_begin + 1) * n + i] = mirrored ? 1 : 0;
+            }
         }
     }
 }
@@ -189,9 +201,10 @@ int sfm_cheirality_batched(const double* corr, int64_t n, int64_t batch, const d
     if (n == 0 || batch == 0) return SFM_OK;
     if (batch > 65535) return fail(SFM_EINVAL, "sfm_cheirality_batched: batch > 65535");
     if (!corr || !pose_rt || !pass) return fail(SFM_EINVAL, "sfm_cheirality_batched: null pointer");
-    // one pose per block in z: 5.08 ms per C5 batch vs 5.29 with all four poses in one wave (profiles/r01/README.md)
+    // one antipodal pair of poses per block in z (one pose per block until round 5: 5.08 ms per C5 batch vs 5.29 with all four
+    // poses in one wave, profiles/r01/README.md; the pair shares its solve now)
     SFM_REQUIRE_GRID("sfm_cheirality_batched", n, kChunkPoints * (256 / kWave), 256, batch);
-    hipLaunchKernelGGL(cheirality_batched_kernel, dim3(grid_for(n, kChunkPoints * (256 / kWave)), (unsigned)batch, 4),
+    hipLaunchKernelGGL(cheirality_batched_kernel, dim3(grid_for(n, kChunkPoints * (256 / kWave)), (unsigned)batch, 2),
                        dim3(256), 0, (hipStream_t)stream, (const Corr*)corr, n, pose_rt, mask, distance_threshold, pass);
     return check_launch("cheirality_batched_kernel");
 }

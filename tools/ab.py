@@ -134,11 +134,12 @@ def profile(args):
     print(f"{args.tree} ({describe(args.tree)}) {args.config}: per-kernel averages, {passes} passes (5 warm-up)")
     for r in rows:
         calls = int(r["Calls"])
-        if calls < args.steps:
+        name = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+        if calls < args.steps or "copyBuffer" in name:   # (copies: the uploads / read-backs around the loop, not per-pass work)
             continue
         per_pass = float(r["TotalDurationNs"]) / passes / 1e3
         total += per_pass
-        print(f"  {r['Name'].split('(')[0][-70:]:70s} {calls / passes:5.1f} x {float(r['AverageNs']) / 1e3:9.1f} us = {per_pass:9.1f} us per pass")
+        print(f"  {name[-70:]:70s} {calls / passes:5.1f} x {float(r['AverageNs']) / 1e3:9.1f} us = {per_pass:9.1f} us per pass")
     print(f"  kernels per pass: {total:.1f} us;  {[l for l in done.stdout.splitlines() if l.startswith('{')][-1:]}")
 
 
