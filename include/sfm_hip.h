@@ -129,12 +129,18 @@ int sfm_hartley_normalize(const double* coords, int64_t n, double* out, void* st
  * filter on the fp16 / bf16 matrix pipe and a lane-per-hypothesis exact tier (sfm_score_options.kernel forces it on / off).
  * Large single-pair launches are cut into ranges of the points whose partial results are added in range order.  NULL selects
  * the all-fp64 kernel.
- * Footprint: sfm_score_workspace_bytes reserves, whether or not a launch ends up using them, 16 bytes per point (fp32 points),
- * 16 KiB of counters per pair, 4 + 324 bytes per hypothesis (scoring order, the partials of up to 16 ranges) and — for pairs of at
- * most 4 194 304 points — the matrix-pipe kernel's tables: 96 bytes per point, 96 + 20 bytes per hypothesis, and for a single
- * pair 512 bytes per hypothesis of filter results that the cost pre-pass hands to the scoring launch.  50 000 x 100 000:
- * 101 MB; 256 pairs x 10 000 x 2 000: 521 MB; one pair x 1 000 000 hypotheses: 962 MB. */
-int64_t sfm_score_workspace_bytes(int64_t n, int64_t h_count, int64_t batch);
+ * Footprint (ABI 11: sized by what the call will launch; until then every region was reserved whether or not a launch could
+ * pick it): always 16 bytes per point (fp32 points of the VALU filter; the matrix-pipe kernel keeps its partial maxima there),
+ * 16 KiB of counters per pair and 4 bytes per hypothesis (scoring order); for one pair 4 more per hypothesis (state of a fused
+ * pass's selection); where the launch is cut into k ranges of the points 20 k bytes per hypothesis (their partials); where the
+ * matrix-pipe kernel runs its tables — 96 bytes per point, 96 + 20 bytes per hypothesis — and, for a single pair whose cost
+ * pre-pass hands its filter results to the scoring launch, 512 bytes per hypothesis.  50 000 x 100 000 (matrix-pipe kernel, 8
+ * ranges): 86 MB; 256 pairs x 10 000 x 2 000: 444 MB with the matrix-pipe kernel (9 ranges), 47 MB with the VALU filter
+ * (521 MB either way until ABI 10).
+ * sfm_score_workspace_bytes_ex sizes for a call made with `options` (NULL = the process-wide defaults, what the plain form
+ * uses): options that pick another kernel or more ranges than the workspace was sized for make the call return SFM_EINVAL —
+ * never a silent overrun.  -1: negative size or bad options. */
+int64_t sfm_score_workspace_bytes(int64_t n, int64_t h_count, int64_t batch);   /* (_ex: below, behind sfm_score_options) */
 int sfm_score_sed(const double* corr, int64_t n, const double* E, const int32_t* S, int64_t h_count,
                   int64_t batch, double thr, int32_t* cnt, double* s1, double* s2, void* workspace,
                   int64_t workspace_bytes, void* stream);
@@ -172,6 +178,7 @@ typedef struct sfm_score_options {
 int sfm_score_sed_ex(const double* corr, int64_t n, const double* E, const int32_t* S, int64_t h_count,
                      int64_t batch, double thr, int32_t* cnt, double* s1, double* s2, void* workspace,
                      int64_t workspace_bytes, void* stream, const sfm_score_options* options);
+int64_t sfm_score_workspace_bytes_ex(int64_t n, int64_t h_count, int64_t batch, const sfm_score_options* options);
 /* Process-wide defaults for calls without options (sfm_score_sed, sfm_ransac_pass_small / _large and sfm_score_sed_ex with
  * options == NULL); NULL restores SFM_SCORE_OPTIONS_DEFAULT.  _get copies the current set out. */
 int sfm_score_set_default_options(const sfm_score_options* options);
@@ -196,8 +203,8 @@ int sfm_score_kernel_choice_ex(int64_t n, int64_t h_count, int64_t batch, const 
  * A small pass is a chain of dependent, latency-bound launches: what shortens it is fewer and leaner ones.
  * h_offset as in sfm_select_best (the record carries global indices = local + h_offset); the mask is always the
  * winner's, whatever h_offset: the kernels index E and S with the local winner.
- * workspace: sfm_score_workspace_bytes(n, h_count, 1) bytes, 16-byte aligned.  options: launch options of the scoring launch
- * (NULL = the process-wide defaults). */
+ * workspace: sfm_score_workspace_bytes_ex(n, h_count, 1, options) bytes, 16-byte aligned.  options: launch options of the
+ * scoring launch (NULL = the process-wide defaults). */
 int sfm_ransac_pass_small(uint64_t seed, const uint64_t* seed_dev, int use_philox, int64_t h_begin, const double* corr,
                           int64_t n, int64_t h_count, double thr, double min_extra, int aggregation, int64_t h_offset,
                           int32_t* S, double* E, int32_t* flags, int32_t* cnt, double* s1, double* s2,
@@ -207,7 +214,8 @@ int sfm_ransac_pass_small(uint64_t seed, const uint64_t* seed_dev, int use_philo
 /* Diagnostic of the matrix-pipe reject filter (tests measure the margin of its error bound with it; not on the product
  * path): prepares the operand tables of one pair exactly as sfm_score_sed does and evaluates tier 1 — the three 16-bit
  * matrix instructions — for EVERY (hypothesis, point), writing the raw fp32 accumulators instead of deciding on them.
- * n <= 4 194 304.  workspace as for sfm_score_sed(n, h_count, 1).  With n_pad = 32 * ceil(n / 32):
+ * n <= 4 194 304.  workspace: sfm_score_workspace_bytes_ex(n, h_count, 1, {kernel = SFM_SCORE_KERNEL_MATRIX, split = 0}) bytes.
+ * With n_pad = 32 * ceil(n / 32):
  *   r_out  dev float [h_count, n_pad]   r'' = the scaled bilinear form c b^T E a s_p s_h as the matrix unit accumulated it
  *   d_out  dev float [h_count, n_pad]   the accumulated upper bound of (dA + dB) / 4 s_p^2 s_h^2 + slack (a point is rejected
  *                                       iff fma(-r'', r'', d) is negative); columns >= n are padding rows of zeros + slack

@@ -154,8 +154,8 @@ SIGNATURES = {
     "sfm_pyshuffle_table": [_P, _P, _I64, _I64, _P, _P, _I64, _P],
     "sfm_score_kernel_choice": [_I64, _I64, _I64],
 }
-OTHER_SYMBOLS = ["sfm_last_error", "sfm_abi_version", "sfm_score_workspace_bytes", "sfm_fit_trace_doubles",
-                 "sfm_match_summary_workspace_bytes"]
+OTHER_SYMBOLS = ["sfm_last_error", "sfm_abi_version", "sfm_score_workspace_bytes", "sfm_score_workspace_bytes_ex",
+                 "sfm_fit_trace_doubles", "sfm_match_summary_workspace_bytes"]
 
 _lib = None
 
@@ -187,6 +187,8 @@ def load() -> C.CDLL:
     lib.sfm_fit_trace_doubles.argtypes = []
     lib.sfm_score_workspace_bytes.restype = C.c_int64
     lib.sfm_score_workspace_bytes.argtypes = [_I64, _I64, _I64]
+    lib.sfm_score_workspace_bytes_ex.restype = C.c_int64
+    lib.sfm_score_workspace_bytes_ex.argtypes = [_I64, _I64, _I64, _P]
     lib.sfm_match_summary_workspace_bytes.restype = C.c_int64
     lib.sfm_match_summary_workspace_bytes.argtypes = [_I64, _I64]
     if lib.sfm_abi_version() != ABI_VERSION:

@@ -704,8 +704,8 @@ __global__ __launch_bounds__(256) void select_large_kernel(
     int n_flag = 0;
     const int64_t hp = sfmws::split_padded(h_count);
     const int32_t* part_c = units > 1 ? reinterpret_cast<const int32_t*>(split) + hp : nullptr;
-    const double* part_a1 = units > 1 ? reinterpret_cast<const double*>(part_c + sfmws::kSplitMaxUnits * hp) : nullptr;
-    const double* part_a2 = units > 1 ? part_a1 + sfmws::kSplitMaxUnits * hp : nullptr;
+    const double* part_a1 = units > 1 ? reinterpret_cast<const double*>(part_c + (int64_t)units * hp) : nullptr;
+    const double* part_a2 = units > 1 ? part_a1 + (int64_t)units * hp : nullptr;
     const int32_t* fix_c = reinterpret_cast<const int32_t*>(fix);
     const double* fix_a1 = units > 1 ? reinterpret_cast<const double*>(fix + 4 * hp) : nullptr;
     for (int64_t h = (int64_t)blockIdx.x * 256 + threadIdx.x; h < h_count; h += (int64_t)select_blocks * 256) {
@@ -813,11 +813,11 @@ __global__ __launch_bounds__(kSelectBlock) void select_fold_mask_batch_kernel(
     s2 += b * h_count;
     if (units > 1) {
         const int64_t hp = sfmws::split_padded(h_count);
-        const unsigned char* sp = split + b * sfmws::split_bytes(h_count);
+        const unsigned char* sp = split + b * sfmws::split_bytes(h_count, units);
         const unsigned char* fx = fix + b * sfmws::matrix_fix_bytes(h_count);
         const int32_t* part_c = reinterpret_cast<const int32_t*>(sp) + hp;
-        const double* part_a1 = reinterpret_cast<const double*>(part_c + sfmws::kSplitMaxUnits * hp);
-        const double* part_a2 = part_a1 + sfmws::kSplitMaxUnits * hp;
+        const double* part_a1 = reinterpret_cast<const double*>(part_c + (int64_t)units * hp);
+        const double* part_a2 = part_a1 + (int64_t)units * hp;
         const int32_t* fix_c = reinterpret_cast<const int32_t*>(fx);
         const double* fix_a1 = reinterpret_cast<const double*>(fx + 4 * hp);
         // (thread t folds hypotheses t, t + 1024, ... — the ones block_select has it read back below)
@@ -1127,8 +1127,8 @@ int sfm_ransac_pass_small(uint64_t seed, const uint64_t* seed_dev, int use_philo
     if (!corr || !S || !E || !flags || !cnt || !s1 || !s2 || !result || !workspace)
         return fail(SFM_EINVAL, "sfm_ransac_pass_small: null pointer");
     if (!sfmhost::score_options_valid(options)) return fail(SFM_EINVAL, "sfm_ransac_pass_small: an option is out of range");
-    if (workspace_bytes < sfm_score_workspace_bytes(n, h_count, 1))
-        return fail(SFM_EINVAL, "sfm_ransac_pass_small: workspace smaller than sfm_score_workspace_bytes(n, h_count, 1)");
+    if (workspace_bytes < sfm_score_workspace_bytes_ex(n, h_count, 1, options))
+        return fail(SFM_EINVAL, "sfm_ransac_pass_small: workspace smaller than sfm_score_workspace_bytes_ex(n, h_count, 1, options)");
     if ((reinterpret_cast<uintptr_t>(workspace) & 15u) != 0)
         return fail(SFM_EINVAL, "sfm_ransac_pass_small: workspace must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
@@ -1180,15 +1180,15 @@ int sfm_ransac_pass_large(uint64_t seed, const uint64_t* seed_dev, int use_philo
     if (!corr || !S || !E || !flags || !cnt || !s1 || !s2 || !result || !workspace)
         return fail(SFM_EINVAL, "sfm_ransac_pass_large: null pointer");
     if (!sfmhost::score_options_valid(options)) return fail(SFM_EINVAL, "sfm_ransac_pass_large: an option is out of range");
-    if (workspace_bytes < sfm_score_workspace_bytes(n, h_count, 1))
-        return fail(SFM_EINVAL, "sfm_ransac_pass_large: workspace smaller than sfm_score_workspace_bytes(n, h_count, 1)");
+    if (workspace_bytes < sfm_score_workspace_bytes_ex(n, h_count, 1, options))
+        return fail(SFM_EINVAL, "sfm_ransac_pass_large: workspace smaller than sfm_score_workspace_bytes_ex(n, h_count, 1, options)");
     if ((reinterpret_cast<uintptr_t>(workspace) & 15u) != 0)
         return fail(SFM_EINVAL, "sfm_ransac_pass_large: workspace must be 16-byte aligned");
     SFM_REQUIRE_GRID("sfm_ransac_pass_large", h_count, kWave, kWave, 1);
     SFM_REQUIRE_GRID("sfm_ransac_pass_large (mask)", n, 256, 256);
     hipStream_t st = (hipStream_t)stream;
     unsigned char* ws = static_cast<unsigned char*>(workspace);
-    unsigned char* state = ws + sfmws::ws_split_offset(n, h_count);   // the unused head of the range-split region
+    unsigned char* state = ws + sfmws::ws_tail_offset(n, h_count, 1);   // the unused head of the range-split region
     const bool state_fits = 4 * sfmws::split_padded(h_count) >= sfmws::kFusedPartialOffset + kLargeSelectBlocks * (int64_t)sizeof(PartialSelect);
     sfmhost::LargePass pass{corr, n, E, S, h_count, thr, cnt, s1, s2, ws, workspace_bytes,
                             state_fits ? reinterpret_cast<unsigned*>(state) : nullptr, st, options};
@@ -1250,8 +1250,8 @@ int sfm_ransac_pass_batch(uint64_t seed, const uint64_t* seed_dev, uint64_t seed
     if (!corr || !S || !E || !flags || !cnt || !s1 || !s2 || !result || !workspace)
         return fail(SFM_EINVAL, "sfm_ransac_pass_batch: null pointer");
     if (!sfmhost::score_options_valid(options)) return fail(SFM_EINVAL, "sfm_ransac_pass_batch: an option is out of range");
-    if (workspace_bytes < sfm_score_workspace_bytes(n, h_count, batch))
-        return fail(SFM_EINVAL, "sfm_ransac_pass_batch: workspace smaller than sfm_score_workspace_bytes(n, h_count, batch)");
+    if (workspace_bytes < sfm_score_workspace_bytes_ex(n, h_count, batch, options))
+        return fail(SFM_EINVAL, "sfm_ransac_pass_batch: workspace smaller than sfm_score_workspace_bytes_ex(n, h_count, batch, options)");
     if ((reinterpret_cast<uintptr_t>(workspace) & 15u) != 0)
         return fail(SFM_EINVAL, "sfm_ransac_pass_batch: workspace must be 16-byte aligned");
     SFM_REQUIRE_GRID("sfm_ransac_pass_batch", h_count, kWave, kWave, batch);

@@ -956,8 +956,8 @@ __global__ __launch_bounds__(256, 5) void score_sed_filtered_kernel(
         if (owner) {
             const int64_t hp = split_padded(h_count);
             int32_t* part_c = reinterpret_cast<int32_t*>(split) + hp;
-            double* part_a1 = reinterpret_cast<double*>(part_c + kSplitMaxUnits * hp);
-            double* part_a2 = part_a1 + kSplitMaxUnits * hp;
+            double* part_a1 = reinterpret_cast<double*>(part_c + (int64_t)units * hp);
+            double* part_a2 = part_a1 + (int64_t)units * hp;
             part_c[unit * hp + my_h] = mine_c;
             part_a1[unit * hp + my_h] = mine_a1;
             part_a2[unit * hp + my_h] = mine_a2;
@@ -1000,6 +1000,7 @@ struct FilteredLaunch {
     sfmhost::LargeScore* deferred = nullptr;   // fused pass: leave the ranges' partials to the selection launch, report them here
     hipEvent_t event_before = nullptr, event_after = nullptr;   // options.timing_before / _after: recorded around the scoring kernel
     bool tables_ready = false;    // fused pass: maxima, zeroing and both operand tables of the matrix-pipe kernel are there already
+    WsPlan plan = WsPlan{false, 1, false};   // what the workspace behind the scoring order was sized for
 };
 
 template <int HPW>
@@ -1032,7 +1033,7 @@ int launch_filtered(const FilteredLaunch& a) {
     unsigned char* split = nullptr;
     if (a.units > 1) {   // single pair: `units` consecutive blocks per group of waves; their partials are folded behind the launch
         flat = dim3(grid.x * (unsigned)a.units);   // (sfm_score_sed checked that this grid fits one launch)
-        split = a.ws + ws_split_offset(a.n, a.h_count);
+        split = a.ws + ws_tail_offset(a.n, a.h_count, 1);
     }
     if (a.event_before) (void)hipEventRecord(a.event_before, a.st);
     if (a.one_sided)
@@ -1087,6 +1088,120 @@ bool use_matrix_kernel(int64_t n, int64_t h_count, int64_t batch, const sfm_scor
     return matrix_fits && (matrix_env > 0 || (matrix_env < 0 && matrix_pays));
 }
 
+// What a scoring call with a workspace will launch for (n, h_count, batch) under `opt` — decided ONCE, before anything is
+// launched: sfm_score_sed_ex launches from it and sfm_score_workspace_bytes_ex sizes the workspace by it (ScorePlan::ws).
+struct ScorePlan {
+    WsPlan ws;          // matrix-pipe kernel or VALU filter; ranges of the points; recorded pre-pass
+    int hpw;            // VALU filter: hypotheses per wave
+    bool use_order;     // heaviest-first processing order (cost pre-pass + counting sort)
+    bool one_sided;     // VALU filter: one-sided test
+    double a_scale;     // factor the prepared a-side coordinates carry
+    int per_unit;       // VALU filter: 64-point chunks per range; matrix-pipe kernel: steps of 32 points per range
+};
+int plan_score(int64_t n, int64_t h_count, int64_t batch, double thr, const sfm_score_options& opt, ScorePlan* plan) {
+    // hypotheses per wave: 4 amortises the point loads best, but a launch with fewer waves than the chip holds
+    // (5120) leaves SIMDs idle — then fewer hypotheses per wave = more waves wins (options.hyps_per_wave overrides)
+    int hpw = kHypPerWave;
+    if (opt.hyps_per_wave != 0) {
+        hpw = opt.hyps_per_wave;
+    } else {
+        while (hpw > 1 && (h_count + hpw - 1) / hpw * batch < 5120) hpw /= 2;
+    }
+    SFM_REQUIRE_GRID("sfm_score_sed", (h_count + hpw - 1) / hpw, 256 / kWave, 256, batch);
+    SFM_REQUIRE_GRID("sfm_score_sed (ordering pre-pass)", h_count, 256, 256, batch);
+    const int64_t waves = (h_count + kHypPerWave - 1) / kHypPerWave;
+    // longest-first processing order (cost pre-pass + counting sort); options.order = 0 keeps index order
+    // It pays only when the launch has few generations of waves (a long wave starting late then idles the chip at
+    // the end): 256 CUs x 20 resident waves = 5120 per generation; beyond ~12 generations the tail is negligible
+    // and the pre-pass would cost more than it saves.
+    const int order_env = opt.order;
+    // ... and its fixed cost (~25 us) needs enough points per hypothesis to be won back (measured break-even ~8k).
+    const bool use_order = order_env >= 0 ? order_env != 0 : (waves * batch <= 12 * 5120 && n >= 8192);
+    // tier 1 on the matrix pipe (sfm_score_matrix.h): options.kernel forces it on (where it applies) / off
+    const bool matrix = use_matrix_kernel(n, h_count, batch, opt);
+    // options.one_sided = 0 switches tier 1 of the VALU filter back to the two-sided test (ablation)
+    const bool one_sided = opt.one_sided != 0;
+    plan->hpw = hpw;
+    plan->one_sided = one_sided;
+    plan->a_scale = matrix ? matrixscore::scale_for(thr) : (one_sided ? one_sided_scale(thr) : 1.0);
+    const int split_env = opt.split;
+    if (!matrix) {
+        // Range split: a single-pair launch of 3 to 8 generations of waves (5120 each) is cut into 2 ranges of the points, so
+        // that its last generation — a whole wave duration of draining chip — is half as long: 2.233-2.240 ms against
+        // 2.279-2.297 ms at 50 000 x 100 000 (4.9 generations), 2.803 vs 2.831 at 125 000 hypotheses (6.1).  Four ranges
+        // give the gain back (2.286 ms), launches of one or two generations lose (20 000 x 40 000: 0.480 vs 0.458 ms with
+        // four ranges), more generations have no tail to speak of (profiles/r03/README.md).  options.split = 0 switches it
+        // off, = k forces k ranges.
+        int units = 1, chunks_per_unit = 0;
+        if (batch == 1 && split_env != 0) {
+            const int64_t launch_waves = (h_count + hpw - 1) / hpw;
+            int want = split_env > 0 ? split_env : (launch_waves >= 3 * 5120 && launch_waves < 8 * 5120 ? 2 : 1);
+            want = std::max(1, std::min(want, kSplitMaxUnits));
+            const int chunks = (int)((n + kWave - 1) / kWave);
+            chunks_per_unit = (chunks + want - 1) / want;
+            chunks_per_unit += chunks_per_unit & 1;   // whole chunk pairs
+            if (split_env <= 0) chunks_per_unit = std::max(chunks_per_unit, 64);   // ranges under 4096 points are mostly epilogue
+            units = (chunks + chunks_per_unit - 1) / chunks_per_unit;
+            if (units <= 1 || !sfmhost::grid_fits((int64_t)grid_for((h_count + hpw - 1) / hpw, 256 / kWave) * (int64_t)units, 1, 256)) {
+                units = 1;
+                chunks_per_unit = 0;
+            }
+        }
+        plan->ws = WsPlan{false, units, false};
+        plan->use_order = use_order;
+        plan->per_unit = chunks_per_unit;
+        return SFM_OK;
+    }
+    // Waves of 32 hypotheses are few (3125 at 100 000 hypotheses, against 12 288 resident ones) and long: the points are cut
+    // into ranges so that the launch has about eight generations of waves — 50 000 x 100 000: 1.79 ms with 8 ranges, 1.96 with
+    // 4, 3.4 with 2; x 20 000: 0.43 ms with 16 ranges, 0.69 with 8, 1.24 with 4 (profiles/r03/README.md).  A range keeps at
+    // least 64 steps (2048 points): each range of a hypothesis pays its own epilogue.
+    const int64_t waves32 = (h_count + matrixscore::kHyps - 1) / matrixscore::kHyps;
+    // a batch: ranges until a pair's waves fill one XCD (512 resident waves) — see the kernel's block map
+    const int64_t by_size = batch > 1 ? (512 + waves32 - 1) / waves32 : (8 * 3072 + waves32 - 1) / waves32;
+    int want = split_env > 0 ? split_env : (int)std::min<int64_t>(kSplitMaxUnits, std::max<int64_t>(1, by_size));
+    want = std::max(1, std::min(want, kSplitMaxUnits));
+    // a multiple of eight ranges puts range u of every group on XCD u mod 8 (consecutive blocks are the ranges of one group,
+    // blocks are dealt round-robin over the XCDs; the persistent waves hand out items the same way): an XCD then streams its
+    // own eighth of the operand table through its L2 — 5 .. 11 ranges wanted -> 8, 12 and more -> 16 (50 000 x 125 000: 7
+    // ranges 1.86 ms, 8 ranges 1.73)
+    if (split_env <= 0 && batch == 1 && want >= 5) want = want >= 12 ? 16 : 8;
+    const int steps = (int)matrixscore::steps_of(n);
+    int steps_per_unit = (steps + want - 1) / want;
+    if (split_env <= 0) steps_per_unit = std::max(steps_per_unit, batch > 1 ? 32 : 64);
+    steps_per_unit = (steps_per_unit + 3) & ~3;   // ranges start on the step loop's group boundaries (groups of kAhead + 1 <= 4 steps)
+    int m_units = (steps + steps_per_unit - 1) / steps_per_unit;
+    const bool must_split = steps > matrixscore::kMaxRangeSteps;   // (a queue entry keeps its step relative to the range in 16 bits)
+    if (must_split && (steps_per_unit > matrixscore::kMaxRangeSteps || m_units <= 1 || split_env == 0)) {
+        steps_per_unit = matrixscore::kMaxRangeSteps;   // more than 2 M points per pair: ranges of 2^16 steps, whatever was asked for
+        m_units = (steps + steps_per_unit - 1) / steps_per_unit;
+        if (!sfmhost::grid_fits((int64_t)grid_for(waves32, 256 / kWave) * (int64_t)m_units * ((batch + 7) / 8 * 8), 1, 256))
+            return fail(SFM_EINVAL, "sfm_score_sed: hypotheses x ranges exceed what one launch covers");
+    } else if (m_units <= 1 || split_env == 0 ||
+               !sfmhost::grid_fits((int64_t)grid_for(waves32, 256 / kWave) * (int64_t)m_units * ((batch + 7) / 8 * 8), 1, 256)) {
+        m_units = 1;
+        steps_per_unit = steps;
+    }
+    const bool matrix_order = order_env != 0 && h_count > (batch > 1 ? 64 : 2047);
+    // The pre-pass' tier-1 results are kept for the scoring launch (MatrixPair::record): the pre-pass then scans the first
+    // kReplaySteps steps of every range of the scoring launch — which must all have that many — instead of the first steps of the
+    // points, records the reject words, and the scoring waves replay them.  Taken when that scan is exactly as large as the
+    // pre-pass would be otherwise (8 ranges x 16 steps = the 128 steps of a large single pair; with 16 ranges — 50 000 x 20 000,
+    // 20 000 x 40 000 — the larger pre-pass costs 3-8 us more than the replay saves), and for a single pair only: for
+    // the 256 pairs of C5 — 9 ranges of 36 steps, so 44 % of all reject words would go through memory, 590 MB written and read —
+    // it was measured a loss (2.71 ms per batch against 2.57-2.69, whether a pre-pass wave took one range or all nine).
+    bool record = false;
+#if SFM_MATRIX_REPLAY
+    using matrixscore::kReplaySteps;
+    record = matrix_order && batch == 1 && m_units >= 2 && m_units % 2 == 0 && m_units * kReplaySteps == matrixscore::estimate_steps(n) &&
+             steps_per_unit >= kReplaySteps && steps - (m_units - 1) * steps_per_unit >= kReplaySteps;
+#endif
+    plan->ws = WsPlan{true, m_units, record};
+    plan->use_order = matrix_order;
+    plan->per_unit = steps_per_unit;
+    return SFM_OK;
+}
+
 // compute units of the current device (256 on MI355X): the grid of the persistent-wave launch
 int compute_units() {
     static std::atomic<int> cached[64];
@@ -1104,10 +1219,10 @@ int compute_units() {
 int launch_matrix(const FilteredLaunch& a) {
     using namespace matrixscore;
     const unsigned pairs = (unsigned)a.batch;
-    const uint4* table = reinterpret_cast<const uint4*>(a.ws + ws_matrix_offset(a.n, a.h_count, a.batch));
+    const uint4* table = reinterpret_cast<const uint4*>(a.ws + ws_matrix_offset(a.n, a.h_count, a.batch, a.plan));
     static_assert(kBlocks * 2 * 16 == 96, "sfm_score_ws.h sizes the tables: 3 blocks");
-    const uint4* hyp_table = reinterpret_cast<const uint4*>(a.ws + ws_matrix_hyp_offset(a.n, a.h_count, a.batch));
-    unsigned char* fix = a.ws + ws_matrix_fix_offset(a.n, a.h_count, a.batch);   // the sample corrections, per pair
+    const uint4* hyp_table = reinterpret_cast<const uint4*>(a.ws + ws_matrix_hyp_offset(a.n, a.h_count, a.batch, a.plan));
+    unsigned char* fix = a.ws + ws_matrix_fix_offset(a.n, a.h_count, a.batch, a.plan);   // the sample corrections, per pair
     // partial maxima (in the workspace's fp32-point region, which this kernel does not use: one float4 per setup block and pair) +
     // all zeroing, then both tables — unless a fused pass has done all of that already (tables_ready: launch_large_setup in front of
     // its fit launch, whose lanes wrote the hypotheses' rows and sample corrections; the point table by blocks of the fit launch
@@ -1133,21 +1248,9 @@ int launch_matrix(const FilteredLaunch& a) {
     const int blocks_per_pair = a.batch > 1 ? (int)blocks : 0;
     const unsigned flat = a.batch > 1 ? blocks * (unsigned)((a.batch + 7) / 8 * 8) : blocks;
     const int32_t* order_arg = nullptr;
-    // The pre-pass' tier-1 results are kept for the scoring launch (MatrixPair::record): the pre-pass then scans the first
-    // kReplaySteps steps of every range of the scoring launch — which must all have that many — instead of the first steps of the
-    // points, records the reject words, and the scoring waves replay them.  Taken when that scan is exactly as large as the
-    // pre-pass would be otherwise (8 ranges x 16 steps = the 128 steps of a large single pair; with 16 ranges — 50 000 x 20 000,
-    // 20 000 x 40 000 — the larger pre-pass costs 3-8 us more than the replay saves), and for a single pair only: for
-    // the 256 pairs of C5 — 9 ranges of 36 steps, so 44 % of all reject words would go through memory, 590 MB written and read —
-    // it was measured a loss (2.71 ms per batch against 2.57-2.69, whether a pre-pass wave took one range or all nine).
-    uint16_t* record = nullptr;
+    // (whether the pre-pass records its reject words for the scoring launch: plan_score)
     using matrixscore::kReplaySteps;
-#if SFM_MATRIX_REPLAY
-    if (a.use_order && a.batch == 1 && a.units >= 2 && a.units % 2 == 0 && a.units * kReplaySteps == matrixscore::estimate_steps(a.n) &&
-        a.chunks_per_unit >= kReplaySteps &&
-        (int)matrixscore::steps_of(a.n) - (a.units - 1) * a.chunks_per_unit >= kReplaySteps)
-        record = reinterpret_cast<uint16_t*>(a.ws + ws_matrix_record_offset(a.n, a.h_count, a.batch));
-#endif
+    uint16_t* record = a.plan.record ? reinterpret_cast<uint16_t*>(a.ws + ws_matrix_record_offset(a.n, a.h_count, a.batch, a.plan)) : nullptr;
     if (a.use_order) {
         // cost pre-pass with this kernel's own tier 1 over the first steps (survivors per 1024 points, in sixteenths, into
         // `cnt`, which the scoring launch rewrites), then the counting sort by class
@@ -1173,7 +1276,7 @@ int launch_matrix(const FilteredLaunch& a) {
         order_arg = a.order;
     }
     unsigned char* split = nullptr;   // partials of the ranges: [range][hypothesis], folded by matrix_fold_kernel behind the launch
-    if (a.units > 1) split = a.ws + (a.batch > 1 ? ws_batch_split_offset(a.n, a.h_count, a.batch) : ws_split_offset(a.n, a.h_count));
+    if (a.units > 1) split = a.ws + ws_tail_offset(a.n, a.h_count, a.batch);
     if (a.event_before) (void)hipEventRecord(a.event_before, a.st);
     const int64_t item_blocks = (int64_t)flat * a.units;
     const unsigned grid_blocks = persistent ? (unsigned)std::min<int64_t>(item_blocks, resident_blocks) : (unsigned)item_blocks;
@@ -1267,9 +1370,20 @@ int score_sed_impl(const double* corr, int64_t n, const double* E, const int32_t
 
 extern "C" {
 
+int64_t sfm_score_workspace_bytes_ex(int64_t n, int64_t h_count, int64_t batch, const sfm_score_options* options) {
+    if (n < 0 || h_count < 0 || batch < 0 || n > 0x7FFFFFFF || h_count > 0x3FFFFFFF) return -1;
+    const sfm_score_options opt = resolve_options(options);
+    if (!valid_options(opt)) return -1;
+    ScorePlan plan;
+    plan.ws = WsPlan{false, 1, false};
+    // (sizes no call accepts — fewer than 8 points, nothing to score, a grid beyond one launch — get the plain layout: the call
+    // itself reports the error)
+    if (n >= 8 && h_count >= 1 && batch >= 1 && plan_score(n, h_count, batch, 1.0, opt, &plan) != SFM_OK) plan.ws = WsPlan{false, 1, false};
+    return workspace_bytes_for(n, h_count, batch, plan.ws);
+}
+
 int64_t sfm_score_workspace_bytes(int64_t n, int64_t h_count, int64_t batch) {
-    if (n < 0 || h_count < 0 || batch < 0) return -1;
-    return workspace_bytes_for(n, h_count, batch);
+    return sfm_score_workspace_bytes_ex(n, h_count, batch, nullptr);
 }
 
 int sfm_score_kernel_choice_ex(int64_t n, int64_t h_count, int64_t batch, const sfm_score_options* options) {
@@ -1305,8 +1419,10 @@ int sfm_debug_matrix_filter(const double* corr, int64_t n, const double* E, int6
     if (n < 8 || h_count < 1 || n > matrixscore::kMaxPoints || h_count > 0x3FFFFFFF)
         return fail(SFM_EINVAL, "sfm_debug_matrix_filter: 8 <= n <= 4194304 points and at least one hypothesis");
     if (!corr || !E || !workspace || !r_out || !d_out || !bound_out) return fail(SFM_EINVAL, "sfm_debug_matrix_filter: null pointer");
-    if (workspace_bytes < workspace_bytes_for(n, h_count, 1) || (reinterpret_cast<uintptr_t>(workspace) & 15u) != 0)
-        return fail(SFM_EINVAL, "sfm_debug_matrix_filter: workspace of sfm_score_workspace_bytes(n, h_count, 1) bytes, 16-byte aligned");
+    const WsPlan layout{true, 1, false};   // the matrix-pipe kernel's tables, no ranges
+    if (workspace_bytes < workspace_bytes_for(n, h_count, 1, layout) || (reinterpret_cast<uintptr_t>(workspace) & 15u) != 0)
+        return fail(SFM_EINVAL, "sfm_debug_matrix_filter: workspace of sfm_score_workspace_bytes_ex(n, h_count, 1, {kernel = matrix, split = 0}) "
+                                "bytes, 16-byte aligned");
     using namespace matrixscore;
     hipStream_t st = (hipStream_t)stream;
     unsigned char* ws = static_cast<unsigned char*>(workspace);
@@ -1318,8 +1434,8 @@ int sfm_debug_matrix_filter(const double* corr, int64_t n, const double* E, int6
     hipLaunchKernelGGL(score_reset_kernel, dim3(1), dim3(256), 0, st, ws, reinterpret_cast<int32_t*>(ws + ws_buckets_offset(n, 1)));
     hipLaunchKernelGGL(score_prepare_kernel, dim3(n <= 8192 ? 1u : grid_stride(n, 256, 64), 1), dim3(256), 0, st, (const Corr*)corr,
                        n, a_scale, ws);
-    uint4* table = reinterpret_cast<uint4*>(ws + ws_matrix_offset(n, h_count, 1));
-    uint4* hyp_table = reinterpret_cast<uint4*>(ws + ws_matrix_hyp_offset(n, h_count, 1));
+    uint4* table = reinterpret_cast<uint4*>(ws + ws_matrix_offset(n, h_count, 1, layout));
+    uint4* hyp_table = reinterpret_cast<uint4*>(ws + ws_matrix_hyp_offset(n, h_count, 1, layout));
     hipLaunchKernelGGL(matrix_prepare_kernel, dim3((unsigned)((table_steps(n) + 3) / 4), 1), dim3(256), 0, st, (const Corr*)corr, (int)n,
                        a_scale, ws, table);
     hipLaunchKernelGGL(matrix_hypothesis_kernel, dim3(grid_for(2 * h_count, 256), 1), dim3(256), 0, st, ws, E, (int)h_count, a_scale,
@@ -1366,115 +1482,39 @@ int score_sed_impl(const double* corr, int64_t n, const double* E, const int32_t
         if (opt.timing_after) (void)hipEventRecord((hipEvent_t)opt.timing_after, st);
         return check_launch("score_sed_exact_kernel");
     }
-    if (workspace_bytes < sfm_score_workspace_bytes(n, h_count, batch))
-        return fail(SFM_EINVAL, "sfm_score_sed: workspace smaller than sfm_score_workspace_bytes(n, h_count, batch)");
+    ScorePlan plan;
+    const int rc_plan = plan_score(n, h_count, batch, thr, opt, &plan);   // every size check comes before the first launch: a refused call must not have touched the workspace
+    if (rc_plan != SFM_OK) return rc_plan;
+    if (workspace_bytes < workspace_bytes_for(n, h_count, batch, plan.ws))
+        return fail(SFM_EINVAL, "sfm_score_sed: workspace smaller than sfm_score_workspace_bytes_ex(n, h_count, batch, options)");
     if ((reinterpret_cast<uintptr_t>(workspace) & 15u) != 0)
         return fail(SFM_EINVAL, "sfm_score_sed: workspace must be 16-byte aligned");
-    // hypotheses per wave: 4 amortises the point loads best, but a launch with fewer waves than the chip holds
-    // (5120) leaves SIMDs idle — then fewer hypotheses per wave = more waves wins (options.hyps_per_wave overrides)
-    int hpw = kHypPerWave;
-    if (opt.hyps_per_wave != 0) {
-        hpw = opt.hyps_per_wave;
-    } else {
-        while (hpw > 1 && (h_count + hpw - 1) / hpw * batch < 5120) hpw /= 2;
-    }
-    // every size check comes before the first launch: a refused call must not have touched the workspace
-    SFM_REQUIRE_GRID("sfm_score_sed", (h_count + hpw - 1) / hpw, 256 / kWave, 256, batch);
-    SFM_REQUIRE_GRID("sfm_score_sed (ordering pre-pass)", h_count, 256, 256, batch);
     unsigned char* ws = static_cast<unsigned char*>(workspace);
     int32_t* buckets = reinterpret_cast<int32_t*>(ws + ws_buckets_offset(n, batch));
     int32_t* order = reinterpret_cast<int32_t*>(ws + ws_order_offset(n, batch));
-    // longest-first processing order (cost pre-pass + counting sort); options.order = 0 keeps index order
-    // It pays only when the launch has few generations of waves (a long wave starting late then idles the chip at
-    // the end): 256 CUs x 20 resident waves = 5120 per generation; beyond ~12 generations the tail is negligible
-    // and the pre-pass would cost more than it saves.
-    const int order_env = opt.order;
-    // ... and its fixed cost (~25 us) needs enough points per hypothesis to be won back (measured break-even ~8k).
-    const bool use_order = order_env >= 0 ? order_env != 0 : (waves * batch <= 12 * 5120 && n >= 8192);
-    // tier 1 on the matrix pipe (sfm_score_matrix.h): options.kernel forces it on (where it applies) / off
-    const bool matrix = use_matrix_kernel(n, h_count, batch, opt);
+    if (plan.ws.matrix) {
+        // (the matrix-pipe kernel: launch_matrix prepares everything itself in two launches — partial maxima + zeroing, then both
+        // operand tables — instead of reset / prepare / point table / hypothesis table / estimate zeroing; batches too since round 5:
+        // until then they went through score_prepare_kernel, which also wrote fp32 points that kernel never reads)
+        const FilteredLaunch margs{(const Corr*)corr, ws, (int)n, E, S, (int)h_count, thr, plan.use_order, cnt, s1, s2,
+                                   buckets, order, batch, st, true, plan.a_scale, plan.ws.units, plan.per_unit, true, opt.persistent > 0,
+                                   select_state, deferred, (hipEvent_t)opt.timing_before, (hipEvent_t)opt.timing_after, tables_ready, plan.ws};
+        return launch_matrix(margs);
+    }
     // Small point sets are prepared by one block per pair, which stores the maxima itself; the zeroing kernel is then
     // only needed for the class counters of the ordering pre-pass (a small pass is a chain of ~4 us launches).
     const unsigned prepare_blocks = n <= 8192 ? 1u : grid_stride(n, 256, 64);
-    // options.one_sided = 0 switches tier 1 of the VALU filter back to the two-sided test (ablation)
-    const bool one_sided = opt.one_sided != 0;
-    const double a_scale = matrix ? matrixscore::scale_for(thr) : (one_sided ? one_sided_scale(thr) : 1.0);
-    // (the matrix-pipe kernel: launch_matrix prepares everything itself in two launches — partial maxima + zeroing, then both
-    // operand tables — instead of reset / prepare / point table / hypothesis table / estimate zeroing; batches too since round 5:
-    // until then they went through score_prepare_kernel, which also wrote fp32 points that kernel never reads)
-    const bool fused_setup = matrix;
-    if (!fused_setup) {
-        if (use_order || matrix || prepare_blocks > 1)
-            hipLaunchKernelGGL(score_reset_kernel, dim3((unsigned)batch), dim3(256), 0, st, ws, buckets);
-        hipLaunchKernelGGL(score_prepare_kernel, dim3(prepare_blocks, (unsigned)batch), dim3(256), 0, st,
-                           (const Corr*)corr, n, a_scale, ws);
-        const int rc = check_launch("score_prepare_kernel");
-        if (rc != SFM_OK) return rc;
-    }
-    // Range split: a single-pair launch of 3 to 8 generations of waves (5120 each) is cut into 2 ranges of the points, so
-    // that its last generation — a whole wave duration of draining chip — is half as long: 2.233-2.240 ms against
-    // 2.279-2.297 ms at 50 000 x 100 000 (4.9 generations), 2.803 vs 2.831 at 125 000 hypotheses (6.1).  Four ranges
-    // give the gain back (2.286 ms), launches of one or two generations lose (20 000 x 40 000: 0.480 vs 0.458 ms with
-    // four ranges), more generations have no tail to speak of (profiles/r03/README.md).  options.split = 0 switches it
-    // off, = k forces k ranges.
-    const int split_env = opt.split;
-    int units = 1, chunks_per_unit = 0;
-    if (batch == 1 && split_env != 0) {
-        const int64_t launch_waves = (h_count + hpw - 1) / hpw;
-        int want = split_env > 0 ? split_env : (launch_waves >= 3 * 5120 && launch_waves < 8 * 5120 ? 2 : 1);
-        want = std::max(1, std::min(want, kSplitMaxUnits));
-        const int chunks = (int)((n + kWave - 1) / kWave);
-        chunks_per_unit = (chunks + want - 1) / want;
-        chunks_per_unit += chunks_per_unit & 1;   // whole chunk pairs
-        if (split_env <= 0) chunks_per_unit = std::max(chunks_per_unit, 64);   // ranges under 4096 points are mostly epilogue
-        units = (chunks + chunks_per_unit - 1) / chunks_per_unit;
-        if (units <= 1 || !sfmhost::grid_fits((int64_t)grid_for((h_count + hpw - 1) / hpw, 256 / kWave) * (int64_t)units, 1, 256)) {
-            units = 1;
-            chunks_per_unit = 0;
-        }
-    }
-    if (matrix) {
-        // Waves of 32 hypotheses are few (3125 at 100 000 hypotheses, against 12 288 resident ones) and long: the points are cut
-        // into ranges so that the launch has about eight generations of waves — 50 000 x 100 000: 1.79 ms with 8 ranges, 1.96 with
-        // 4, 3.4 with 2; x 20 000: 0.43 ms with 16 ranges, 0.69 with 8, 1.24 with 4 (profiles/r03/README.md).  A range keeps at
-        // least 64 steps (2048 points): each range of a hypothesis pays its own epilogue.
-        const int64_t waves32 = (h_count + matrixscore::kHyps - 1) / matrixscore::kHyps;
-        // a batch: ranges until a pair's waves fill one XCD (512 resident waves) — see the kernel's block map
-        const int64_t by_size = batch > 1 ? (512 + waves32 - 1) / waves32 : (8 * 3072 + waves32 - 1) / waves32;
-        int want = split_env > 0 ? split_env : (int)std::min<int64_t>(kSplitMaxUnits, std::max<int64_t>(1, by_size));
-        want = std::max(1, std::min(want, kSplitMaxUnits));
-        // a multiple of eight ranges puts range u of every group on XCD u mod 8 (consecutive blocks are the ranges of one group,
-        // blocks are dealt round-robin over the XCDs; the persistent waves hand out items the same way): an XCD then streams its
-        // own eighth of the operand table through its L2 — 5 .. 11 ranges wanted -> 8, 12 and more -> 16 (50 000 x 125 000: 7
-        // ranges 1.86 ms, 8 ranges 1.73)
-        if (split_env <= 0 && batch == 1 && want >= 5) want = want >= 12 ? 16 : 8;
-        const int steps = (int)matrixscore::steps_of(n);
-        int steps_per_unit = (steps + want - 1) / want;
-        if (split_env <= 0) steps_per_unit = std::max(steps_per_unit, batch > 1 ? 32 : 64);
-        steps_per_unit = (steps_per_unit + 3) & ~3;   // ranges start on the step loop's group boundaries (groups of kAhead + 1 <= 4 steps)
-        int m_units = (steps + steps_per_unit - 1) / steps_per_unit;
-        const bool must_split = steps > matrixscore::kMaxRangeSteps;   // (a queue entry keeps its step relative to the range in 16 bits)
-        if (must_split && (steps_per_unit > matrixscore::kMaxRangeSteps || m_units <= 1 || split_env == 0)) {
-            steps_per_unit = matrixscore::kMaxRangeSteps;   // more than 2 M points per pair: ranges of 2^16 steps, whatever was asked for
-            m_units = (steps + steps_per_unit - 1) / steps_per_unit;
-            if (!sfmhost::grid_fits((int64_t)grid_for(waves32, 256 / kWave) * (int64_t)m_units * ((batch + 7) / 8 * 8), 1, 256))
-                return fail(SFM_EINVAL, "sfm_score_sed: hypotheses x ranges exceed what one launch covers");
-        } else if (m_units <= 1 || split_env == 0 ||
-                   !sfmhost::grid_fits((int64_t)grid_for(waves32, 256 / kWave) * (int64_t)m_units * ((batch + 7) / 8 * 8), 1, 256)) {
-            m_units = 1;
-            steps_per_unit = steps;
-        }
-        const FilteredLaunch margs{(const Corr*)corr, ws, (int)n, E, S, (int)h_count, thr, order_env != 0 && h_count > (batch > 1 ? 64 : 2047), cnt, s1, s2,
-                                   buckets, order, batch, st, true, a_scale, m_units, steps_per_unit, true, opt.persistent > 0,
-                                   select_state, deferred, (hipEvent_t)opt.timing_before, (hipEvent_t)opt.timing_after, tables_ready};
-        return launch_matrix(margs);
-    }
+    if (plan.use_order || prepare_blocks > 1)
+        hipLaunchKernelGGL(score_reset_kernel, dim3((unsigned)batch), dim3(256), 0, st, ws, buckets);
+    hipLaunchKernelGGL(score_prepare_kernel, dim3(prepare_blocks, (unsigned)batch), dim3(256), 0, st, (const Corr*)corr, n, plan.a_scale, ws);
+    const int rc = check_launch("score_prepare_kernel");
+    if (rc != SFM_OK) return rc;
     if (select_state != nullptr)
         hipLaunchKernelGGL(score_split_reset_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<int32_t*>(select_state), (int64_t)16);
-    const FilteredLaunch args{(const Corr*)corr, ws, (int)n, E, S, (int)h_count, thr, use_order, cnt, s1, s2,
-                              buckets, order, batch, st, one_sided, a_scale, units, chunks_per_unit, opt.xcd_map != 0, true, nullptr,
-                              nullptr, (hipEvent_t)opt.timing_before, (hipEvent_t)opt.timing_after};
-    switch (hpw) {
+    const FilteredLaunch args{(const Corr*)corr, ws, (int)n, E, S, (int)h_count, thr, plan.use_order, cnt, s1, s2,
+                              buckets, order, batch, st, plan.one_sided, plan.a_scale, plan.ws.units, plan.per_unit, opt.xcd_map != 0, true,
+                              nullptr, nullptr, (hipEvent_t)opt.timing_before, (hipEvent_t)opt.timing_after, false, plan.ws};
+    switch (plan.hpw) {
         case 1: return launch_filtered<1>(args);
         case 2: return launch_filtered<2>(args);
         default: return launch_filtered<4>(args);
@@ -1501,7 +1541,8 @@ int launch_large_setup(const LargePass& p, MatrixTables* t) {
     const sfm_score_options opt = resolve_options(p.options);
     if (!valid_options(opt) || p.h_count < 1 || p.batch < 1 || p.n < 8 || p.n > 0x7FFFFFFF || p.h_count > 0x3FFFFFFF)
         return SFM_OK;   // (the scoring call reports it)
-    if (!use_matrix_kernel(p.n, p.h_count, p.batch, opt)) return SFM_OK;
+    ScorePlan plan;
+    if (plan_score(p.n, p.h_count, p.batch, p.thr, opt, &plan) != SFM_OK || !plan.ws.matrix) return SFM_OK;
     using namespace matrixscore;
     const unsigned setup_blocks = grid_stride(p.n, 1024, kSetupBlocks);
     float4* partial = reinterpret_cast<float4*>(p.workspace + ws_points_offset(p.batch));
@@ -1510,9 +1551,9 @@ int launch_large_setup(const LargePass& p, MatrixTables* t) {
     t->partial = partial;
     t->partials = (int)setup_blocks;
     t->a_scale = scale_for(p.thr);
-    t->hyp_table = reinterpret_cast<uint4*>(p.workspace + ws_matrix_hyp_offset(p.n, p.h_count, p.batch));
-    t->fix = p.workspace + ws_matrix_fix_offset(p.n, p.h_count, p.batch);
-    t->table = reinterpret_cast<uint4*>(p.workspace + ws_matrix_offset(p.n, p.h_count, p.batch));
+    t->hyp_table = reinterpret_cast<uint4*>(p.workspace + ws_matrix_hyp_offset(p.n, p.h_count, p.batch, plan.ws));
+    t->fix = p.workspace + ws_matrix_fix_offset(p.n, p.h_count, p.batch, plan.ws);
+    t->table = reinterpret_cast<uint4*>(p.workspace + ws_matrix_offset(p.n, p.h_count, p.batch, plan.ws));
     t->step_blocks = p.batch == 1 ? (int)((table_steps(p.n) + 3) / 4) : 0;
     hipLaunchKernelGGL(matrix_setup_kernel, dim3(setup_blocks, (unsigned)p.batch), dim3(256), 0, p.stream, (const Corr*)p.corr, (int)p.n,
                        t->a_scale, partial, buckets, p.cnt, (int)p.h_count, p.select_state);

@@ -665,8 +665,8 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
             // the step loop stubbed out the launch still took 0.6 ms, two thirds of every wave's life spent in that hand-off
             // (profiles/r04/README.md); a kernel boundary orders the same data for nothing.
             int32_t* part_c = reinterpret_cast<int32_t*>(a.split) + hp;
-            double* part_a1 = reinterpret_cast<double*>(part_c + sfmws::kSplitMaxUnits * hp);
-            double* part_a2 = part_a1 + sfmws::kSplitMaxUnits * hp;
+            double* part_a1 = reinterpret_cast<double*>(part_c + (int64_t)units * hp);
+            double* part_a2 = part_a1 + (int64_t)units * hp;
             part_c[unit * hp + h] = ck;
             part_a1[unit * hp + h] = s1k;
             part_a2[unit * hp + h] = s2k;
@@ -701,14 +701,14 @@ __global__ __launch_bounds__(256) void matrix_fold_kernel(const unsigned char* _
                                                           double* __restrict__ s1, double* __restrict__ s2) {
     const int64_t pair = blockIdx.y;
     const int64_t hp = sfmws::split_padded(h_count);
-    split += pair * sfmws::split_bytes(h_count);
+    split += pair * sfmws::split_bytes(h_count, units);
     if (fix != nullptr) fix += pair * sfmws::matrix_fix_bytes(h_count);
     cnt += pair * (int64_t)h_count;
     s1 += pair * (int64_t)h_count;
     s2 += pair * (int64_t)h_count;
     const int32_t* part_c = reinterpret_cast<const int32_t*>(split) + hp;
-    const double* part_a1 = reinterpret_cast<const double*>(part_c + sfmws::kSplitMaxUnits * hp);
-    const double* part_a2 = part_a1 + sfmws::kSplitMaxUnits * hp;
+    const double* part_a1 = reinterpret_cast<const double*>(part_c + (int64_t)units * hp);
+    const double* part_a2 = part_a1 + (int64_t)units * hp;
     const int32_t* fix_c = reinterpret_cast<const int32_t*>(fix);
     const double* fix_a1 = reinterpret_cast<const double*>(fix + 4 * hp);
     for (int64_t h = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; h < h_count; h += (int64_t)gridDim.x * blockDim.x) {
@@ -794,7 +794,7 @@ __global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
         if (units > 1) {
             unit = block_of_range % units;
             block_of_range /= units;
-            if (a.split != nullptr) a.split += pair * sfmws::split_bytes(h_count);   // (the pre-pass has ranges and no partials)
+            if (a.split != nullptr) a.split += pair * sfmws::split_bytes(h_count, units);   // (the pre-pass has ranges and no partials)
         }
         a.pts += pair * (int64_t)n;
         a.table += pair * table_steps(n) * kBlocks * 64;

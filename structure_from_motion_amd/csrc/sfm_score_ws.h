@@ -3,7 +3,7 @@
 // fused pass in spare blocks of its own launch.
 //
 //   [batch x 4 uint32 maxima][batch x n float4 points][kPointsPad bytes][batch x kBuckets int32][batch x h_count int32]
-//   then, for one pair, the range-split region, and the operand tables of the matrix-pipe kernel: points, hypotheses   (below)
+//   then — sized by what the call launches (WsPlan, below) — the range-split region and the matrix-pipe kernel's operand tables
 //
 // maxima: data-set maxima of |xa'|, |ya'|, |xb|, |yb| of the fp32 points as bit patterns (non-negative floats order
 // like unsigned ints).  buckets: per pair 256 ints — class counters of the longest-first ordering in large launches;
@@ -40,46 +40,45 @@ __host__ __device__ inline int64_t ws_buckets_offset(int64_t n, int64_t batch) {
 __host__ __device__ inline int64_t ws_order_offset(int64_t n, int64_t batch) {
     return ws_buckets_offset(n, batch) + ((4 * (int64_t)kBuckets * batch + 15) / 16) * 16;
 }
-// Range split of a single-pair launch (sfm_score.hip): a wave's hypotheses are scored over up to kSplitMaxUnits ranges of
-// the points by different waves.  Behind the scoring order: h_pad unused ints, then the ranges' partial
-// counts and sums —  [h_pad int32 unused][kSplitMaxUnits x h_pad int32][kSplitMaxUnits x h_pad f64][kSplitMaxUnits x h_pad f64]
+// Behind the scoring order the workspace is sized by what the call will actually launch (WsPlan: round 5; until then every
+// region was reserved whether or not a launch could pick it — 521 MB for 256 pairs x 10 000 x 2 000).
+struct WsPlan {
+    bool matrix;   // the matrix-pipe kernel runs: its operand tables and sample corrections are reserved
+    int units;     // ranges of the points the scoring launch is cut into (1: none)
+    bool record;   // one pair, matrix-pipe kernel: the cost pre-pass hands its reject words to the scoring launch
+};
+// Range split (sfm_score.hip): a wave's hypotheses are scored over `units` ranges of the points by different waves, which leave
+// their partial counts and sums at [range][hypothesis]:  [h_pad int32 head][units x h_pad int32][units x h_pad f64][units x h_pad f64]
+// per pair.  The head is unused by the scoring kernels; for one pair it holds the state of a fused pass's selection launch.
 constexpr int kSplitMaxUnits = 16;
 __host__ __device__ inline int64_t split_padded(int64_t h_count) { return (h_count + 3) & ~(int64_t)3; }
-__host__ __device__ inline int64_t ws_split_offset(int64_t n, int64_t h_count) {   // batch == 1
-    return ((ws_order_offset(n, 1) + 4 * h_count + 15) / 16) * 16;
-}
-__host__ __device__ inline int64_t split_bytes(int64_t h_count) {
-    return split_padded(h_count) * (4 + kSplitMaxUnits * (4 + 8 + 8));
-}
-// The partials are written with plain stores by the scoring kernels and added in range order by matrixscore::matrix_fold_kernel,
-// launched behind them (the arrival words are a leftover of the per-hypothesis counters of rounds 2-3 and are not used).
-// Operand tables of the matrix-pipe kernel (sfm_score_matrix.h; at most kMatrixMaxPoints points per pair), behind everything
-// else: per pair and step of 32 points three blocks of 64 lanes x 16 bytes (96 bytes per point), then per pair and hypothesis
-// 2 halves x 3 blocks x 16 bytes.
-constexpr int64_t kMatrixMaxPoints = 1 << 22;   // 4 M points per pair (a 400 MB operand table); until round 4: 65 536 (absolute steps in 16 bits)
-__host__ __device__ inline int64_t matrix_table_steps(int64_t n) { return (((n + 31) / 32) + 3) & ~(int64_t)3; }   // (with pad steps: sfm_score_matrix.h)
-__host__ __device__ inline int64_t matrix_table_bytes(int64_t n) {   // one pair
-    return n <= kMatrixMaxPoints ? matrix_table_steps(n) * 3 * 64 * 16 : 0;
-}
-__host__ __device__ inline int64_t matrix_hyp_table_bytes(int64_t n, int64_t h_count) {   // one pair
-    return n <= kMatrixMaxPoints ? h_count * 96 : 0;
-}
-// (a batch of pairs keeps one range-split region per pair in front of the tables: the matrix-pipe kernel splits batches too)
-__host__ __device__ inline int64_t ws_batch_split_offset(int64_t n, int64_t h_count, int64_t batch) {   // batch > 1
+__host__ __device__ inline int64_t ws_tail_offset(int64_t n, int64_t h_count, int64_t batch) {   // behind the scoring order(s)
     return ((ws_order_offset(n, batch) + 4 * h_count * batch + 15) / 16) * 16;
 }
-__host__ __device__ inline int64_t ws_matrix_offset(int64_t n, int64_t h_count, int64_t batch) {
-    const int64_t before = batch == 1 ? ws_split_offset(n, h_count) + split_bytes(h_count)
-                                      : ws_batch_split_offset(n, h_count, batch) + (n <= kMatrixMaxPoints ? batch * split_bytes(h_count) : 0);
-    return ((before + 255) / 256) * 256;
+__host__ __device__ inline int64_t split_bytes(int64_t h_count, int units) {   // one pair
+    return split_padded(h_count) * (4 + (int64_t)(units > 1 ? units : 0) * (4 + 8 + 8));
 }
-__host__ __device__ inline int64_t ws_matrix_hyp_offset(int64_t n, int64_t h_count, int64_t batch) {
-    return ((ws_matrix_offset(n, h_count, batch) + batch * matrix_table_bytes(n) + 255) / 256) * 256;
+__host__ __device__ inline int64_t split_region_bytes(int64_t h_count, int64_t batch, int units) {
+    return batch == 1 ? split_bytes(h_count, units) : (units > 1 ? batch * split_bytes(h_count, units) : 0);
 }
-// ... and per pair the sample corrections of the hypotheses (matrix_hypothesis_kernel): [h_pad] int32 | [h_pad] f64 | [h_pad] f64
+// The partials are written with plain stores by the scoring kernels and added in range order by matrixscore::matrix_fold_kernel
+// (or the selection launch of a fused pass).
+// Operand tables of the matrix-pipe kernel (sfm_score_matrix.h; at most kMatrixMaxPoints points per pair), behind the split
+// region: per pair and step of 32 points three blocks of 64 lanes x 16 bytes (96 bytes per point), then per pair and hypothesis
+// 2 halves x 3 blocks x 16 bytes, then per pair the sample corrections of the hypotheses ([h_pad] int32 | [h_pad] f64 | [h_pad] f64).
+constexpr int64_t kMatrixMaxPoints = 1 << 22;   // 4 M points per pair (a 400 MB operand table); until round 4: 65 536 (absolute steps in 16 bits)
+__host__ __device__ inline int64_t matrix_table_steps(int64_t n) { return (((n + 31) / 32) + 3) & ~(int64_t)3; }   // (with pad steps: sfm_score_matrix.h)
+__host__ __device__ inline int64_t matrix_table_bytes(int64_t n) { return matrix_table_steps(n) * 3 * 64 * 16; }   // one pair
+__host__ __device__ inline int64_t matrix_hyp_table_bytes(int64_t h_count) { return h_count * 96; }                // one pair
 __host__ __device__ inline int64_t matrix_fix_bytes(int64_t h_count) { return split_padded(h_count) * (4 + 8 + 8); }
-__host__ __device__ inline int64_t ws_matrix_fix_offset(int64_t n, int64_t h_count, int64_t batch) {
-    return ((ws_matrix_hyp_offset(n, h_count, batch) + batch * matrix_hyp_table_bytes(n, h_count) + 255) / 256) * 256;
+__host__ __device__ inline int64_t ws_matrix_offset(int64_t n, int64_t h_count, int64_t batch, const WsPlan& plan) {
+    return ((ws_tail_offset(n, h_count, batch) + split_region_bytes(h_count, batch, plan.units) + 255) / 256) * 256;
+}
+__host__ __device__ inline int64_t ws_matrix_hyp_offset(int64_t n, int64_t h_count, int64_t batch, const WsPlan& plan) {
+    return ((ws_matrix_offset(n, h_count, batch, plan) + (plan.matrix ? batch * matrix_table_bytes(n) : 0) + 255) / 256) * 256;
+}
+__host__ __device__ inline int64_t ws_matrix_fix_offset(int64_t n, int64_t h_count, int64_t batch, const WsPlan& plan) {
+    return ((ws_matrix_hyp_offset(n, h_count, batch, plan) + (plan.matrix ? batch * matrix_hyp_table_bytes(h_count) : 0) + 255) / 256) * 256;
 }
 // ... and, for a single pair, the reject words the cost pre-pass records for the scoring launch (sfm_score_matrix.h, MatrixPair::record):
 // [range][2 chunks of 8 steps][h_pad][2 halves] x 16 bytes (the first 16 steps of every range; the launcher records only when the
@@ -91,11 +90,11 @@ constexpr int kMatrixReplaySteps = 16;
 __host__ __device__ inline int64_t matrix_record_bytes(int64_t h_count) {   // one pair
     return split_padded(h_count) * (int64_t)((SFM_MATRIX_ESTIMATE_STEPS / kMatrixReplaySteps) * (kMatrixReplaySteps / 8) * 2 * 16);
 }
-__host__ __device__ inline int64_t ws_matrix_record_offset(int64_t n, int64_t h_count, int64_t batch) {
-    return ((ws_matrix_fix_offset(n, h_count, batch) + (n <= kMatrixMaxPoints ? batch * matrix_fix_bytes(h_count) : 0) + 255) / 256) * 256;
+__host__ __device__ inline int64_t ws_matrix_record_offset(int64_t n, int64_t h_count, int64_t batch, const WsPlan& plan) {
+    return ((ws_matrix_fix_offset(n, h_count, batch, plan) + (plan.matrix ? batch * matrix_fix_bytes(h_count) : 0) + 255) / 256) * 256;
 }
-__host__ __device__ inline int64_t workspace_bytes_for(int64_t n, int64_t h_count, int64_t batch) {
-    return ws_matrix_record_offset(n, h_count, batch) + (n <= kMatrixMaxPoints && batch == 1 ? matrix_record_bytes(h_count) : 0);
+__host__ __device__ inline int64_t workspace_bytes_for(int64_t n, int64_t h_count, int64_t batch, const WsPlan& plan) {
+    return ws_matrix_record_offset(n, h_count, batch, plan) + (plan.record ? matrix_record_bytes(h_count) : 0);
 }
 // Work counters of the matrix-pipe kernel's persistent waves (one per XCD, a 64-byte line each), in the words of the class-counter
 // block that no class uses (classes end at int 16 * 240 = 3840); score_reset_kernel zeroes them with the class counters.

@@ -184,10 +184,19 @@ def hartley_normalize(coords: np.ndarray):
     return raw[:2 * n].reshape(n, 2).copy(), T
 
 
-def score_workspace(n: int, h_count: int, batch: int, device) -> torch.Tensor:
-    """Scratch buffer that enables the two-tier scoring kernel (see include/sfm_hip.h)."""
-    lib = _native.load()
-    return torch.empty((int(lib.sfm_score_workspace_bytes(n, h_count, batch)),), dtype=torch.uint8, device=device)
+def score_workspace_bytes(n: int, h_count: int, batch: int, options: Optional[ScoreOptions] = None) -> int:
+    """Bytes of scoring workspace a call with ``options`` (default: the process-wide set) needs — sized by what it will launch
+    (``sfm_score_workspace_bytes_ex``)."""
+    size = int(_native.load().sfm_score_workspace_bytes_ex(n, h_count, batch, None if options is None else C.byref(options)))
+    if size < 0:
+        raise ValueError("sfm_score_workspace_bytes_ex: negative size or an option out of range")
+    return size
+
+
+def score_workspace(n: int, h_count: int, batch: int, device, options: Optional[ScoreOptions] = None) -> torch.Tensor:
+    """Scratch buffer that enables the two-tier scoring kernels (see include/sfm_hip.h), sized for calls made with
+    ``options`` (default: the process-wide set)."""
+    return torch.empty((score_workspace_bytes(n, h_count, batch, options),), dtype=torch.uint8, device=device)
 
 
 def score_sed(corr: torch.Tensor, E: torch.Tensor, S: torch.Tensor, thr: float, cnt=None, s1=None,
@@ -211,7 +220,7 @@ def score_sed(corr: torch.Tensor, E: torch.Tensor, S: torch.Tensor, thr: float, 
         if exact:
             workspace = None   # NULL selects the all-fp64 kernel
         elif workspace is None:
-            workspace = score_workspace(N, H, B, corr.device)
+            workspace = score_workspace(N, H, B, corr.device, options)
         assert S.dtype == torch.int32 and corr.dtype == F64 and E.dtype == F64
         with torch.cuda.device(corr.device):
             check(_native.load().sfm_score_sed_ex(_ptr(corr), N, _ptr(E), _ptr(S), H, B, float(thr), _ptr(cnt), _ptr(s1),
@@ -526,7 +535,14 @@ class RansacWorkspace:
         self.s2 = torch.empty((batch, h), dtype=F64, device=dev)
         self.result = torch.empty((batch, SELECT_BYTES // 8), dtype=torch.int64, device=dev)
         self.mask = torch.empty((batch, n), dtype=torch.uint8, device=dev)
-        self.score_ws = score_workspace(n, h, batch, dev)
+        self.score_ws = score_workspace(n, h, batch, dev)   # (for the process-wide options of this moment: see _fit_workspace)
+
+    def _fit_workspace(self, options: Optional[ScoreOptions]) -> None:
+        """The scoring workspace is sized by what a call launches: other options (per call, or process-wide defaults changed
+        since this engine was built) may need more — grown here, outside any captured graph, rather than refused by the library."""
+        need = score_workspace_bytes(self.n, self.h, self.batch, options)
+        if need > self.score_ws.numel():
+            self.score_ws = torch.empty((need,), dtype=torch.uint8, device=self.score_ws.device)
 
     def run(self, corr: torch.Tensor, thr: float, min_extra: float, aggregation: int,
             h_offset: int = 0, with_mask: bool = True, philox=None, options: Optional[ScoreOptions] = None) -> None:
@@ -534,6 +550,8 @@ class RansacWorkspace:
         ``philox=(seed, h_begin, seed_stride)``, for Philox samples drawn inside the fit kernel (which also fills
         ``self.S``); ``seed`` may be an int64 device tensor (read at kernel run time).  ``options``: launch options of the
         scoring launch of THIS pass (timing events included); default: the process-wide set."""
+        if not torch.cuda.is_current_stream_capturing():
+            self._fit_workspace(options)
         if small_pass_eligible(self.batch, self.n, self.h):
             # workspace preparation rides in the fit launch, selection over 32 blocks (seed_stride only matters for batches)
             ransac_pass_small(corr, self.S, self.E, self.flags, self.cnt, self.s1, self.s2, self.result,

@@ -1243,7 +1243,7 @@ def _matrix_filter_dump(dev, corr, E, thr):
     n_pad = (n + 31) // 32 * 32
     corr_d = dev.to_device(corr)
     E_d = dev.to_device(E.reshape(h, 9))
-    ws = dev.score_workspace(n, h, 1, corr_d.device)
+    ws = dev.score_workspace(n, h, 1, corr_d.device, _options(kernel="matrix", split=0))   # the matrix-pipe kernel's tables, no ranges
     r = torch.full((h, n_pad), float("nan"), dtype=torch.float32, device=corr_d.device)
     d = torch.full((h, n_pad), float("nan"), dtype=torch.float32, device=corr_d.device)
     bound = torch.zeros((h, 8), dtype=torch.float32, device=corr_d.device)

@@ -30,22 +30,42 @@ def test_header_symbols_exported(native_lib):
 
 
 def test_score_workspace_holds_every_region(native_lib):
-    """sfm_score_workspace_bytes (csrc/sfm_score_ws.h): fp32 points, class counters, scoring order, per-pair range-split
-    partials (16 ranges: 324 bytes per hypothesis) and the matrix-pipe kernel's operand tables (96 bytes per point and per
-    hypothesis, pairs of at most 4 M points) — monotone in every argument, nothing for the tables beyond that."""
-    size = native_lib.sfm_score_workspace_bytes
+    """sfm_score_workspace_bytes(_ex) (csrc/sfm_score_ws.h), sized by what the call will launch (round 5; round 3's advisor):
+    always fp32 points, class counters and the scoring order; the partials of the k ranges the launcher picks for (n, h, batch,
+    options) — 20 k bytes per hypothesis —; the matrix-pipe kernel's tables (96 bytes per point, 96 + 20 per hypothesis) only
+    where that kernel is chosen; the recorded pre-pass (512 bytes per hypothesis) only for a single pair of eight ranges."""
+    from structure_from_motion_amd import _native
+
+    plain = native_lib.sfm_score_workspace_bytes
+
+    def size(n, h, b, **options):
+        return native_lib.sfm_score_workspace_bytes_ex(n, h, b, C.byref(_native.ScoreOptions(**options)) if options else None)
+
     n, h = 50_000, 100_000
     one = size(n, h, 1)
-    assert one >= 16 * n + 4 * h + 324 * h + 96 * (n + 31) // 32 * 32 + 96 * h
-    assert size(n + 32, h, 1) > one and size(n, h + 1, 1) > one
+    assert one == plain(n, h, 1)                                     # NULL options = the process-wide defaults
+    tables = 96 * ((n + 31) // 32 * 32) + (96 + 20) * h
+    assert 16 * n + 4 * h + 4 * h + 8 * 20 * h + tables + 512 * h <= one < 16 * n + 8 * h + 8 * 20 * h + tables + 512 * h + (1 << 20)   # 86 MB
+    assert size(n + 32, h, 1) > one and size(n, h + 4, 1) > one
+    valu = size(n, h, 1, kernel="filtered")                          # the VALU filter: 2 ranges of this size, no tables, no record
+    assert 16 * n + 8 * h + 2 * 20 * h <= valu < 16 * n + 8 * h + 2 * 20 * h + (1 << 20) and valu < one / 8
+    assert size(n, h, 1, kernel="filtered", split=0) < valu          # no ranges: no partials
+    assert size(n, h, 1, split=16) > size(n, h, 1, split=4)          # more ranges asked for: more partials (and no recorded pre-pass)
     big = size(5_000_000, h, 1)
-    assert big < size(4_194_304, h, 1)         # no operand tables for a pair the matrix-pipe kernel cannot take (> 4 M points)
-    assert big >= 16 * 5_000_000 + 4 * h + 324 * h
-    assert size(70_000, h, 1) > size(65_536, h, 1) >= 96 * 65_536   # (the cap of rounds 1-3 is gone)
-    batch = size(10_000, 2_000, 256)
-    assert batch >= 256 * (16 * 10_000 + 4 * 2_000 + 324 * 2_000 + 96 * 10_016 + 96 * 2_000)
-    assert size(10_000, 2_000, 257) > batch
-    assert size(-1, 5, 1) == -1 and size(5, -1, 1) == -1 and size(5, 5, -1) == -1
+    assert big < size(4_194_304, h, 1)          # no operand tables for a pair the matrix-pipe kernel cannot take (> 4 M points)
+    assert big >= 16 * 5_000_000 + 8 * h
+    assert size(70_000, h, 1) > size(65_536, h, 1) >= 96 * 65_536    # (the cap of rounds 1-3 is gone)
+    # BASELINE configs[4]: 256 pairs x 10 000 x 2 000 — matrix-pipe kernel by size (9 ranges), 47 MB with the VALU filter
+    c5 = size(10_000, 2_000, 256)
+    assert native_lib.sfm_score_kernel_choice(10_000, 2_000, 256) == 2
+    assert 256 * (16 * 10_000 + 4 * 2_000 + 9 * 20 * 2_000 + 96 * 10_016 + 116 * 2_000) <= c5 < 460_000_000
+    c5_valu = size(10_000, 2_000, 256, kernel="filtered")
+    assert 256 * (16 * 10_000 + 4 * 2_000) <= c5_valu < 100_000_000     # VERDICT r4 item 5: under 100 MB when the VALU kernel is chosen
+    assert size(10_000, 2_000, 257) > c5
+    assert size(10_000, 2_000, 16) < 16 * (16 * 10_000 + 8 * 2_000) + (1 << 20)   # a batch too small for the matrix-pipe kernel: no tables
+    assert size(300, 64, 1, kernel="matrix") > size(300, 64, 1)      # forced on: the tables are reserved
+    assert plain(-1, 5, 1) == -1 and plain(5, -1, 1) == -1 and plain(5, 5, -1) == -1
+    assert size(300, 64, 1, kernel=7) == -1                          # bad options
 
 
 def test_score_kernel_choice_rule(native_lib):

@@ -23,7 +23,7 @@ pa, pb, K, *_ = synthetic.two_view_scene(n, seed=6)
 corr = dev.normalize_correspondences(dev.to_device(pa), dev.to_device(pb), K).reshape(1, n, 4)
 S = dev.sample_philox(5, 0, h, n)
 E, flags = dev.fit_eight_point(corr, S)
-ws = dev.score_workspace(n, h, 1, corr.device)
+ws = dev.score_workspace(n, h, 1, corr.device)   # (sized for the process-wide options: the SFM_SCORE_* variables)
 before, after = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 before.record(); after.record(); torch.cuda.synchronize()
 for _ in range(3):

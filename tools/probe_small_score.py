@@ -14,7 +14,7 @@ pa, pb, K, *_ = synthetic.two_view_scene(n, seed=6)
 corr = dev.normalize_correspondences(dev.to_device(pa), dev.to_device(pb), K).reshape(1, n, 4)
 S = dev.sample_philox(5, 0, h, n)
 E, flags = dev.fit_eight_point(corr, S)
-ws = dev.score_workspace(n, h, 1, corr.device)
+ws = dev.score_workspace(n, h, 1, corr.device, dev.ScoreOptions(kernel="filtered", split=0))
 for hpw in (1, 2, 4):
     options = dev.ScoreOptions(kernel="filtered", hyps_per_wave=hpw)
     for thr in (1.5e-6, 1e-10):
