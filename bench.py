@@ -443,6 +443,116 @@ def other_configs(torch, device, distributed, synthetic, agg):
     return out
 
 
+_PUBLIC = os.path.join("..", "..", "include", "sfm_hip.h")
+WIDENED_SOURCES = {   # (translation unit, headers it includes) a widened row's kernels are compiled from: what its counter record is stamped with
+    "f1_match_20000x20000_ncc9": (("sfm_match.hip",), ("sfm_common.h", "sfm_math.h", _PUBLIC)),
+    "f1_match_600x600_ncc9": (("sfm_match.hip",), ("sfm_common.h", "sfm_math.h", _PUBLIC)),
+    "f2_harris_vga": (("sfm_harris.hip",), ("sfm_common.h", _PUBLIC)),
+    "f2_harris_1080p": (("sfm_harris.hip",), ("sfm_common.h", _PUBLIC)),
+    "f4_refine_50000": (("sfm_refine.hip",), ("sfm_common.h", "sfm_math.h", "sfm_fit.h", _PUBLIC)),
+    "pose_tail_c5": (("sfm_pose.hip",), ("sfm_common.h", "sfm_math.h", _PUBLIC)),
+}
+
+
+def widened_sha(name):
+    from structure_from_motion_amd import build
+
+    sources, headers = WIDENED_SOURCES[name]
+    return build.source_sha(sources, headers=headers)
+FP64_PER_DLT = 420   # fp64 wave-instructions of one DLT solve (4 x 4 null vector: Householder QR + inverse iteration) as compiled
+
+
+def widened_configs(torch):
+    """The widened rows of SURVEY.md §8f and the pose tail of configs[4] on the bench line, outside `value`:
+    brute-force matcher (reference matching.py:36-118: 20 000 x 20 000 NCC-9 and the demo's 600 x 600), Harris detector
+    (harris_detector.py:11-113: VGA and 1080p), local optimisation (refine_kernel, N = 50 000), cheirality + vote + triangulation
+    at C5's sizes (eight_point.py:181-242,449-488; triangulation.py:42-62).  Per row: the kernels, their time by HIP events around
+    the library call (inputs resident; the Harris rows time the whole call, which uploads the image and reads the corners back),
+    a floor where the work is countable, and — when profiles/<row>_counters.json (tools/collect_config_counters.sh) exists — the
+    counter-based issue-slot utilisation and HBM traffic, flagged stale when the kernels' sources changed since."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import widened_workloads as ww
+    from structure_from_motion_amd import build
+
+    def timed(fn, reps):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps, (time.perf_counter() - t0) / reps * 1e3   # (stream time, wall time) in ms
+
+    def counters(name, kernel_ms):
+        try:
+            rec = json.load(open(os.path.join(REPO, "profiles", name + "_counters.json")))
+        except (OSError, ValueError):
+            return None
+        out = {"counters_stale": rec.get("source_sha") != widened_sha(name),
+               "counters_from": {k: rec.get(k) for k in ("git", "source_sha", "collected")}, "kernels": {}}
+        for kernel, c in rec.get("kernels", {}).items():
+            f64 = sum(c.get(k, 0.0) for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64",
+                                              "SQ_INSTS_VALU_TRANS_F64"))
+            entry = {"launches_per_pass": c.get("launches_per_pass"), "trace_avg_us": c.get("trace_avg_us")}
+            if "SQ_INSTS_VALU" in c and c.get("trace_avg_us"):
+                cycles = (c["SQ_INSTS_VALU"] - f64) * CYC_VALU + f64 * CYC_F64 + c.get("SQ_INSTS_MFMA", 0.0) * CYC_MFMA
+                entry.update({"valu_insts_per_launch": c["SQ_INSTS_VALU"], "fp64_insts": f64,
+                              "issue_frac": cycles / SIMDS / (CLOCK_GHZ * 1e9) / (c["trace_avg_us"] * 1e-6)})
+            if "FETCH_SIZE" in c and "WRITE_SIZE" in c and c.get("trace_avg_us"):
+                traffic = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+                entry.update({"traffic": traffic, "hbm_frac": traffic / (c["trace_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS})
+            out["kernels"][kernel] = entry
+        return out
+
+    def fp64_floor_ms(wave_insts):
+        return wave_insts * CYC_F64 / SIMDS / (CLOCK_GHZ * 1e9) * 1e3
+
+    out = {}
+    for name, build_workload in ww.BUILDERS.items():
+        run, info = build_workload()
+        reps = {"f1_match_20000x20000_ncc9": 5, "f1_match_600x600_ncc9": 50, "f2_harris_vga": 20, "f2_harris_1080p": 5,
+                "f4_refine_50000": 20, "pose_tail_c5": 5}[name]
+        gpu_ms, wall_ms = timed(run, reps)
+        row = {"kernel": info.get("kernel"), "kernel_ms": gpu_ms}
+        if name.startswith("f1_"):
+            floor = fp64_floor_ms(info["pairs"] * info["fp64_insts_per_pair"] / 64.0)
+            row.update({"features": [info["features_a"], info["features_b"]], "window_elements": info["window_elements"],
+                        "pairs_per_s": info["pairs"] / (gpu_ms * 1e-3),
+                        "fp64_floor": {"floor_ms": floor, "frac_of_kernel": floor / gpu_ms,
+                                       "note": "K separately rounded multiplies + K adds per pair (no FMA: bit-exact window sums) at 4 "
+                                               "cycles per fp64 wave-instruction, 64 lanes x 1024 SIMDs x 2.4 GHz"}})
+        elif name.startswith("f2_"):
+            row.update({"call_ms": wall_ms, "kernel_ms": None, "pixels": info["pixels"], "megapixels_per_s": info["pixels"] / wall_ms / 1e3,
+                        "corners": info["corners"],
+                        "note": "whole detect_harris_corners call: image upload, Sobel x / y, cornerness, 12 NMS rounds + check, "
+                                "compaction, corner list read back (host-synchronous: wall clock)"})
+        elif name.startswith("f4_"):
+            row.update({"matches": info["matches"], "rounds": info["rounds"], "inliers_in": info["inliers_in"],
+                        "note": "one block per pair runs the whole refit + re-score loop: latency-bound by construction"})
+        else:
+            stages = {}
+            for stage, fn in info["stages"].items():
+                ms, _ = timed(fn, reps)
+                stages[stage] = {"kernel_ms": ms}
+                if stage in info["dlt_solves"]:
+                    floor = fp64_floor_ms(info["dlt_solves"][stage] / 64.0 * FP64_PER_DLT)
+                    stages[stage]["fp64_floor"] = {"dlt_solves": info["dlt_solves"][stage], "fp64_insts_per_solve": FP64_PER_DLT,
+                                                   "floor_ms": floor, "frac_of_kernel": floor / ms}
+            row.update({"pairs": info["pairs"], "matches": info["matches"], "inliers": info["inliers"], "stages": stages,
+                        "kernel": "cheirality_batched_kernel + pose_vote_kernel + triangulate_selected_kernel"})
+        pmc = counters(name, gpu_ms)
+        if pmc is not None:
+            row["counters"] = pmc
+        out[name] = row
+        del run, info
+        torch.cuda.empty_cache()
+    return out
+
+
 def _native_lib():
     from structure_from_motion_amd import _native
 
@@ -660,6 +770,7 @@ def main():
         if world == 1 and not args.no_extras:
             device.score_sed = score
             line["configs"] = other_configs(torch, device, distributed, synthetic, AGG_RMS)
+            line["configs"].update(widened_configs(torch))
             line["api_ms"] = api_timings(device)
         if not args.no_cpu_baseline and world == 1:
             corr_host = corr.cpu().numpy()

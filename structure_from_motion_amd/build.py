@@ -21,6 +21,23 @@ def _extra_flags():
     return os.environ.get("SFM_EXTRA_HIPCC_FLAGS", "").split()   # experiment builds (e.g. -DSFM_SCORE_E_IN_VGPR=1)
 
 
+def source_sha(sources, extra=None, headers=None) -> str:
+    """Fingerprint of the translation units `sources` (names under csrc/), the headers they include (``headers=None``: every
+    csrc/*.h and the public header) and the compiler flags (``extra=None``: the flags the in-tree library was built with) —
+    what a committed counter record of one of their kernels is stamped with."""
+    import hashlib
+
+    if extra is None:
+        extra = built_flags()
+    h = hashlib.sha256()
+    for name in list(sources) + (HEADERS if headers is None else list(headers)):
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(f.read())
+    for flag in FLAGS + list(extra):
+        h.update(flag.encode())
+    return h.hexdigest()[:16]
+
+
 def score_source_sha(extra=None) -> str:
     """Fingerprint of what the scoring kernels are compiled from — sfm_score.hip, every csrc/*.h it can include, the
     public header and the compiler flags INCLUDING the extra flags of an experiment build; profiles/score_traffic.json

@@ -1,6 +1,8 @@
-"""One of the other BASELINE configurations as a plain loop (for rocprofv3 passes; tools/collect_config_counters.sh):
-   python tools/run_config.py c2|c5 [passes]  — C2 = 5 000 x 10 000 (the lean small pass), C5 = 256 pairs x 10 000 x 2 000
-(the batched pipeline), with bench.py's scenes and seeds."""
+"""One of the other BASELINE configurations, or one of the widened rows of SURVEY.md §8f, as a plain loop (for rocprofv3 passes;
+tools/collect_config_counters.sh):
+   python tools/run_config.py c2|c5|<widened workload> [passes]  — C2 = 5 000 x 10 000 (the lean small pass), C5 = 256 pairs x
+10 000 x 2 000 (the batched pipeline), with bench.py's scenes and seeds; widened workloads: the names of
+tools/widened_workloads.py::BUILDERS (f1_match_20000x20000_ncc9, f2_harris_vga, f4_refine_50000, pose_tail_c5, ...)."""
 import os
 import sys
 
@@ -23,6 +25,15 @@ if which == "c2":
         eng.step(1000 + r)
     torch.cuda.synchronize()
     print("c2", eng.outcome().best_h)
+elif which != "c5":
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import widened_workloads
+
+    run, info = widened_workloads.BUILDERS[which]()
+    for r in range(passes):
+        run()
+    torch.cuda.synchronize()
+    print(which, {k: v for k, v in info.items() if k not in ("keepalive", "stages")})
 else:
     B, n, h = 256, 10_000, 2_000
     base = [synthetic.two_view_scene(n, seed=300 + b, outlier_fraction=0.25) for b in range(16)]
