@@ -2,7 +2,8 @@
 variables spell (translated once, when the library is loaded: run it once per setting), checked against the all-fp64 kernel:
 counts bit-equal, sums to 1e-12; kernel time by HIP events carried in the call's options (sfm_score_options.timing_*)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.abspath(os.environ["SFM_TREE"]) if os.environ.get("SFM_TREE") else   # a tree prepared by tools/ab.py
+                os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from structure_from_motion_amd import device as dev, synthetic
 n, h = int(os.environ.get("N", 50000)), int(os.environ.get("H", 100000))
