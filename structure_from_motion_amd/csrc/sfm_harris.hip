@@ -124,9 +124,10 @@ __global__ void nms_round_kernel(const double* __restrict__ image, uint8_t* stat
             state[r * w + c] = 1;
         }
     }
-    // count what is left
-    const unsigned long long mask = __ballot(pending != 0);
-    if ((threadIdx.x & (kWave - 1)) == 0 && mask != 0ull) atomicAdd(unresolved, (int)__popcll(mask));
+    // what is left: one add per BLOCK with pending pixels (one per wave — 32 000 atomics on one word in the early rounds of a
+    // 1080p image — took 94 us a round where the stencil itself takes ~10: profiles/r05/README.md)
+    const int left = __syncthreads_count(pending != 0);
+    if (threadIdx.x == 0 && left != 0) atomicAdd(unresolved, left);
 }
 
 __global__ void nms_finalize_kernel(double* __restrict__ image, const uint8_t* __restrict__ state, int64_t count) {
@@ -137,29 +138,49 @@ __global__ void nms_finalize_kernel(double* __restrict__ image, const uint8_t* _
 __global__ void zero_counter_kernel(int32_t* counter) { *counter = 0; }
 
 // Compaction of the suppressed cornerness image: (flat index, value) of every non-zero pixel, in no particular
-// order (one atomic per wave reserves the slots).  After suppression a few thousand of ~300 k pixels survive; only
-// they need to reach the host for the top-k selection of harris_detector.py:32-42.
+// order.  After suppression a few thousand of ~300 k pixels survive (tens of thousands on integer-valued images, whose
+// equal neighbours all survive); only they need to reach the host for the top-k selection of harris_detector.py:32-42.
+// A block first COUNTS the survivors of all the pixels it walks, reserves their slots with one atomic, and walks the pixels
+// again to write them (the image is L2-resident): at most 1024 atomics on the counter per launch — one per wave and
+// iteration were 32 000 at 1080p, 370 us of serialised read-modify-writes for a 20 us scan.
 __global__ __launch_bounds__(256) void compact_nonzero_kernel(const double* __restrict__ image, int64_t count,
                                                               int32_t capacity, int32_t* __restrict__ counter,
                                                               int32_t* __restrict__ index,
                                                               double* __restrict__ value) {
-    const int lane = threadIdx.x & (kWave - 1);
+    __shared__ int wave_total[256 / kWave];
+    __shared__ int block_start;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    // whole waves iterate together (the ballot needs every lane): the bound is rounded up to the wave
-    for (int64_t base = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x - lane); base < count; base += stride) {
+    const int64_t first = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x - lane);   // whole waves iterate together (the ballots need every lane)
+    int mine = 0;   // survivors this wave will write (wave-uniform)
+    for (int64_t base = first; base < count; base += stride) {
         const int64_t i = base + lane;
         const double v = i < count ? image[i] : 0.0;
-        const bool keep = v != 0.0;  // NaN != 0 is true: kept, as `cornerness != 0` keeps it in the reference
+        mine += (int)__popcll(__ballot(v != 0.0));   // NaN != 0 is true: kept, as `cornerness != 0` keeps it in the reference
+    }
+    if (lane == 0) wave_total[wave] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int total = 0;
+#pragma unroll
+        for (int w = 0; w < 256 / kWave; ++w) total += wave_total[w];
+        block_start = total != 0 ? atomicAdd(counter, total) : 0;
+    }
+    __syncthreads();
+    int slot0 = block_start;
+    for (int w = 0; w < wave; ++w) slot0 += wave_total[w];
+    for (int64_t base = first; base < count; base += stride) {
+        const int64_t i = base + lane;
+        const double v = i < count ? image[i] : 0.0;
+        const bool keep = v != 0.0;
         const unsigned long long votes = __ballot(keep);
         if (votes == 0ull) continue;
-        int start = 0;
-        if (lane == 0) start = atomicAdd(counter, (int)__popcll(votes));
-        start = __shfl(start, 0, kWave);
-        const int slot = start + __builtin_amdgcn_mbcnt_hi((unsigned)(votes >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)votes, 0));
+        const int slot = slot0 + __builtin_amdgcn_mbcnt_hi((unsigned)(votes >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)votes, 0));
         if (keep && slot < capacity) {
             index[slot] = (int32_t)i;
             value[slot] = v;
         }
+        slot0 += (int)__popcll(votes);
     }
 }
 
