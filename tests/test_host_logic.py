@@ -152,6 +152,34 @@ def test_argument_validation_without_gpu(native_lib):
     # empty work is a successful no-op
     assert native_lib.sfm_triangulate(None, 0, None, None, None, None) == 0
     assert native_lib.sfm_cheirality(None, 0, None, 4, 50.0, None, None) == 0
+    # the fused passes (ABI 11: trailing launch options; sfm_ransac_pass_batch): sizes, null pointers, options and the
+    # plan-sized workspace are checked before anything is launched
+    from structure_from_motion_amd import _native
+
+    p = C.c_void_p(0x1000)
+    bad = C.byref(_native.ScoreOptions(split=-7))
+    for entry in (native_lib.sfm_ransac_pass_small, native_lib.sfm_ransac_pass_large):
+        assert entry(1, None, 1, 0, p, 7, 100, 1e-6, 10.0, 3, 0, p, p, p, p, p, p, p, None, p, 1 << 40, None, None) == -1        # n < 8
+        assert entry(1, None, 1, 0, p, 100, 100, 1e-6, 10.0, 9, 0, p, p, p, p, p, p, p, None, p, 1 << 40, None, None) == -1      # aggregation
+        assert entry(1, None, 1, 0, p, 100, 100, 1e-6, 10.0, 3, 0, p, p, None, p, p, p, p, None, p, 1 << 40, None, None) == -1   # null flags
+        assert entry(1, None, 1, 0, p, 100, 100, 1e-6, 10.0, 3, 0, p, p, p, p, p, p, p, None, p, 1 << 40, None, bad) == -1       # bad options
+        assert b"option" in native_lib.sfm_last_error()
+        assert entry(1, None, 1, 0, p, 100, 100, 1e-6, 10.0, 3, 0, p, p, p, p, p, p, p, None, p, 16, None, None) == -1           # workspace too small
+        assert b"workspace" in native_lib.sfm_last_error()
+    batch = native_lib.sfm_ransac_pass_batch
+    assert batch(1, None, 1, 1, 0, p, 100, 100, 0, 1e-6, 10.0, 3, p, p, p, p, p, p, p, None, p, 1 << 40, None, None) == 0         # no pairs: nothing to do
+    assert batch(1, None, 1, 1, 0, p, 100, 100, 70000, 1e-6, 10.0, 3, p, p, p, p, p, p, p, None, p, 1 << 40, None, None) == -1    # grid y
+    assert batch(1, None, 1, 1, 0, p, 100, 0, 4, 1e-6, 10.0, 3, p, p, p, p, p, p, p, None, p, 1 << 40, None, None) == -1          # no hypotheses
+    assert batch(1, None, 1, 1, 0, p, 100, 100, 4, 1e-6, 10.0, 3, p, p, p, p, p, p, None, None, p, 1 << 40, None, None) == -1     # null result
+    assert batch(1, None, 1, 1, 0, p, 100, 100, 4, 1e-6, 10.0, 3, p, p, p, p, p, p, p, None, p, 16, None, None) == -1             # workspace too small
+    # a workspace sized for the process-wide options is refused by a call whose options need the matrix-pipe kernel's tables
+    n, h = 9_000, 5_000
+    small = native_lib.sfm_score_workspace_bytes_ex(n, h, 1, C.byref(_native.ScoreOptions(kernel="filtered")))
+    forced = C.byref(_native.ScoreOptions(kernel="matrix"))
+    assert native_lib.sfm_score_workspace_bytes_ex(n, h, 1, forced) > small
+    ws = C.c_void_p(0x10000)
+    assert native_lib.sfm_score_sed_ex(p, n, p, p, h, 1, 1e-6, p, p, p, ws, small, None, forced) == -1
+    assert b"workspace" in native_lib.sfm_last_error()
 
 
 def test_sizes_beyond_one_launch_are_refused(native_lib):
