@@ -536,12 +536,16 @@ class RansacWorkspace:
         self.result = torch.empty((batch, SELECT_BYTES // 8), dtype=torch.int64, device=dev)
         self.mask = torch.empty((batch, n), dtype=torch.uint8, device=dev)
         self.score_ws = score_workspace(n, h, batch, dev)   # (for the process-wide options of this moment: see _fit_workspace)
+        self.frozen = False   # set by ShardedRansac.capture: the buffers' addresses are baked into a graph
 
     def _fit_workspace(self, options: Optional[ScoreOptions]) -> None:
         """The scoring workspace is sized by what a call launches: other options (per call, or process-wide defaults changed
         since this engine was built) may need more — grown here, outside any captured graph, rather than refused by the library."""
         need = score_workspace_bytes(self.n, self.h, self.batch, options)
         if need > self.score_ws.numel():
+            if self.frozen:   # a captured HIP graph holds the address of the present buffer
+                raise RuntimeError("RansacWorkspace: these launch options need a larger scoring workspace than the one a captured "
+                                   "graph of this engine refers to; build a new engine (or capture again) with them")
             self.score_ws = torch.empty((need,), dtype=torch.uint8, device=self.score_ws.device)
 
     def run(self, corr: torch.Tensor, thr: float, min_extra: float, aggregation: int,

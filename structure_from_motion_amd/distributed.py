@@ -186,6 +186,8 @@ class ShardedRansac:
         Every buffer the captured kernels touch is allocated before capture begins (``RansacWorkspace`` and
         ``seed_dev``): nothing is allocated from the graph's private pool."""
         self.seed_dev = torch.zeros(1, dtype=torch.int64, device=self.corr.device)
+        self.ws._fit_workspace(self.score_options)   # sized for this engine's launch options BEFORE capture ...
+        self.ws.frozen = True                        # ... and never reallocated afterwards: the graph holds its address
         side = torch.cuda.Stream(device=self.corr.device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
