@@ -349,3 +349,30 @@ def test_ssd_integer_window_beyond_the_32_bit_accumulators_and_unpadded_layout()
     np.testing.assert_array_equal(scores.cpu().numpy(), want.cpu().numpy())
     assert lib.sfm_pair_scores(0x100 | 24, ta.data_ptr(), nA, tb.data_ptr(), nB, qa.data_ptr(), qb.data_ptr(), oka.data_ptr(),
                                okb.data_ptr(), nA, nB, K, scores.data_ptr(), st) != 0       # 24-bit pixels: no such dtype
+
+
+def test_ssd_integer_edge_cases():
+    """Empty and one-element feature lists, every window out of bounds, a 1 x 1 window, equal images (all zeros), and the largest
+    magnitudes of int64 (sums that wrap modulo 2^64 exactly as NumPy's do) — against the oracle."""
+    rng = np.random.default_rng(99)
+    ia = rng.integers(0, 256, (20, 24), dtype=np.uint8)
+    ib = rng.integers(0, 256, (20, 24), dtype=np.uint8)
+    f = np.array([[5.0, 6.0], [0.0, 0.0], [23.0, 19.0], [12.0, 10.0]])
+    for fa, fb in ((f[:0], f), (f, f[:0]), (f[:1], f[3:]), (f[1:3], f[1:3])):
+        if len(fa) == 0 or len(fb) == 0:
+            got = _device_match.score_matrix(1, ia, ib, feats(fa), feats(fb), 3)
+            assert tuple(got.shape) == (len(fa), len(fb))
+            continue
+        got = _device_match.score_matrix(1, ia, ib, feats(fa), feats(fb), 3).cpu().numpy()
+        np.testing.assert_array_equal(got, mo.ssd_scores_in_dtype(ia, ib, fa, fb, 3))
+    got = _device_match.score_matrix(1, ia, ib, feats(f), feats(f), 1).cpu().numpy()          # 1 x 1 windows: nothing out of bounds
+    np.testing.assert_array_equal(got, mo.ssd_scores_in_dtype(ia, ib, f, f, 1))
+    same = _device_match.score_matrix(1, ia, ia.copy(), feats(f[[0, 3]]), feats(f[[0, 3]]), 5).cpu().numpy()
+    assert same[0, 0] == 0.0 and same[1, 1] == 0.0
+    big = np.iinfo(np.int64)
+    la = rng.integers(big.min, big.max, (12, 12), dtype=np.int64, endpoint=True)
+    lb = rng.integers(big.min, big.max, (12, 12), dtype=np.int64, endpoint=True)
+    c = np.array([[5.0, 5.0], [6.0, 4.0]])
+    got = _device_match.score_matrix(1, la, lb, feats(c), feats(c), 9).cpu().numpy()
+    np.testing.assert_array_equal(got, mo.ssd_scores(la, lb, c, c, 9))                        # exact Python integers, reduced modulo 2^64
+    np.testing.assert_array_equal(got, mo.ssd_scores_in_dtype(la, lb, c, c, 9))
