@@ -55,6 +55,8 @@ slots = (st[:, 8] >> np.uint64(32)).astype(np.float64) * 64.0
 pops = (st[:, 8] & np.uint64(0xFFFFFFFF)).astype(np.float64)
 clock = st[:, 9].astype(np.float64) / np.maximum(dur, 1e-3) * 1e-3   # shader cycles per us -> GHz
 print(f"shader clock while a wave runs: median {np.median(clock):.2f} GHz, p10 {np.percentile(clock, 10):.2f}, p90 {np.percentile(clock, 90):.2f}")
+true_inliers = float(cnt.sum().item())
+print(f"true inliers (sum of the counts): {true_inliers:.4g} = {true_inliers / max(pops.sum(), 1):.3f} of the points popped; the rest passed tier 1 and failed the exact test")
 print(f"exact tier: {pops.sum():.4g} points popped in {slots.sum():.4g} lane slots -> lane utilisation {pops.sum() / max(slots.sum(), 1):.3f}")
 edges = [0, 2048, 4096, 6144, 8192, 16384, 32768, 65536, 1 << 30]
 for lo, hi in zip(edges[:-1], edges[1:]):
