@@ -413,8 +413,10 @@ int sfm_harris_cornerness(const double* sobel_x, const double* sobel_y, int64_t 
 int sfm_nms_inplace(double* image, int64_t height, int64_t width, void* stream);
 
 /* The same suppression as a parallel fixpoint (fast path): call sfm_nms_round repeatedly on a zero-initialised
- * state array (dev uint8 [height,width]: 0 unknown, 1 survives, 2 suppressed) until *unresolved (dev int32, zeroed
- * by the caller before each round) stays 0, then sfm_nms_finalize zeroes the suppressed pixels of `image` in place.
+ * state array (dev uint8 [height,width]; bits 0-1: 0 unknown, 1 survives, 2 suppressed; bits 4-7 of an unknown pixel:
+ * which raster-earlier neighbours are larger; a zero byte: not looked at yet — the first round classifies every pixel
+ * from the image, the following ones read state bytes only) until *unresolved (dev int32, zeroed by the caller
+ * before each round) stays 0, then sfm_nms_finalize zeroes the suppressed pixels of `image` in place.
  * The number of rounds is the longest chain of strictly increasing raster-earlier neighbours (a handful on natural
  * images); the result is identical to sfm_nms_inplace. */
 int sfm_nms_round(const double* image, uint8_t* state, int64_t height, int64_t width, int32_t* unresolved,

@@ -12,6 +12,7 @@
 #include <stdint.h>
 
 #include "sfm_common.h"
+#include "sfm_math.h"
 
 namespace {
 
@@ -69,11 +70,16 @@ __global__ __launch_bounds__(1024) void nms_inplace_kernel(double* image, int64_
             const int64_t c = t - 2 * r;
             const double v = image[r * w + c];
             double top = v;
+            bool any_nan = v != v;   // np.amax propagates a NaN: `pixel < nan` is false, a window with a NaN keeps its centre
             const int64_t r0 = max((int64_t)0, r - 1), r1 = min(h - 1, r + 1);
             const int64_t c0 = max((int64_t)0, c - 1), c1 = min(w - 1, c + 1);
             for (int64_t rr = r0; rr <= r1; ++rr)
-                for (int64_t cc = c0; cc <= c1; ++cc) top = fmax(top, image[rr * w + cc]);
-            if (v < top) image[r * w + c] = 0.0;
+                for (int64_t cc = c0; cc <= c1; ++cc) {
+                    const double x = image[rr * w + cc];
+                    any_nan |= x != x;
+                    top = fmax(top, x);
+                }
+            if (!any_nan && v < top) image[r * w + c] = 0.0;
         }
         __syncthreads();  // workgroup-scope visibility of the stores: the whole sweep runs on one CU
     }
@@ -87,52 +93,97 @@ __global__ __launch_bounds__(1024) void nms_inplace_kernel(double* image, int64_
 // Dependencies only point to strictly larger earlier neighbours, so they form a DAG; each round resolves every
 // pixel whose larger earlier neighbours are resolved (states only move unknown -> alive/dead, so reading a stale
 // "unknown" merely postpones a decision).  Rounds needed = longest such chain: a handful on natural images.
-// state: 0 unknown, 1 alive, 2 dead.  unresolved[0] receives the number of pixels still unknown after the round.
-__global__ void nms_round_kernel(const double* __restrict__ image, uint8_t* state, int64_t h, int64_t w,
-                                 int32_t* __restrict__ unresolved) {
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// state byte: bits 0-1  0 unknown, 1 alive, 2 dead;  bits 4-7 (unknown pixels) which raster-earlier neighbours are larger — left,
+// upper left, upper, upper right.  A ZERO byte is a pixel no round has looked at yet: the first round on a zero-initialised
+// state CLASSIFIES every pixel from the image (dead by a later neighbour / alive with no larger earlier neighbour / unknown with
+// its mask); every further round reads state bytes only — one per larger earlier neighbour of a pixel still unknown — and
+// never the image again.  (Until round 5 every round re-read the 3 x 3 doubles of every unknown pixel, and since the unknown
+// pixels are scattered nearly every wave still had one: rounds 1-4 of a 1080p image took 116, 105, 99 and 70 us with 12 %, 5 %,
+// 2 % and 0.6 % of the pixels unknown.)  A thread owns four consecutive pixels of a row: the classification loads a 3 x 6
+// window for them instead of 4 x 9 values.  unresolved[0] receives the number of pixels still unknown after the round.
+constexpr int kNmsPixels = 4;
+__global__ __launch_bounds__(256) void nms_round_kernel(const double* __restrict__ image, uint8_t* state, int64_t h, int64_t w,
+                                                        int32_t* __restrict__ unresolved) {
+    __shared__ int block_pending;
+    if (threadIdx.x == 0) block_pending = 0;
+    __syncthreads();
+    const int64_t c0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * kNmsPixels;
     const int64_t r = blockIdx.y;
     int pending = 0;
-    if (c < w && state[r * w + c] == 0) {
-        const double v = image[r * w + c];
-        bool dead = false;
-        // raster-later neighbours: original values
-        if (c + 1 < w && image[r * w + c + 1] > v) dead = true;
-        if (r + 1 < h) {
-            if (c > 0 && image[(r + 1) * w + c - 1] > v) dead = true;
-            if (image[(r + 1) * w + c] > v) dead = true;
-            if (c + 1 < w && image[(r + 1) * w + c + 1] > v) dead = true;
+    if (c0 < w) {
+        uint8_t st[kNmsPixels];
+        bool fresh = false, open = false;
+#pragma unroll
+        for (int k = 0; k < kNmsPixels; ++k) {
+            st[k] = c0 + k < w ? state[r * w + c0 + k] : (uint8_t)2;
+            fresh |= st[k] == 0;
+            open |= (st[k] & 3) == 0;
         }
-        // raster-earlier neighbours: only survivors count
-        auto earlier = [&](int64_t rr, int64_t cc) {
-            if (image[rr * w + cc] > v) {
-                const uint8_t st = state[rr * w + cc];
-                if (st == 1) dead = true;
-                else if (st == 0) pending = 1;
+        if (fresh) {
+            // rows r - 1 .. r + 1, columns c0 - 1 .. c0 + 4; outside the image: -inf (never larger than anything)
+            double win[3][kNmsPixels + 2];
+#pragma unroll
+            for (int dr = 0; dr < 3; ++dr)
+#pragma unroll
+                for (int dc = 0; dc < kNmsPixels + 2; ++dc) {
+                    const int64_t rr = r + dr - 1, cc = c0 + dc - 1;
+                    win[dr][dc] = (rr >= 0 && rr < h && cc >= 0 && cc < w) ? image[rr * w + cc] : -INFINITY;
+                }
+#pragma unroll
+            for (int k = 0; k < kNmsPixels; ++k) {
+                if (st[k] != 0) continue;   // (a pixel beyond the row, or — never by the protocol — one already classified)
+                const double v = win[1][k + 1];
+                bool any_nan = false;   // a NaN anywhere in the window (a NaN pixel is never zeroed, so it stays one): np.amax is NaN,
+#pragma unroll                          // `pixel < nan` is false and the centre survives whatever else the window holds
+                for (int dr = 0; dr < 3; ++dr)
+#pragma unroll
+                    for (int dc = 0; dc < 3; ++dc) any_nan |= win[dr][k + dc] != win[dr][k + dc];
+                if (any_nan) {
+                    state[r * w + c0 + k] = 1;
+                    continue;
+                }
+                const bool dead = (win[1][k + 2] > v) | (win[2][k] > v) | (win[2][k + 1] > v) | (win[2][k + 2] > v);   // later: original values
+                const unsigned mask = (win[1][k] > v ? 1u : 0u) | (win[0][k] > v ? 2u : 0u) | (win[0][k + 1] > v ? 4u : 0u) |
+                                      (win[0][k + 2] > v ? 8u : 0u);                                                  // earlier: only survivors will count
+                const uint8_t now = dead ? (uint8_t)2 : (mask == 0u ? (uint8_t)1 : (uint8_t)(mask << 4));
+                state[r * w + c0 + k] = now;
+                pending += (now & 3) == 0 ? 1 : 0;
             }
-        };
-        if (c > 0) earlier(r, c - 1);
-        if (r > 0) {
-            if (c > 0) earlier(r - 1, c - 1);
-            earlier(r - 1, c);
-            if (c + 1 < w) earlier(r - 1, c + 1);
-        }
-        if (dead) {
-            state[r * w + c] = 2;
-            pending = 0;
-        } else if (!pending) {
-            state[r * w + c] = 1;
+        } else if (open) {
+#pragma unroll
+            for (int k = 0; k < kNmsPixels; ++k) {
+                if ((st[k] & 3) != 0) continue;
+                const int64_t c = c0 + k;
+                const unsigned mask = st[k] >> 4;
+                bool dead = false, wait = false;
+                auto earlier = [&](unsigned bit, int64_t rr, int64_t cc) {
+                    if (mask & bit) {   // (the mask is only ever set for neighbours inside the image)
+                        const uint8_t q = state[rr * w + cc] & 3;
+                        dead |= q == 1;
+                        wait |= q == 0;
+                    }
+                };
+                earlier(1u, r, c - 1);
+                earlier(2u, r - 1, c - 1);
+                earlier(4u, r - 1, c);
+                earlier(8u, r - 1, c + 1);
+                if (dead) state[r * w + c] = 2;
+                else if (!wait) state[r * w + c] = 1;
+                else pending += 1;
+            }
         }
     }
-    // what is left: one add per BLOCK with pending pixels (one per wave — 32 000 atomics on one word in the early rounds of a
-    // 1080p image — took 94 us a round where the stencil itself takes ~10: profiles/r05/README.md)
-    const int left = __syncthreads_count(pending != 0);
-    if (threadIdx.x == 0 && left != 0) atomicAdd(unresolved, left);
+    // what is left: one add per wave into LDS, one per BLOCK with pending pixels on the counter (one per wave — 32 000 atomics on
+    // one word in the early rounds of a 1080p image — took 94 us a round: profiles/r05/README.md)
+    const int wave_pending = sfm::wave_sum(pending);
+    if ((threadIdx.x & (kWave - 1)) == 0 && wave_pending != 0) atomicAdd(&block_pending, wave_pending);
+    __syncthreads();
+    if (threadIdx.x == 0 && block_pending != 0) atomicAdd(unresolved, block_pending);
 }
 
 __global__ void nms_finalize_kernel(double* __restrict__ image, const uint8_t* __restrict__ state, int64_t count) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count && state[i] != 1) image[i] = 0.0;
+    if (i < count && (state[i] & 3) != 1) image[i] = 0.0;
 }
 
 __global__ void zero_counter_kernel(int32_t* counter) { *counter = 0; }
@@ -228,8 +279,8 @@ int sfm_nms_round(const double* image, uint8_t* state, int64_t height, int64_t w
                   void* stream) {
     if (height <= 0 || width <= 0 || height > 65535) return fail(SFM_EINVAL, "sfm_nms_round: bad size");
     if (!image || !state || !unresolved) return fail(SFM_EINVAL, "sfm_nms_round: null pointer");
-    SFM_REQUIRE_GRID("sfm_nms_round", width, 256, 256, height);
-    hipLaunchKernelGGL(nms_round_kernel, dim3(grid_for(width, 256), (unsigned)height), dim3(256), 0,
+    SFM_REQUIRE_GRID("sfm_nms_round", (width + kNmsPixels - 1) / kNmsPixels, 256, 256, height);
+    hipLaunchKernelGGL(nms_round_kernel, dim3(grid_for((width + kNmsPixels - 1) / kNmsPixels, 256), (unsigned)height), dim3(256), 0,
                        (hipStream_t)stream, image, state, height, width, unresolved);
     return check_launch("nms_round_kernel");
 }

@@ -93,10 +93,18 @@ def _strongest_indices_device(suppressed: torch.Tensor, num_corners: int) -> np.
     return nonzero[order[:keep]]
 
 
+_NARROW = (np.uint8, np.int8, np.int16, np.int32, np.float32)   # every value is a float64: widened on the device, bit for bit what NumPy's astype gives
+
+
 def _image_tensor(image: np.ndarray) -> torch.Tensor:
+    """The image as float64 on the device.  An 8 / 16 / 32-bit image travels in its own dtype (a 1080p uint8 frame: 2 MB instead
+    of 16.6 MB over PCIe, a third of the whole call) and is widened there."""
     if image.ndim != 2:
         raise ValueError("Only 2D single channel images are supported")
-    device.require_gpu()
+    dev = device.require_gpu()
+    image = np.asarray(image)
+    if image.dtype.type in _NARROW:
+        return torch.as_tensor(np.ascontiguousarray(image)).to(dev).to(torch.float64)
     return device.to_device(np.ascontiguousarray(image, dtype=np.float64))
 
 

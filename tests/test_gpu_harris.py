@@ -91,6 +91,26 @@ def test_nms_and_detector_vs_oracle_random(shape, seed):
             np.testing.assert_array_equal(harris._calculate_cornerness_image(photo, bs, k), ho.cornerness_image(photo, bs, k))
 
 
+@pytest.mark.parametrize("dtype", [np.uint8, np.int8, np.int16, np.int32, np.float32, np.uint16, np.int64, np.float64])
+def test_detector_image_dtypes(dtype):
+    """An image of any dtype gives the corners of its float64 copy (narrow types are widened on the device, the others on the
+    host: both exact) — and those of the oracle, which converts like the reference (harris_detector.py:56 works on the array as
+    it comes; its Sobel correlation accumulates in float64)."""
+    rng = np.random.default_rng(11)
+    info = np.iinfo(dtype) if np.issubdtype(dtype, np.integer) else None
+    if info is not None:
+        img = rng.integers(max(info.min, -3000), min(info.max, 3000) + 1, size=(90, 120)).astype(dtype)
+    else:
+        img = (rng.random((90, 120)) * 255).astype(dtype)
+    view = img[:, ::-1]                                      # not contiguous
+    for im in (img, view):
+        got = harris.detect_harris_corners(im, 80)
+        wide = harris.detect_harris_corners(np.ascontiguousarray(im, dtype=np.float64), 80)
+        assert [(c.x, c.y) for c in got] == [(c.x, c.y) for c in wide]
+        pts, _ = ho.detect_harris_corners(np.ascontiguousarray(im, dtype=np.float64), 80)
+        np.testing.assert_array_equal(np.array([[c.x, c.y] for c in got]).reshape(-1, 2), pts)
+
+
 def test_nms_fixpoint_equals_wavefront_and_oracle():
     """Both device formulations of the in-place raster-order suppression agree with the sequential oracle,
     including adversarial monotone ramps (dependency chains as long as the image) that force the wavefront fallback."""
@@ -102,7 +122,12 @@ def test_nms_fixpoint_equals_wavefront_and_oracle():
     rng = np.random.default_rng(5)
     cases = [rng.integers(0, 4, (37, 53)).astype(float), rng.random((64, 200)),
              np.add.outer(np.arange(40.0), np.arange(150.0))[::-1, ::-1].copy(),      # increasing towards the origin
-             np.add.outer(np.arange(40.0), np.arange(150.0)), np.zeros((5, 7)), np.ones((9, 9))]
+             np.add.outer(np.arange(40.0), np.arange(150.0)), np.zeros((5, 7)), np.ones((9, 9)),
+             # widths around the four pixels a thread of the round kernel owns, single rows and columns, NaN and inf pixels
+             rng.integers(0, 5, (6, 1)).astype(float), rng.integers(0, 5, (1, 6)).astype(float), rng.integers(0, 5, (9, 2)).astype(float),
+             rng.integers(0, 5, (11, 3)).astype(float), rng.integers(0, 5, (13, 5)).astype(float), rng.integers(0, 9, (33, 1023)).astype(float),
+             np.where(rng.random((30, 41)) < 0.05, np.nan, rng.integers(0, 5, (30, 41)).astype(float)),
+             np.where(rng.random((30, 41)) < 0.05, np.inf, rng.integers(0, 5, (30, 41)).astype(float))]
     for img in cases:
         want = img.copy()
         ho.non_max_suppress(want)
