@@ -56,7 +56,7 @@ typedef struct sfm_select_result {
 
 /* Version of this interface: libsfm_hip.so reports the one it was compiled from (sfm_abi_version), the Python binding
  * and the torch op library (sfm_torch_ops_abi_version) refuse a library of another version. */
-#define SFM_ABI_VERSION 11
+#define SFM_ABI_VERSION 12
 
 const char* sfm_last_error(void);
 int sfm_abi_version(void);
@@ -429,6 +429,16 @@ int sfm_nms_finalize(double* image, const uint8_t* state, int64_t height, int64_
  * value: dev f64 [capacity]. */
 int sfm_compact_nonzero(const double* image, int64_t count, int32_t capacity, int32_t* counter, int32_t* index,
                         double* value, void* stream);
+
+/* (new, ABI 12) Of the candidates sfm_compact_nonzero left — value / index: dev [capacity], *found: dev int32, the counter it
+ * wrote (read on the device: no host round trip in between; min(*found, capacity) candidates are looked at) — those that can be
+ * among the m largest values: every candidate at or above the m-th largest (ties included; a NaN of either sign counts as the
+ * largest value there is), plus at most the ones that share the m-th's sign, exponent and top twelve mantissa bits.  What
+ * np.argsort of harris_detector.py:32-42 needs of a 1080p image is then num_corners + a few pairs instead of 220 000.
+ * workspace: dev, 8192 int32 (zeroed by the call).  *counter_out receives the number kept (may exceed capacity_out; only that many slots are written);
+ * fewer than m candidates: all are kept. */
+int sfm_prune_top(const double* value, const int32_t* index, const int32_t* found, int32_t capacity, int32_t m, void* workspace,
+                  int32_t capacity_out, int32_t* counter_out, int32_t* index_out, double* value_out, void* stream);
 
 /* HOST: exact replay of CPython's random.shuffle as used by ransac.py:59-64.  `mt_state` is the 624-word
  * MT19937 state and `*mt_index` its position (random.getstate()[1]); both are advanced.  The cumulative

@@ -16,7 +16,7 @@ FIT_DEGENERATE = 1
 MATCH_NCC, MATCH_SSD = 0, 1
 PATCH_PLAIN, PATCH_MEAN_REMOVED, PATCH_RAW64 = 0, 1, 2
 INT64_MAX = (1 << 63) - 1
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 def match_ssd_int(bits: int, signed: bool) -> int:
@@ -151,6 +151,7 @@ SIGNATURES = {
     "sfm_nms_round": [_P, _P, _I64, _I64, _P, _P],
     "sfm_nms_finalize": [_P, _P, _I64, _I64, _P],
     "sfm_compact_nonzero": [_P, _I64, C.c_int32, _P, _P, _P, _P],
+    "sfm_prune_top": [_P, _P, _P, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, _P, _P],
     "sfm_pyshuffle_table": [_P, _P, _I64, _I64, _P, _P, _I64, _P],
     "sfm_score_kernel_choice": [_I64, _I64, _I64],
 }

@@ -235,6 +235,123 @@ __global__ __launch_bounds__(256) void compact_nonzero_kernel(const double* __re
     }
 }
 
+
+// Pruning of the compacted maxima to the ones that can be among the m largest (the top-k selection of harris_detector.py:32-42
+// needs num_corners + 1 of them; a 1080p texture leaves 220 000, and copying them back — 2.6 MB — with the host's partition of
+// them was half of the whole detector call).  A value's bit pattern, mapped so that unsigned order is numeric order (a NaN of
+// either sign on top, so the host still sees it and takes the reference's literal expression), is cut into two 12-bit digits:
+// a histogram of the first digit (sign + exponent) finds the digit d1 the m-th largest value has, a histogram of the second
+// digit (the top twelve mantissa bits) among the candidates with that d1 finds its d2, and a second compaction keeps the
+// candidates at or above (d1, d2): everything at or above the m-th largest value, ties included, plus at most the ones within
+// 2^-12 of it.  Both histograms are counted in LDS per block and merged with one atomic per block and non-empty bin (a global
+// histogram of 2^16 keys, the first version, took 280 us for the 220 000 maxima of a 1080p image: thousands of them share a key,
+// and atomics on one word serialise).
+constexpr int kPruneBins = 4096;
+SFM_DEVICE unsigned long long prune_order(double v) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    if (v != v) return ~0ull;
+    return (bits >> 63) ? ~bits : (bits | 0x8000000000000000ull);
+}
+SFM_DEVICE unsigned prune_digit1(double v) { return (unsigned)(prune_order(v) >> 52); }
+SFM_DEVICE unsigned prune_digit2(double v) { return (unsigned)(prune_order(v) >> 40) & (kPruneBins - 1); }
+// By a whole block of 256 threads: the largest bin b with at least m entries in bins >= b (0 when there are fewer than m
+// altogether: keep everything), and how many entries the bins above b hold.
+SFM_DEVICE void prune_threshold(const int32_t* __restrict__ hist, int m, int& bin, int& above) {
+    __shared__ int chunk[256];
+    __shared__ int result[2];
+    const int t = threadIdx.x;
+    int own = 0;
+#pragma unroll
+    for (int k = 0; k < kPruneBins / 256; ++k) own += hist[(kPruneBins / 256) * t + k];
+    chunk[t] = own;
+    if (t == 0) result[0] = 0, result[1] = 0;
+    __syncthreads();
+    int higher = 0;   // entries in the chunks above this thread's
+    for (int c = t + 1; c < 256; ++c) higher += chunk[c];
+    if (higher < m && higher + own >= m) {   // at most one thread: the m-th largest lies in this chunk
+        int running = higher;
+        for (int k = kPruneBins / 256 - 1; k >= 0; --k) {
+            const int here = hist[(kPruneBins / 256) * t + k];
+            if (running + here >= m) {
+                result[0] = (kPruneBins / 256) * t + k;
+                result[1] = running;
+                break;
+            }
+            running += here;
+        }
+    }
+    __syncthreads();
+    bin = result[0];
+    above = result[1];
+    __syncthreads();   // (the shared words are reused by a second call)
+}
+// LEVEL 1: digit 1 of every candidate; LEVEL 2: digit 2 of the candidates whose digit 1 is the threshold's
+template <int LEVEL>
+__global__ __launch_bounds__(256) void prune_histogram_kernel(const double* __restrict__ value, const int32_t* __restrict__ found,
+                                                              int32_t capacity, int32_t m, const int32_t* __restrict__ hist1,
+                                                              int32_t* __restrict__ hist) {
+    __shared__ int bins[kPruneBins];
+    for (int k = threadIdx.x; k < kPruneBins; k += 256) bins[k] = 0;
+    int d1 = 0, above = 0;
+    if (LEVEL == 2) prune_threshold(hist1, m, d1, above);
+    __syncthreads();
+    const int n = min(*found, capacity);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const double v = value[i];
+        if (LEVEL == 1) atomicAdd(&bins[prune_digit1(v)], 1);
+        else if (prune_digit1(v) == (unsigned)d1) atomicAdd(&bins[prune_digit2(v)], 1);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < kPruneBins; k += 256)
+        if (bins[k] != 0) atomicAdd(hist + k, bins[k]);
+}
+__global__ __launch_bounds__(256) void prune_filter_kernel(const double* __restrict__ value, const int32_t* __restrict__ index,
+                                                           const int32_t* __restrict__ found, int32_t capacity, int32_t m,
+                                                           const int32_t* __restrict__ hist1, const int32_t* __restrict__ hist2,
+                                                           int32_t capacity_out, int32_t* __restrict__ counter_out,
+                                                           int32_t* __restrict__ index_out, double* __restrict__ value_out) {
+    __shared__ int wave_total[256 / kWave];
+    __shared__ int block_start;
+    int d1, above1, d2, above2;
+    prune_threshold(hist1, m, d1, above1);
+    prune_threshold(hist2, m - above1, d2, above2);
+    const unsigned long long T = ((unsigned long long)d1 << 52) | ((unsigned long long)d2 << 40);
+    const int n = min(*found, capacity);
+    if (n <= 0) return;   // (the same for every thread of the launch)
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int stride = gridDim.x * blockDim.x;
+    const int first = blockIdx.x * blockDim.x + (threadIdx.x - lane);
+    int mine = 0;
+    for (int base = first; base < n; base += stride) {
+        const int i = base + lane;
+        mine += (int)__popcll(__ballot(i < n && prune_order(value[min(i, n - 1)]) >= T));
+    }
+    if (lane == 0) wave_total[wave] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int total = 0;
+#pragma unroll
+        for (int w = 0; w < 256 / kWave; ++w) total += wave_total[w];
+        block_start = total != 0 ? atomicAdd(counter_out, total) : 0;
+    }
+    __syncthreads();
+    int slot0 = block_start;
+    for (int w = 0; w < wave; ++w) slot0 += wave_total[w];
+    for (int base = first; base < n; base += stride) {
+        const int i = base + lane;
+        const double v = value[min(i, n - 1)];
+        const bool keep = i < n && prune_order(v) >= T;
+        const unsigned long long votes = __ballot(keep);
+        if (votes == 0ull) continue;
+        const int slot = slot0 + __builtin_amdgcn_mbcnt_hi((unsigned)(votes >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)votes, 0));
+        if (keep && slot < capacity_out) {
+            index_out[slot] = index[i];
+            value_out[slot] = v;
+        }
+        slot0 += (int)__popcll(votes);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -307,6 +424,27 @@ int sfm_compact_nonzero(const double* image, int64_t count, int32_t capacity, in
         hipLaunchKernelGGL(compact_nonzero_kernel, dim3(grid_stride(count, 256, 1024)), dim3(256), 0, st, image, count,
                            capacity, counter, index, value);
     return check_launch("compact_nonzero_kernel");
+}
+
+int sfm_prune_top(const double* value, const int32_t* index, const int32_t* found, int32_t capacity, int32_t m, void* workspace,
+                  int32_t capacity_out, int32_t* counter_out, int32_t* index_out, double* value_out, void* stream) {
+    if (capacity < 0 || capacity_out < 0 || m < 1) return fail(SFM_EINVAL, "sfm_prune_top: bad size");
+    if (!found || !workspace || !counter_out || (capacity > 0 && (!value || !index)) || (capacity_out > 0 && (!index_out || !value_out)))
+        return fail(SFM_EINVAL, "sfm_prune_top: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    int32_t* hist1 = reinterpret_cast<int32_t*>(workspace);   // the two histograms of kPruneBins counters
+    int32_t* hist2 = hist1 + kPruneBins;
+    if (hipMemsetAsync(hist1, 0, (size_t)(2 * kPruneBins) * sizeof(int32_t), st) != hipSuccess)
+        return fail(SFM_EHIP, "sfm_prune_top: hipMemsetAsync failed");
+    hipLaunchKernelGGL(zero_counter_kernel, dim3(1), dim3(1), 0, st, counter_out);
+    if (capacity > 0) {
+        const unsigned blocks = (unsigned)grid_stride(capacity, 256, 256);
+        hipLaunchKernelGGL(prune_histogram_kernel<1>, dim3(blocks), dim3(256), 0, st, value, found, capacity, m, hist1, hist1);
+        hipLaunchKernelGGL(prune_histogram_kernel<2>, dim3(blocks), dim3(256), 0, st, value, found, capacity, m, hist1, hist2);
+        hipLaunchKernelGGL(prune_filter_kernel, dim3(blocks), dim3(256), 0, st, value, index, found, capacity, m, hist1, hist2,
+                           capacity_out, counter_out, index_out, value_out);
+    }
+    return check_launch("prune_filter_kernel");
 }
 
 }  // extern "C"

@@ -56,36 +56,50 @@ def _strongest_indices(suppressed: np.ndarray, num_corners: int) -> np.ndarray:
 
 
 _COMPACT_CAPACITY = 1 << 20   # (index, value) slots of the device compaction: 12 MB; integer-valued 1080p images leave ~150 000 maxima
+_PRUNE_WORDS = 8192           # the two digit histograms of sfm_prune_top
 
 
 def _strongest_indices_device(suppressed: torch.Tensor, num_corners: int) -> np.ndarray:
-    """``_strongest_indices`` without copying the image back: the few non-zero pixels are compacted on the device
-    (``sfm_compact_nonzero``) and only they travel.  Falls back to the full image when exact ties among the values
-    that matter make the reference's order depend on NumPy's sort of the whole array, or when more than
-    ``_COMPACT_CAPACITY`` pixels survive."""
+    """``_strongest_indices`` without copying the image back: the non-zero pixels are compacted on the device
+    (``sfm_compact_nonzero``), pruned there to the ones that can be among the ``num_corners + 1`` largest
+    (``sfm_prune_top``: everything at or above that value, ties included) and only they travel, with the two counters, in ONE
+    read-back.  Falls back to the full image when exact ties among the values that matter make the reference's
+    order depend on NumPy's sort of the whole array, when a NaN survives, or when more than ``_COMPACT_CAPACITY`` pixels do."""
     lib = _native.load()
     count = suppressed.numel()
     capacity = min(count, _COMPACT_CAPACITY)
     dev = suppressed.device
-    counter = torch.empty((1,), dtype=torch.int32, device=dev)
     index = torch.empty((max(capacity, 1),), dtype=torch.int32, device=dev)
     value = torch.empty((max(capacity, 1),), dtype=torch.float64, device=dev)
-    check(lib.sfm_compact_nonzero(suppressed.data_ptr(), count, capacity, counter.data_ptr(), index.data_ptr(),
+    # one buffer: [found, kept, -, -][room values (f64)][room indices][histograms]; its head is what travels
+    room = max(2048, 2 * (num_corners + 1))
+    words = 4 + 3 * room
+    buf = torch.empty((words + _PRUNE_WORDS,), dtype=torch.int32, device=dev)
+    check(lib.sfm_compact_nonzero(suppressed.data_ptr(), count, capacity, buf[0:].data_ptr(), index.data_ptr(),
                                   value.data_ptr(), device._stream()), "sfm_compact_nonzero")
-    found = int(counter.cpu()[0])
+    check(lib.sfm_prune_top(value.data_ptr(), index.data_ptr(), buf[0:].data_ptr(), capacity, num_corners + 1,
+                            buf[words:].data_ptr(), room, buf[1:].data_ptr(), buf[4 + 2 * room:].data_ptr(),
+                            buf[4:].data_ptr(), device._stream()), "sfm_prune_top")
+    host = buf[:words].cpu().numpy()
+    found, kept = int(host[0]), int(host[1])
     if found == 0:
         return np.zeros(0, dtype=np.int64)
     if found > capacity:
         return _strongest_indices(suppressed.cpu().numpy(), num_corners)
-    nonzero = index[:found].cpu().numpy().astype(np.int64)  # slot order is arbitrary (atomics)
-    values = value[:found].cpu().numpy()
+    if kept <= room:   # the leaders (and whatever lies within 2^-12 of the last one): all that the selection below can pick from
+        values = host[4:4 + 2 * room].view(np.float64)[:kept]
+        nonzero = host[4 + 2 * room:4 + 2 * room + kept].astype(np.int64)  # slot order is arbitrary (atomics)
+    else:              # (more than the buffer next to the last leader: e.g. an image whose maxima are all equal)
+        nonzero = index[:found].cpu().numpy().astype(np.int64)
+        values = value[:found].cpu().numpy()
     if bool(np.isnan(values).any()):
         return _strongest_indices(suppressed.cpu().numpy(), num_corners)
     # the keep + 1 largest, ordered by (value descending, flat index ascending) — what a stable sort of the
     # raster-ordered non-zeros gives; a selection (O(n)) instead of a full sort, then a sort of those few
+    have = len(values)
     keep = min(num_corners, found)
-    m = min(keep + 1, found)
-    cand = np.argpartition(-values, m - 1)[:m] if m < found else np.arange(found)
+    m = min(keep + 1, have)
+    cand = np.argpartition(-values, m - 1)[:m] if m < have else np.arange(have)
     order = cand[np.lexsort((nonzero[cand], -values[cand]))]
     head = values[order]
     if bool(np.any(head[1:] == head[:-1])):

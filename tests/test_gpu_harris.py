@@ -168,3 +168,69 @@ def test_compact_nonzero_and_topk_equal_full_image_path():
             got = hd._strongest_indices_device(t, k)
             want = hd._strongest_indices(img, k)
             np.testing.assert_array_equal(got, want)
+
+
+def test_prune_top_keeps_every_leader():
+    """sfm_prune_top: whatever the values — negative, subnormal, huge, equal, NaN of either sign — every candidate at or above
+    the m-th largest is kept, nothing is invented, and with fewer than m candidates all of them are.  Then the detector's
+    selection on images whose maxima crowd one key (all equal, or all within a factor 1.06 of each other: more than the
+    pruning buffer) and on one whose leaders straddle a key boundary."""
+    import ctypes as C
+
+    from structure_from_motion_amd import _native, device
+    from structure_from_motion_amd._native import check
+    from structure_from_motion_amd.harris import harris_detector as hd
+
+    lib = _native.load()
+    rng = np.random.default_rng(21)
+
+    def prune(values, m, capacity_out=1 << 15, found=None):
+        n = len(values)
+        v = device.to_device(np.asarray(values, dtype=np.float64))
+        idx = device.to_device(np.arange(n, dtype=np.int32) * 3 + 1, dtype=torch.int32)
+        cnt = device.to_device(np.array([n if found is None else found, 0], dtype=np.int32), dtype=torch.int32)
+        ws = torch.empty((8192,), dtype=torch.int32, device=v.device)
+        out_i = torch.empty((max(capacity_out, 1),), dtype=torch.int32, device=v.device)
+        out_v = torch.empty((max(capacity_out, 1),), dtype=torch.float64, device=v.device)
+        check(lib.sfm_prune_top(v.data_ptr(), idx.data_ptr(), cnt[0:].data_ptr(), n, m, ws.data_ptr(), capacity_out, cnt[1:].data_ptr(),
+                                out_i.data_ptr(), out_v.data_ptr(), device._stream()), "sfm_prune_top")
+        kept = int(cnt.cpu()[1])
+        return kept, out_i[:min(kept, capacity_out)].cpu().numpy(), out_v[:min(kept, capacity_out)].cpu().numpy()
+
+    neg_nan = np.frombuffer(np.array([0xFFF8000000000001], dtype=np.uint64).tobytes(), dtype=np.float64)[0]
+    sets = [rng.random(5000), rng.standard_normal(5000) * 1e6, np.exp(rng.uniform(-700, 700, 5000)) * rng.choice([-1, 1], 5000),
+            np.concatenate([rng.random(3000), np.full(40, 2.5), np.full(40, 2.5000000001)]), np.full(3000, 7.0),
+            np.concatenate([rng.random(2000) * 1e-310, [0.0, -0.0]]), np.concatenate([rng.random(999), [np.nan]]),
+            np.concatenate([rng.random(999), [neg_nan, np.inf, -np.inf]]), np.array([3.0]), rng.integers(0, 40, 20000).astype(float)]
+    for values in sets:
+        for m in (1, 2, 51, 601, 100000):
+            kept, gi, gv = prune(values, m)
+            order = np.sort(values[~np.isnan(values)])[::-1]
+            nans = int(np.isnan(values).sum())            # a NaN counts as the largest value there is (the host then takes the literal path)
+            floor = np.inf if m <= nans else (order[m - nans - 1] if m - nans <= len(order) else -np.inf)
+            must = np.flatnonzero(np.isnan(values) | ((values >= floor) & (m > nans)))
+            assert kept == len(gi) and len(set(gi.tolist())) == kept                      # nothing twice
+            np.testing.assert_array_equal(values[(gi - 1) // 3].view(np.uint64), gv.view(np.uint64))   # pairs intact, bit for bit
+            assert set((must * 3 + 1).tolist()) <= set(gi.tolist()), (m, len(must), kept)
+            if m > len(values):
+                assert kept == len(values)
+    # the counter says how many would be kept even when they do not fit; a device-side `found` below the capacity bounds the scan
+    kept, gi, gv = prune(np.full(3000, 7.0), 10, capacity_out=100)
+    assert kept == 3000 and len(gi) == 100 and np.all(gv == 7.0)
+    kept, gi, _ = prune(np.arange(1000.0), 5, found=10)
+    assert kept >= 5 and set(gi.tolist()) <= {3 * i + 1 for i in range(10)} and {3 * i + 1 for i in range(5, 10)} <= set(gi.tolist())
+    kept, gi, _ = prune(np.arange(10.0), 5, found=0)
+    assert kept == 0
+    # argument checks
+    assert lib.sfm_prune_top(None, None, None, 4, 1, None, 4, None, None, None, None) == -1   # SFM_EINVAL
+    # the detector's selection through the pruning
+    flat = np.zeros((200, 300))
+    flat[::2, ::2] = 5.0                                   # 15 000 equal maxima: one key, ties among the leaders
+    crowded = np.zeros((300, 400))
+    crowded[::2, ::2] = 1.0 + rng.random((150, 200)) * 2e-4   # 30 000 maxima inside one key's range (2^-12): more than the pruning buffer
+    straddle = np.zeros((64, 64))
+    straddle.ravel()[rng.choice(4096, 700, replace=False)] = np.concatenate([np.linspace(1.9, 2.1, 350), rng.random(350)])
+    for img in (flat, crowded, straddle):
+        t = device.to_device(img)
+        for k in (1, 10, 349, 351, 600, 20000):
+            np.testing.assert_array_equal(hd._strongest_indices_device(t, k), hd._strongest_indices(img, k))
