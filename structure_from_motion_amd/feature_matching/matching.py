@@ -143,7 +143,6 @@ def match_brute_force(
     else:
         best, arg, second, has_second = _host_rows(features_a, features_b, score_function)
 
-    rows = list(range(len(features_a)))
     if len(features_b) == 0:
         # every heap of the reference is empty here (matching.py:55-65).  Its ratio filter drops empty heaps
         # (:84-97) and an empty feature list has no heap to index; otherwise it indexes heap[0] of an empty heap —
@@ -151,18 +150,22 @@ def match_brute_force(
         if len(features_a) == 0 or ValidationStrategy.RATIO_TEST in strategies:
             return []
         raise IndexError("list index out of range")
+    # plain Python numbers from here on (20 000 rows: NumPy scalars made the loops below three times as slow)
+    best_list = best.tolist() if isinstance(best, np.ndarray) else [_plain(v) for v in best]
+    arg_list = arg.tolist() if isinstance(arg, np.ndarray) else [int(v) for v in arg]
+    rows = range(len(features_a))
     if ValidationStrategy.RATIO_TEST in strategies and has_second:
         with np.errstate(divide="ignore", invalid="ignore"):
             passed = (np.asarray(best, dtype=np.float64) / np.asarray(second, dtype=np.float64)) <= ratio_test_threshold
-        rows = [a for a in rows if passed[a]]
+        rows = np.flatnonzero(passed).tolist()
     if ValidationStrategy.CROSSCHECK in strategies:
         claimant: Dict[int, int] = {}
         for a in rows:  # a strictly better score replaces the claimant, so the earliest wins ties
-            b = int(arg[a])
-            if b not in claimant or best[claimant[b]] > best[a]:
+            b = arg_list[a]
+            if b not in claimant or best_list[claimant[b]] > best_list[a]:
                 claimant[b] = a
-        rows = [a for a in rows if claimant[int(arg[a])] == a]
-    return [Match(a_index=a, b_index=int(arg[a]), match_score=_plain(best[a])) for a in rows]
+        rows = [a for a in rows if claimant[arg_list[a]] == a]
+    return [Match(a, arg_list[a], best_list[a]) for a in rows]
 
 
 def _plain(value):
