@@ -528,8 +528,9 @@ def widened_configs(torch):
         elif name.startswith("f2_"):
             row.update({"call_ms": wall_ms, "kernel_ms": None, "pixels": info["pixels"], "megapixels_per_s": info["pixels"] / wall_ms / 1e3,
                         "corners": info["corners"],
-                        "note": "whole detect_harris_corners call: image upload, Sobel x / y, cornerness, 12 NMS rounds + check, "
-                                "compaction, corner list read back (host-synchronous: wall clock)"})
+                        "note": "whole detect_harris_corners call: image upload (uint8, widened on the device), Sobel x / y, cornerness, "
+                                "12 NMS rounds + check, compaction, pruning to the leaders, their read-back, the Feature list "
+                                "(host-synchronous: wall clock)"})
         elif name.startswith("f4_"):
             row.update({"matches": info["matches"], "rounds": info["rounds"], "inliers_in": info["inliers_in"],
                         "note": "one block per pair runs the whole refit + re-score loop: latency-bound by construction"})

@@ -33,12 +33,12 @@ def _image_tensor(image: np.ndarray, integer_dtype=None) -> torch.Tensor:
         raise ValueError("the matcher works on single-channel (2-D) images")
     dev = device.require_gpu()
     if integer_dtype is None:
-        if image.dtype.type in _NARROW_FLOAT:
+        if image.dtype.type in _NARROW_FLOAT and image.dtype.isnative:
             return torch.as_tensor(np.ascontiguousarray(image)).to(dev).to(torch.float64)
         return device.to_device(np.ascontiguousarray(image, dtype=np.float64))
     # integer SSD: the pixels in the common dtype NumPy would promote both images to (value-preserving), then as int64 —
     # the two's-complement bit pattern for uint64, whose modular arithmetic is the same
-    if image.dtype.type in _NARROW_INT and np.can_cast(image.dtype, integer_dtype, casting="safe"):
+    if image.dtype.type in _NARROW_INT and image.dtype.isnative and np.can_cast(image.dtype, integer_dtype, casting="safe"):
         return torch.as_tensor(np.ascontiguousarray(image)).to(dev).to(torch.int64)   # value-preserving both ways
     wide = np.ascontiguousarray(image).astype(integer_dtype, copy=False)
     wide = wide.view(np.int64) if wide.dtype == np.uint64 else wide.astype(np.int64)

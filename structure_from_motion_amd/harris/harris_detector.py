@@ -117,7 +117,7 @@ def _image_tensor(image: np.ndarray) -> torch.Tensor:
         raise ValueError("Only 2D single channel images are supported")
     dev = device.require_gpu()
     image = np.asarray(image)
-    if image.dtype.type in _NARROW:
+    if image.dtype.type in _NARROW and image.dtype.isnative:
         return torch.as_tensor(np.ascontiguousarray(image)).to(dev).to(torch.float64)
     return device.to_device(np.ascontiguousarray(image, dtype=np.float64))
 

@@ -103,7 +103,8 @@ def test_detector_image_dtypes(dtype):
     else:
         img = (rng.random((90, 120)) * 255).astype(dtype)
     view = img[:, ::-1]                                      # not contiguous
-    for im in (img, view):
+    swapped = img.astype(img.dtype.newbyteorder())           # same values, foreign byte order (a no-op for one-byte types)
+    for im in (img, view, swapped):
         got = harris.detect_harris_corners(im, 80)
         wide = harris.detect_harris_corners(np.ascontiguousarray(im, dtype=np.float64), 80)
         assert [(c.x, c.y) for c in got] == [(c.x, c.y) for c in wide]

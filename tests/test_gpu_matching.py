@@ -376,3 +376,32 @@ def test_ssd_integer_edge_cases():
     got = _device_match.score_matrix(1, la, lb, feats(c), feats(c), 9).cpu().numpy()
     np.testing.assert_array_equal(got, mo.ssd_scores(la, lb, c, c, 9))                        # exact Python integers, reduced modulo 2^64
     np.testing.assert_array_equal(got, mo.ssd_scores_in_dtype(la, lb, c, c, 9))
+
+
+@pytest.mark.parametrize("name", ["uint8", "int8", "int16", "int32", "uint16", "float32", "float64"])
+def test_image_layouts_do_not_matter(name):
+    """Narrow images cross PCIe in their own dtype and are widened on the device; images that are not contiguous or carry a
+    foreign byte order take the host conversion.  Either way the scores are those of the plain contiguous image: NCC and SSD
+    (integer SSD in the image dtype's modular arithmetic) against the oracle, bit for bit."""
+    rng = np.random.default_rng(5)
+    dt = np.dtype(name)
+    H, W = 60, 90
+    if dt.kind in "iu":
+        info = np.iinfo(dt)
+        ia = rng.integers(info.min, info.max, (H, W), dtype=dt, endpoint=True)
+        ib = rng.integers(info.min, info.max, (H, W), dtype=dt, endpoint=True)
+    else:
+        ia, ib = (rng.random((H, W)) * 255).astype(dt), (rng.random((H, W)) * 255).astype(dt)
+    fa = np.column_stack([rng.integers(0, W, 70), rng.integers(0, H, 70)]).astype(np.float64)
+    fb = np.column_stack([rng.integers(0, W, 50), rng.integers(0, H, 50)]).astype(np.float64)
+    want_ssd = mo.ssd_scores_in_dtype(ia, ib, fa, fb, 5) if dt.kind in "iu" else mo.ssd_scores(ia, ib, fa, fb, 5)
+    want_ncc = mo.ncc_scores(ia, ib, fa, fb, 5)
+    wide_a, wide_b = np.zeros((H, 2 * W), dtype=dt), np.zeros((H, 2 * W), dtype=dt)
+    wide_a[:, ::2], wide_b[:, ::2] = ia, ib
+    layouts = [(ia, ib), (wide_a[:, ::2], wide_b[:, ::2]), (ia.astype(dt.newbyteorder()), ib.astype(dt.newbyteorder())),
+               (np.asfortranarray(ia), np.asfortranarray(ib))]
+    for a, b in layouts:
+        got = _device_match.score_matrix(1, a, b, feats(fa), feats(fb), 5).cpu().numpy()
+        np.testing.assert_array_equal(got, want_ssd)
+        got = _device_match.score_matrix(0, a, b, feats(fa), feats(fb), 5).cpu().numpy()
+        np.testing.assert_array_equal(got, want_ncc)

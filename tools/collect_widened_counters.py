@@ -28,7 +28,7 @@ GROUPS = [("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]),
           ("f64", ["SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"]),
           ("wait", ["SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU"])]
 OURS = ("pair_summary_kernel", "summary_combine_kernel", "patch_extract_kernel", "correlate_kernel", "cornerness_kernel", "nms_round_kernel",
-        "nms_finalize_kernel", "nms_inplace_kernel", "compact_nonzero_kernel", "refine_kernel", "cheirality_batched_kernel", "pose_vote_kernel",
+        "nms_finalize_kernel", "nms_inplace_kernel", "compact_nonzero_kernel", "prune_histogram_kernel", "prune_filter_kernel", "refine_kernel", "cheirality_batched_kernel", "pose_vote_kernel",
         "triangulate_selected_kernel")
 
 

@@ -67,7 +67,7 @@ def harris(height, width, corners=600, seed=5):
         return harris_detector.detect_harris_corners(image, num_corners=corners)   # (uploads the image, reads the corners back)
 
     return run, {"height": height, "width": width, "corners": corners, "pixels": float(height) * width,
-                 "kernel": "correlate_kernel x 2 + cornerness_kernel + nms_round_kernel x 12 + nms_finalize + compact_nonzero"}
+                 "kernel": "correlate_kernel x 2 + cornerness_kernel + nms_round_kernel x 12 + nms_finalize + compact_nonzero + prune_histogram x 2 + prune_filter"}
 
 
 def refine(n=50_000, h=2_000, rounds=1):
