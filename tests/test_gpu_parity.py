@@ -5,6 +5,8 @@ Bars: bit-exact for integer / index work (sample tables, inlier counts, inlier i
 selected hypothesis) and for element-wise fp64 values whose operation order is fixed (K-normalisation,
 SED); relative tolerances written next to each assertion for the iterative eigen/SVD routines and the
 order-dependent sums."""
+import os
+
 import numpy as np
 import pytest
 
@@ -943,9 +945,12 @@ def test_fused_batch_and_large_pass_random_sizes(dev, monkeypatch):
     VALU filter: every output bit for bit."""
     from structure_from_motion_amd._native import AGG_MEAN, AGG_RMS
 
-    rng = np.random.default_rng(2025)
+    # (a soak: SFM_SOAK_SHAPES=300 SFM_SOAK_N_MAX=40000 SFM_SOAK_H_MAX=3000 SFM_SOAK_SEED=7 — profiles/r05/soak_fused_passes.txt)
+    rng = np.random.default_rng(int(os.environ.get("SFM_SOAK_SEED", 2025)))
+    n_max, h_max = int(os.environ.get("SFM_SOAK_N_MAX", 3000)), int(os.environ.get("SFM_SOAK_H_MAX", 200))
     shapes = [(1, 8, 1), (1, 40, 33), (3, 31, 1), (2, 257, 64), (7, 1000, 65), (4, 2049, 31), (1, 4100, 97), (5, 640, 130)]
-    shapes += [(int(rng.integers(1, 9)), int(rng.integers(8, 3000)), int(rng.integers(1, 200))) for _ in range(8)]
+    shapes += [(int(rng.integers(1, 9)), int(rng.integers(8, n_max)), int(rng.integers(1, h_max)))
+               for _ in range(int(os.environ.get("SFM_SOAK_SHAPES", 8)))]
     saved = dev.default_score_options()
     try:
         for kernel in ("matrix", "filtered"):
