@@ -81,6 +81,9 @@
 #ifndef SFM_MATRIX_ABLATE
 #define SFM_MATRIX_ABLATE 0  // measurement builds only (WRONG results; tools/r04/ablate.sh): bit 0 no operand refills, bit 1 one matrix
 #endif                       // instruction instead of three, bit 2 one sign test instead of sixteen, bit 3 no queue push, bit 4 no fp16 subnormal operands
+#ifndef SFM_MATRIX_MASKED_EVAL
+#define SFM_MATRIX_MASKED_EVAL (-1)   // exact-tier evaluations under the execution mask of the lanes with a point: -1 by the size of the launch, 0 / 1 forced (A/B builds)
+#endif
 #ifndef SFM_MATRIX_E_IN_REGISTERS
 #define SFM_MATRIX_E_IN_REGISTERS 1   // E held in 18 VGPRs through the tier-1 loop (0: loaded where a burst of rounds starts — better while the
                                       // loop's registers were the constraint, 2.8 % slower at the bench size on the final kernel)
@@ -344,7 +347,7 @@ SFM_DEVICE int take_ticket(int32_t* counter) {
     return ticket;
 }
 
-template <bool ESTIMATE>
+template <bool ESTIMATE, bool MASKED>
 SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr, int units, int steps_per_unit, int wave, int unit,
                             uint32_t* const my_queue, int lane, unsigned item_id) {
     const Corr* __restrict__ pts = a.pts;
@@ -455,6 +458,22 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
 #endif
 #pragma unroll
         for (int k = 0; k < kPops; ++k) {
+            if (MASKED) {
+                // The whole evaluation under the execution mask of the lanes that popped a point: the same instructions are issued,
+                // the idle lanes (a fifth of them at the bench size) do not toggle — on a launch that runs at the card's power
+                // cap that is clock: -1.6 % at 50 000 x 100 000, -2.0 % for the 256-pair batch; +1 ... +3 % at 20 000 x 40 000 and
+                // 50 000 x 20 000, which run at a higher clock and pay for the mask instructions (profiles/r05/README.md).  The
+                // launcher picks by the size of the launch (matrix_masked_evaluation).
+                if (active[k]) {
+                    double sed;
+                    const bool ok = sfm::sed_inlier(e, p[k].xa, p[k].ya, p[k].xb, p[k].yb, gate, sed);
+                    c += ok ? 1 : 0;
+                    const double kept = ok ? sed : 0.0;
+                    a1 += kept;
+                    a2 = fma(kept, kept, a2);
+                }
+                continue;
+            }
             double sed;
             const bool ok = sfm::sed_inlier(e, p[k].xa, p[k].ya, p[k].xb, p[k].yb, gate, sed) && active[k];
 #if SFM_MATRIX_MASKED_SUMS
@@ -730,6 +749,16 @@ __global__ __launch_bounds__(256) void matrix_fold_kernel(const unsigned char* _
     }
 }
 
+// Whether a launch evaluates under the execution mask (matrix_item's MASKED): launches of 2 x 10^9 evaluations and more — the ones
+// that run at the power cap (measured: 5 x 10^9 and up gain 1.5-2 %, 0.8-1 x 10^9 lose 1-3 %).  The results are the same bits either way.
+__host__ inline bool matrix_masked_evaluation(int64_t n, int64_t h_count, int64_t batch) {
+#if SFM_MATRIX_MASKED_EVAL >= 0
+    return SFM_MATRIX_MASKED_EVAL != 0;
+#else
+    return (double)n * (double)h_count * (double)batch >= 2e9;
+#endif
+}
+
 // The launch.  tickets == nullptr: one item per wave, placed by block index (batches of pairs with their XCD-aware block map).
 // tickets != nullptr (a single pair): PERSISTENT waves — the grid is what the chip holds at once (CUs x SFM_MATRIX_OCC blocks),
 // and every wave takes items from a counter until they run out.  Why: the hardware's workgroup dispatcher does not keep this
@@ -741,7 +770,7 @@ __global__ __launch_bounds__(256) void matrix_fold_kernel(const unsigned char* _
 // Items of XCD x (tickets[16 x]): the ranges u = x (mod 8) of every group when the ranges are a multiple of eight — an XCD then
 // streams only its own eighth of the point operand table through its L2, as the block order of round 3 did; otherwise one
 // counter serves all.  The counters are zeroed by score_reset_kernel (they live behind the class counters).
-template <bool ESTIMATE>
+template <bool ESTIMATE, bool MASKED = false>
 __global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
     const Corr* __restrict__ pts, const uint4* __restrict__ hyp_table, const uint4* __restrict__ table, int n,
     const double* __restrict__ E, int h_count, double thr, const int32_t* __restrict__ order, int32_t* __restrict__ cnt,
@@ -774,7 +803,7 @@ __global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
                 if (t >= items) break;   // (every wave gets here: the counter only grows)
                 const int wave = t / mine;
                 const int unit = by_xcc ? (int)x + 8 * (t % mine) : t % mine;
-                matrix_item<ESTIMATE>(a, n, h_count, thr, units, steps_per_unit, wave, unit, my_queue, lane,
+                matrix_item<ESTIMATE, MASKED>(a, n, h_count, thr, units, steps_per_unit, wave, unit, my_queue, lane,
                                       (unsigned)(wave * units + unit));
             }
         }
@@ -817,10 +846,10 @@ __global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
         // for the 256 pairs of C5 cost more in starting up than the replay saves)
         const int per_wave = record_ranges / units;
         for (int p = 0; p < per_wave; ++p)
-            matrix_item<ESTIMATE>(a, n, h_count, thr, record_ranges, steps_per_unit, wave, unit * per_wave + p, my_queue, lane, 0u);
+            matrix_item<ESTIMATE, MASKED>(a, n, h_count, thr, record_ranges, steps_per_unit, wave, unit * per_wave + p, my_queue, lane, 0u);
         return;
     }
-    matrix_item<ESTIMATE>(a, n, h_count, thr, units, steps_per_unit, wave, unit, my_queue, lane,
+    matrix_item<ESTIMATE, MASKED>(a, n, h_count, thr, units, steps_per_unit, wave, unit, my_queue, lane,
                           blockIdx.x * (256 / kWave) + wave_in_block);
 }
 
