@@ -33,7 +33,7 @@ for cfg, (n, h, b) in shapes.items():
         seen = set()
         for row in csv.DictReader(open(path)):
             k = row["Kernel_Name"]
-            if "score_sed_" not in k or "<true>" in k.split("(")[0]:
+            if "score_sed_" not in k or "score_sed_matrix_kernel<true" in k:   # (<true, ...>: the cost pre-pass)
                 continue
             values[(row["Counter_Name"], k)].append(float(row["Counter_Value"]))
             if row["Dispatch_Id"] not in seen:

@@ -49,8 +49,8 @@ def main():
         shutil.copy(stats[0], os.path.join(out, "kernel_stats.csv"))
 
     def scoring(name):
-        # (score_sed_matrix_kernel<true> is that kernel's cost pre-pass, not the scoring launch)
-        return "score_sed_filtered_kernel" in name or ("score_sed_matrix_kernel" in name and "<true>" not in name)
+        # (score_sed_matrix_kernel<true, ...> is that kernel's cost pre-pass, not the scoring launch)
+        return "score_sed_filtered_kernel" in name or ("score_sed_matrix_kernel" in name and "score_sed_matrix_kernel<true" not in name)
 
     kernels = sorted({k for (_, k) in values if scoring(k)},
                      key=lambda k: -sum(sum(v) for (p, kk), v in spans.items() if kk == k))   # the one the time went to
