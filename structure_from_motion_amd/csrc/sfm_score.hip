@@ -1280,8 +1280,9 @@ int launch_matrix(const FilteredLaunch& a) {
     if (a.event_before) (void)hipEventRecord(a.event_before, a.st);
     const int64_t item_blocks = (int64_t)flat * a.units;
     const unsigned grid_blocks = persistent ? (unsigned)std::min<int64_t>(item_blocks, resident_blocks) : (unsigned)item_blocks;
-    const auto scoring_kernel = matrixscore::matrix_masked_evaluation(a.n, a.h_count, a.batch) ? score_sed_matrix_kernel<false, true>
-                                                                                              : score_sed_matrix_kernel<false, false>;
+    // (the pops of a round that share one execution-mask region: sfm_score_matrix.h, matrix_item's MASK_GROUP)
+    const auto scoring_kernel = a.batch > 1 ? score_sed_matrix_kernel<false, SFM_MATRIX_MASK_GROUP_BATCH>
+                                            : score_sed_matrix_kernel<false, SFM_MATRIX_MASK_GROUP_SINGLE>;
     hipLaunchKernelGGL(scoring_kernel, dim3(grid_blocks), dim3(256), 0, a.st, a.corr, hyp_table, table, a.n,
                        a.E, a.h_count, a.thr, order_arg, a.cnt, a.s1, a.s2, a.units, a.chunks_per_unit, split, fix,
                        (int)a.batch, blocks_per_pair * a.units, persistent ? a.buckets + kTicketWords : (int32_t*)nullptr, record, 0, 0);

@@ -81,8 +81,11 @@
 #ifndef SFM_MATRIX_ABLATE
 #define SFM_MATRIX_ABLATE 0  // measurement builds only (WRONG results; tools/r04/ablate.sh): bit 0 no operand refills, bit 1 one matrix
 #endif                       // instruction instead of three, bit 2 one sign test instead of sixteen, bit 3 no queue push, bit 4 no fp16 subnormal operands
-#ifndef SFM_MATRIX_MASKED_EVAL
-#define SFM_MATRIX_MASKED_EVAL (-1)   // exact-tier evaluations under the execution mask of the lanes with a point: -1 by the size of the launch, 0 / 1 forced (A/B builds)
+#ifndef SFM_MATRIX_MASK_GROUP_SINGLE
+#define SFM_MATRIX_MASK_GROUP_SINGLE 4   // pops of an exact-tier round that share one execution-mask region, launches of one pair (0: no masking; A/B builds)
+#endif
+#ifndef SFM_MATRIX_MASK_GROUP_BATCH
+#define SFM_MATRIX_MASK_GROUP_BATCH 2    // ... launches over a batch of pairs
 #endif
 #ifndef SFM_MATRIX_E_IN_REGISTERS
 #define SFM_MATRIX_E_IN_REGISTERS 1   // E held in 18 VGPRs through the tier-1 loop (0: loaded where a burst of rounds starts — better while the
@@ -347,7 +350,7 @@ SFM_DEVICE int take_ticket(int32_t* counter) {
     return ticket;
 }
 
-template <bool ESTIMATE, bool MASKED>
+template <bool ESTIMATE, int MASK_GROUP>
 SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr, int units, int steps_per_unit, int wave, int unit,
                             uint32_t* const my_queue, int lane, unsigned item_id) {
     const Corr* __restrict__ pts = a.pts;
@@ -456,39 +459,41 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
 #pragma unroll
         for (int k = 0; k < kPops; ++k) stat_pops += active[k] ? 1u : 0u;
 #endif
+        // `from` .. `to`: evaluate the pops of this stretch in straight-line code (the scheduler interleaves their dependency chains)
+        auto evaluate = [&](int from, int to) __attribute__((always_inline)) {
 #pragma unroll
-        for (int k = 0; k < kPops; ++k) {
-            if (MASKED) {
-                // The whole evaluation under the execution mask of the lanes that popped a point: the same instructions are issued,
-                // the idle lanes (a fifth of them at the bench size) do not toggle — on a launch that runs at the card's power
-                // cap that is clock: -1.6 % at 50 000 x 100 000, -2.0 % for the 256-pair batch; +1 ... +3 % at 20 000 x 40 000 and
-                // 50 000 x 20 000, which run at a higher clock and pay for the mask instructions (profiles/r05/README.md).  The
-                // launcher picks by the size of the launch (matrix_masked_evaluation).
-                if (active[k]) {
-                    double sed;
-                    const bool ok = sfm::sed_inlier(e, p[k].xa, p[k].ya, p[k].xb, p[k].yb, gate, sed);
-                    c += ok ? 1 : 0;
-                    const double kept = ok ? sed : 0.0;
-                    a1 += kept;
-                    a2 = fma(kept, kept, a2);
-                }
-                continue;
-            }
-            double sed;
-            const bool ok = sfm::sed_inlier(e, p[k].xa, p[k].ya, p[k].xb, p[k].yb, gate, sed) && active[k];
+            for (int k = from; k < to; ++k) {
+                double sed;
+                const bool ok = sfm::sed_inlier(e, p[k].xa, p[k].ya, p[k].xb, p[k].yb, gate, sed) && active[k];
 #if SFM_MATRIX_MASKED_SUMS
-            if (ok) {   // under the execution mask (three instructions for the inlier lanes) instead of three selects + three instructions for all
-                asm volatile("" : "+v"(c));
-                c += 1;
-                a1 += sed;
-                a2 = fma(sed, sed, a2);
-            }
+                if (ok) {   // under the execution mask (three instructions for the inlier lanes) instead of three selects + three instructions for all
+                    asm volatile("" : "+v"(c));
+                    c += 1;
+                    a1 += sed;
+                    a2 = fma(sed, sed, a2);
+                }
 #else
-            c += ok ? 1 : 0;
-            const double kept = ok ? sed : 0.0;   // masked once; its square is the masked square
-            a1 += kept;
-            a2 = fma(kept, kept, a2);
+                c += ok ? 1 : 0;
+                const double kept = ok ? sed : 0.0;   // masked once; its square is the masked square
+                a1 += kept;
+                a2 = fma(kept, kept, a2);
 #endif
+            }
+        };
+        if (MASK_GROUP > 0) {
+            // Under the execution mask of the lanes that popped a point in this stretch of MASK_GROUP pops (a lane pops in order, so
+            // active[k] implies active[k - 1]: the first pop of a stretch decides).  The same instructions are issued, but the idle
+            // lanes — a fifth of the slots at the bench size — no longer compute on a dummy point: these launches run at the card's
+            // power cap, and the energy comes back as clock.  One region per pop saves the most energy and lets the scheduler
+            // interleave nothing (-1.8 % at 50 000 x 100 000, +3 ... +6 % on launches of few hypotheses over many points, whose
+            // lanes are rarely idle); one region per round of four keeps the four dependency chains interleaved and never lost
+            // (-1.0 ... -1.9 % on every shape measured); batches of small pairs, whose lanes often hold one or two points, do best
+            // with pairs of pops (256 x 10 000 x 2 000: -2.4 % against -1.5 %).  profiles/r05/README.md item 10.
+#pragma unroll
+            for (int g = 0; g < kPops; g += (MASK_GROUP > 0 ? MASK_GROUP : kPops))
+                if (active[g]) evaluate(g, g + MASK_GROUP < kPops ? g + MASK_GROUP : kPops);
+        } else {
+            evaluate(0, kPops);
         }
     };
 
@@ -749,16 +754,6 @@ __global__ __launch_bounds__(256) void matrix_fold_kernel(const unsigned char* _
     }
 }
 
-// Whether a launch evaluates under the execution mask (matrix_item's MASKED): launches of 2 x 10^9 evaluations and more — the ones
-// that run at the power cap (measured: 5 x 10^9 and up gain 1.5-2 %, 0.8-1 x 10^9 lose 1-3 %).  The results are the same bits either way.
-__host__ inline bool matrix_masked_evaluation(int64_t n, int64_t h_count, int64_t batch) {
-#if SFM_MATRIX_MASKED_EVAL >= 0
-    return SFM_MATRIX_MASKED_EVAL != 0;
-#else
-    return (double)n * (double)h_count * (double)batch >= 2e9;
-#endif
-}
-
 // The launch.  tickets == nullptr: one item per wave, placed by block index (batches of pairs with their XCD-aware block map).
 // tickets != nullptr (a single pair): PERSISTENT waves — the grid is what the chip holds at once (CUs x SFM_MATRIX_OCC blocks),
 // and every wave takes items from a counter until they run out.  Why: the hardware's workgroup dispatcher does not keep this
@@ -770,7 +765,7 @@ __host__ inline bool matrix_masked_evaluation(int64_t n, int64_t h_count, int64_
 // Items of XCD x (tickets[16 x]): the ranges u = x (mod 8) of every group when the ranges are a multiple of eight — an XCD then
 // streams only its own eighth of the point operand table through its L2, as the block order of round 3 did; otherwise one
 // counter serves all.  The counters are zeroed by score_reset_kernel (they live behind the class counters).
-template <bool ESTIMATE, bool MASKED = false>
+template <bool ESTIMATE, int MASK_GROUP = 0>
 __global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
     const Corr* __restrict__ pts, const uint4* __restrict__ hyp_table, const uint4* __restrict__ table, int n,
     const double* __restrict__ E, int h_count, double thr, const int32_t* __restrict__ order, int32_t* __restrict__ cnt,
@@ -803,7 +798,7 @@ __global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
                 if (t >= items) break;   // (every wave gets here: the counter only grows)
                 const int wave = t / mine;
                 const int unit = by_xcc ? (int)x + 8 * (t % mine) : t % mine;
-                matrix_item<ESTIMATE, MASKED>(a, n, h_count, thr, units, steps_per_unit, wave, unit, my_queue, lane,
+                matrix_item<ESTIMATE, MASK_GROUP>(a, n, h_count, thr, units, steps_per_unit, wave, unit, my_queue, lane,
                                       (unsigned)(wave * units + unit));
             }
         }
@@ -846,10 +841,10 @@ __global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
         // for the 256 pairs of C5 cost more in starting up than the replay saves)
         const int per_wave = record_ranges / units;
         for (int p = 0; p < per_wave; ++p)
-            matrix_item<ESTIMATE, MASKED>(a, n, h_count, thr, record_ranges, steps_per_unit, wave, unit * per_wave + p, my_queue, lane, 0u);
+            matrix_item<ESTIMATE, MASK_GROUP>(a, n, h_count, thr, record_ranges, steps_per_unit, wave, unit * per_wave + p, my_queue, lane, 0u);
         return;
     }
-    matrix_item<ESTIMATE, MASKED>(a, n, h_count, thr, units, steps_per_unit, wave, unit, my_queue, lane,
+    matrix_item<ESTIMATE, MASK_GROUP>(a, n, h_count, thr, units, steps_per_unit, wave, unit, my_queue, lane,
                           blockIdx.x * (256 / kWave) + wave_in_block);
 }
 

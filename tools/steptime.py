@@ -43,7 +43,8 @@ if args.options:
 
 SINGLE = {"c3": (50_000, 100_000), "c4": (50_000, 125_000), "c4x4": (50_000, 250_000), "c4x2": (50_000, 500_000),
           "c2": (5_000, 10_000), "mid": (20_000, 40_000), "wide": (50_000, 20_000), "c1": (300, 2_000),
-          "e2": (50_000, 40_000), "e3": (50_000, 60_000), "e2n": (20_000, 100_000), "e1n": (100_000, 15_000)}   # 2, 3, 2, 1.5 x 10^9 evaluations
+          "e2": (50_000, 40_000), "e3": (50_000, 60_000), "e2n": (20_000, 100_000), "e1n": (100_000, 15_000),
+          "f2": (100_000, 20_000), "f4": (100_000, 40_000), "g2": (200_000, 10_000), "g2n": (10_000, 200_000), "g3": (150_000, 20_000)}   # 2, 3, 2, 1.5 x 10^9 evaluations
 out = {"config": args.config, "tree": root, "steps": args.steps}
 if args.config in SINGLE:
     n, h = SINGLE[args.config]
