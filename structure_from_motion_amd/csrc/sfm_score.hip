@@ -525,9 +525,13 @@ __global__ __launch_bounds__(256) void score_class_scatter_kernel(const int32_t*
 
 // The same with the scan inside (one launch fewer): every block scans the 241 class counts itself — they are final, the count
 // kernel ran before — and claims its slots on a second word of each class' cache line (zeroed with the counters).
+// wide_from_min > 0 (one pair): block 0 also leaves, in buckets[kWideFromWord], the entry of the order where the scoring launch's
+// waves of 64 hypotheses begin — the first CLASS boundary at or behind entry wide_from_min, so that a hypothesis' kind of wave
+// depends on its class alone (the order inside a class is the arrival order of atomics; the two kinds of wave add a hypothesis'
+// points in different orders) — or 0 (waves of 64 everywhere) when no class starts in [wide_from_min, wide_from_max].
 __global__ __launch_bounds__(256) void score_class_scan_scatter_kernel(const int32_t* __restrict__ estimate, int h_count,
                                                                        int32_t* __restrict__ buckets,
-                                                                       int32_t* __restrict__ order) {
+                                                                       int32_t* __restrict__ order, int wide_from_min, int wide_from_max) {
     __shared__ int scan[256];
     __shared__ int block_count[256];
     __shared__ int block_base[256];
@@ -544,6 +548,12 @@ __global__ __launch_bounds__(256) void score_class_scan_scatter_kernel(const int
         __syncthreads();
         scan[c] += below;
         __syncthreads();
+    }
+    if (wide_from_min > 0 && blockIdx.x == 0 && c <= kClasses) {
+        // start of class c (c == kClasses: the end of the order) and of the class before it
+        const int start = c > 0 ? scan[c - 1] : 0;
+        const int before = c > 1 ? scan[c - 2] : (c == 1 ? 0 : -1);
+        if (start >= wide_from_min && before < wide_from_min) buckets[b * kBuckets + kWideFromWord] = start <= wide_from_max ? start : 0;
     }
     const int cls = h < h_count ? cost_class(estimate[b * (int64_t)h_count + h]) : -1;
     const int rank = cls >= 0 ? atomicAdd(&block_count[cls], 1) : 0;
@@ -1240,9 +1250,15 @@ int launch_matrix(const FilteredLaunch& a) {
     // a single pair: persistent waves — as many blocks as the chip holds at once, every wave takes (group of 32 hypotheses,
     // range) items from a per-XCD counter (see the kernel); the counters were zeroed with the class counters
     const bool persistent = a.batch == 1 && a.persistent;
-    const unsigned resident_blocks = (unsigned)compute_units() * SFM_MATRIX_OCC;
-    const int64_t waves = (a.h_count + kHyps - 1) / kHyps;
+    // one pair, in cost order, many hypotheses: waves of 64 hypotheses behind the heaviest entries of the order (the kernel's
+    // WIDE_WAVES); everything else — batches, unordered launches, fewer hypotheses — waves of 32
+    const bool wide_waves = kWideWaves && a.batch == 1 && a.use_order && a.h_count >= SFM_MATRIX_WIDE_MIN_HYPOTHESES;
+    // (where the wide waves begin is decided on the device — the sort leaves it in buckets[kWideFromWord] —, anywhere from 0 to
+    // kWideFromMax: the grid covers kWideFromMax entries in waves of 32 and all entries in waves of 64; waves without entries return)
+    const int64_t waves = wide_waves ? kWideFromMax / kHyps + (a.h_count + 2 * kHyps - 1) / (2 * kHyps) : (a.h_count + kHyps - 1) / kHyps;
     const unsigned blocks = grid_for(waves, 256 / kWave);
+    const unsigned blocks_of_32 = grid_for((a.h_count + kHyps - 1) / kHyps, 256 / kWave);   // the cost pre-pass: waves of 32 always
+    const unsigned resident_blocks = (unsigned)compute_units() * (unsigned)(wide_waves ? kWideOcc : SFM_MATRIX_OCC);
     // batches: flat grid of 8-pair groups (the kernel's block -> (pair, block) map), `units` range blocks per block of a pair; a
     // single pair: blocks x ranges
     const int blocks_per_pair = a.batch > 1 ? (int)blocks : 0;
@@ -1263,14 +1279,16 @@ int launch_matrix(const FilteredLaunch& a) {
         const int e_units = record != nullptr ? (a.batch == 1 ? std::max(1, a.units / SFM_MATRIX_RECORD_RANGES_PER_WAVE) : 1)
                                               : (a.batch == 1 && e_steps >= 128 ? 4 : 1);
         // (the ranges of the pre-pass add into `cnt`: zeroed by matrix_setup_kernel)
-        hipLaunchKernelGGL(score_sed_matrix_kernel<true>, dim3(flat * (unsigned)e_units), dim3(256), 0, a.st, a.corr, hyp_table, table,
+        const unsigned flat_of_32 = a.batch > 1 ? flat : blocks_of_32;   // (batches never take wide waves: blocks == blocks_of_32)
+        hipLaunchKernelGGL(score_sed_matrix_kernel<true>, dim3(flat_of_32 * (unsigned)e_units), dim3(256), 0, a.st, a.corr, hyp_table, table,
                            a.n, a.E, a.h_count, a.thr, (const int32_t*)nullptr, a.cnt, a.s1, a.s2, e_units,
                            record != nullptr ? kReplaySteps : e_steps / e_units,
                            (unsigned char*)nullptr, (const unsigned char*)nullptr, (int)a.batch, blocks_per_pair * e_units, (int32_t*)nullptr,
-                           record, a.chunks_per_unit, a.units);
+                           record, a.chunks_per_unit, a.units, (const int32_t*)nullptr);
         const dim3 per_hyp(grid_for(a.h_count, 256), pairs);
         hipLaunchKernelGGL(score_class_count_kernel, per_hyp, dim3(256), 0, a.st, a.cnt, a.h_count, a.buckets);
-        hipLaunchKernelGGL(score_class_scan_scatter_kernel, per_hyp, dim3(256), 0, a.st, a.cnt, a.h_count, a.buckets, a.order);
+        hipLaunchKernelGGL(score_class_scan_scatter_kernel, per_hyp, dim3(256), 0, a.st, a.cnt, a.h_count, a.buckets, a.order,
+                           wide_waves ? SFM_MATRIX_WIDE_FROM : 0, kWideFromMax);
         const int rc = check_launch("score order kernels");
         if (rc != SFM_OK) return rc;
         order_arg = a.order;
@@ -1281,11 +1299,13 @@ int launch_matrix(const FilteredLaunch& a) {
     const int64_t item_blocks = (int64_t)flat * a.units;
     const unsigned grid_blocks = persistent ? (unsigned)std::min<int64_t>(item_blocks, resident_blocks) : (unsigned)item_blocks;
     // (the pops of a round that share one execution-mask region: sfm_score_matrix.h, matrix_item's MASK_GROUP)
-    const auto scoring_kernel = a.batch > 1 ? score_sed_matrix_kernel<false, SFM_MATRIX_MASK_GROUP_BATCH>
-                                            : score_sed_matrix_kernel<false, SFM_MATRIX_MASK_GROUP_SINGLE>;
+    const auto scoring_kernel = a.batch > 1 ? score_sed_matrix_kernel<false, SFM_MATRIX_MASK_GROUP_BATCH, false>
+                                : wide_waves ? score_sed_matrix_kernel<false, SFM_MATRIX_MASK_GROUP_SINGLE, true>
+                                             : score_sed_matrix_kernel<false, SFM_MATRIX_MASK_GROUP_SINGLE, false>;
     hipLaunchKernelGGL(scoring_kernel, dim3(grid_blocks), dim3(256), 0, a.st, a.corr, hyp_table, table, a.n,
                        a.E, a.h_count, a.thr, order_arg, a.cnt, a.s1, a.s2, a.units, a.chunks_per_unit, split, fix,
-                       (int)a.batch, blocks_per_pair * a.units, persistent ? a.buckets + kTicketWords : (int32_t*)nullptr, record, 0, 0);
+                       (int)a.batch, blocks_per_pair * a.units, persistent ? a.buckets + kTicketWords : (int32_t*)nullptr, record, 0, 0,
+                       wide_waves ? a.buckets + kWideFromWord : (const int32_t*)nullptr);
     if (a.event_after) (void)hipEventRecord(a.event_after, a.st);
     if (a.deferred != nullptr) {   // a fused pass folds the ranges inside its selection launch
         *a.deferred = sfmhost::LargeScore{a.units, split, fix};

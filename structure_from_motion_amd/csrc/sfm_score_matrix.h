@@ -72,8 +72,11 @@
 // gets an infinite slack: nothing is rejected and the exact tier decides everything.
 #pragma once
 
+#ifndef SFM_MATRIX_WIDE
+#define SFM_MATRIX_WIDE 1    // large single-pair launches: waves of 64 hypotheses behind the heaviest groups (matrix_item's WIDE; 0: waves of 32 everywhere)
+#endif
 #ifndef SFM_MATRIX_OCC
-#define SFM_MATRIX_OCC 4     // blocks per CU the matrix-pipe kernel is compiled for (32 KiB of queues each)
+#define SFM_MATRIX_OCC 4     // blocks per CU the matrix-pipe kernel is compiled for (32 KiB of queues each); the kernel with wide waves: 3 (163 VGPRs)
 #endif
 #ifndef SFM_MATRIX_POPS
 #define SFM_MATRIX_POPS 4    // points a lane pops per round of the exact tier (2: the same at 50 000 x 100 000, 10-13 % slower at 20 000 x 40 000 and 50 000 x 20 000 where the final drains dominate; 6: a wave less per SIMD; 8: spills)
@@ -119,6 +122,16 @@ __device__ unsigned long long g_matrix_stamps[10 * 65536];   // begin, operands 
 #ifndef SFM_MATRIX_CAP
 #define SFM_MATRIX_CAP 32
 #endif
+constexpr bool kWideWaves = SFM_MATRIX_WIDE != 0;   // the launcher may pick the kernel with wide waves (score_sed_matrix_kernel<.., .., true>)
+constexpr int kWideOcc = 3;
+#ifndef SFM_MATRIX_WIDE_MIN_HYPOTHESES
+#define SFM_MATRIX_WIDE_MIN_HYPOTHESES 49152   // ... for one pair with at least this many hypotheses, in cost order (40 000: +6 ... +10 %, 60 000: -7 %)
+#endif
+#ifndef SFM_MATRIX_WIDE_FROM
+#define SFM_MATRIX_WIDE_FROM 4096              // entries of the heaviest-first order that stay in waves of 32 (a multiple of 128: whole blocks)
+#endif
+constexpr int kWideFromMax = 4 * SFM_MATRIX_WIDE_FROM;   // the wide waves begin at the first class boundary in [WIDE_FROM, kWideFromMax] (none: at entry 0)
+static_assert(SFM_MATRIX_WIDE_FROM % 128 == 0, "blocks of four waves of 32 hypotheses");
 constexpr int kCap = SFM_MATRIX_CAP;   // entries per lane queue (a power of two: the queue is a ring); an entry is one step's survivors
 constexpr int kHigh = kCap - 4;  // a step pushes at most one entry per lane: rounds start when a queue holds this many (checked once per group of steps) ...
 constexpr int kLow = 8;          // ... and stop when every queue is down to this
@@ -126,7 +139,7 @@ constexpr int kPops = SFM_MATRIX_POPS;
 #ifndef SFM_MATRIX_AHEAD
 #define SFM_MATRIX_AHEAD 1
 #endif
-static_assert(SFM_MATRIX_AHEAD >= 1 && kHigh + SFM_MATRIX_AHEAD <= kCap, "a group of kAhead + 1 steps must fit behind kHigh - 1 entries");
+static_assert(SFM_MATRIX_AHEAD >= 1 && kHigh + 2 * (SFM_MATRIX_AHEAD + 1) - 1 <= kCap, "a group of kAhead + 1 steps (two entries each in a wide wave) must fit behind kHigh - 1 entries");
 static_assert(SFM_MATRIX_AHEAD + 1 <= 4, "the point operand table is padded to a multiple of four steps");
 constexpr int kAhead = SFM_MATRIX_AHEAD;   // steps of operand loads in flight behind the one being processed (register stages: kAhead + 1)
 #ifndef SFM_MATRIX_ESTIMATE_AHEAD
@@ -148,7 +161,7 @@ static_assert(SFM_MATRIX_ESTIMATE_AHEAD == 1 || SFM_MATRIX_ESTIMATE_AHEAD == 3, 
 #endif
 constexpr int kEstimateSteps = SFM_MATRIX_ESTIMATE_STEPS;   // steps of 32 points the cost pre-pass scans at most (4096 points)
 constexpr int64_t kMaxPoints = sfmws::kMatrixMaxPoints;
-constexpr int kMaxRangeSteps = 65536;   // a queue entry keeps the step RELATIVE TO ITS RANGE in 16 bits: at most 2^16 steps (2 M points) per range
+constexpr int kMaxRangeSteps = kWideWaves ? 32768 : 65536;   // a queue entry keeps the step RELATIVE TO ITS RANGE (wide waves: 2 x step + half) in 16 bits: at most 2^15 steps (1 M points) per range
 static_assert(kMaxPoints <= (int64_t)sfmws::kSplitMaxUnits * kMaxRangeSteps * kTile, "sixteen ranges of 2^16 steps cover the largest pair");
 
 // ... and an eighth of a smaller point set, but no fewer than 1024 points: the pre-pass is tier 1 over that share of the points
@@ -327,7 +340,7 @@ struct MatrixPair {   // the arrays of one image pair
     int range_stride;   // steps between the starts of the pre-pass' ranges (= the scoring launch's steps per range) when recording
 };
 constexpr int kReplaySteps = sfmws::kMatrixReplaySteps;   // 16 steps of every range: 8 ranges = the 128 steps (4096 points) of the bench workload's pre-pass
-static_assert(kReplaySteps % 8 == 0 && kReplaySteps <= kCap - 4, "whole 16-byte stores; the replayed entries fit the empty ring");
+static_assert(kReplaySteps % 8 == 0 && kReplaySteps <= kCap - 4 && 2 * kReplaySteps <= kCap, "whole 16-byte stores; the replayed entries fit the empty ring");
 __host__ __device__ inline int64_t record_bytes(int64_t h_count) { return sfmws::matrix_record_bytes(h_count); }
 
 // One wave-uniform ticket from an agent-scope counter, in straight-line assembly with the exec mask set by hand: written as
@@ -350,9 +363,9 @@ SFM_DEVICE int take_ticket(int32_t* counter) {
     return ticket;
 }
 
-template <bool ESTIMATE, int MASK_GROUP>
-SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr, int units, int steps_per_unit, int wave, int unit,
-                            uint32_t* const my_queue, int lane, unsigned item_id) {
+template <bool ESTIMATE, int MASK_GROUP, bool WIDE>
+SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr, int units, int steps_per_unit, int h0, int h_limit,
+                            int unit, uint32_t* const my_queue, int lane, unsigned item_id) {
     const Corr* __restrict__ pts = a.pts;
     const uint4* __restrict__ hyp_table = a.hyp_table;
     const uint4* __restrict__ table = a.table;
@@ -366,12 +379,21 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
     stamp[0] = __builtin_amdgcn_s_memrealtime();
     const unsigned long long clock_begin = __builtin_amdgcn_s_memtime();
 #endif
-    const int h0 = wave * kHyps;
-    if (h0 >= h_count) return;   // (no block-level synchronisation in this kernel)
+    if (h0 >= h_limit) return;   // (no block-level synchronisation in this kernel); h_limit: the end of this kind of wave's entries of the order
     const int col = lane & 31, half = lane >> 5;
-    const bool valid = h0 + col < h_count;
-    const int slot = min(h0 + col, h_count - 1);
+    // A lane OWNS one hypothesis — its queue, its exact entries, its sums.  Waves of 32: entry h0 + col of the order, shared by the
+    // two lanes of a column (16 of a step's 32 points each).  Wide waves (64): entry h0 + lane — the lower lanes the columns of the
+    // first operand group, the upper lanes those of the second —, all 32 points of a step; for tier 1 a lane also supplies its
+    // half of the operand rows of BOTH groups' column `col`.
+    const bool valid = h0 + (WIDE ? lane : col) < h_limit;
+    const int slot = min(h0 + (WIDE ? lane : col), h_limit - 1);
     const int h = order != nullptr ? order[slot] : slot;
+    int h_first = h, h_second = h;   // wide waves: the hypotheses of column `col` in the two operand groups
+    if (WIDE) {
+        const int slot_first = min(h0 + col, h_limit - 1), slot_second = min(h0 + kHyps + col, h_limit - 1);
+        h_first = order != nullptr ? order[slot_first] : slot_first;
+        h_second = order != nullptr ? order[slot_second] : slot_second;
+    }
 
     // ---- this lane's hypothesis: exact entries for the exact tier; the B operands of tier 1 come from the table
     // matrix_hypothesis_kernel wrote once per launch (a hypothesis is scored by up to 16 range waves and the cost pre-pass)
@@ -388,10 +410,14 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
     if (ESTIMATE)
 #endif
         load_e();
-    const uint4* __restrict__ operands = hyp_table + ((int64_t)h * 2 + half) * kBlocks;
+    const uint4* __restrict__ operands = hyp_table + ((int64_t)h_first * 2 + half) * kBlocks;
     const f16x8 B0 = __builtin_bit_cast(f16x8, operands[0]);
     const f16x8 B1 = __builtin_bit_cast(f16x8, operands[1]);
     const bf16x8 B2 = __builtin_bit_cast(bf16x8, operands[2]);
+    const uint4* __restrict__ operands_second = hyp_table + ((int64_t)h_second * 2 + half) * kBlocks;   // (wide waves; else the same rows, unused)
+    const f16x8 C0 = __builtin_bit_cast(f16x8, operands_second[0]);
+    const f16x8 C1 = __builtin_bit_cast(f16x8, operands_second[1]);
+    const bf16x8 C2 = __builtin_bit_cast(bf16x8, operands_second[2]);
     SFM_STAMP(1);
 
     // The lane's queue is a ring of entries (step << 16 | the step's 16 survivor bits), pushed at `tail`, popped at `head`; the
@@ -427,7 +453,7 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
     // instead of 55 for its 50 000 store instructions of 64 separate lines each.)
     const int64_t record_stride = sfmws::split_padded(h_count) * 2;   // chunks between a lane's consecutive chunks
     uint4* const my_record = a.record == nullptr ? nullptr
-        : reinterpret_cast<uint4*>(a.record) + (int64_t)unit * (kReplaySteps / 8) * record_stride + (int64_t)h * 2 + half;
+        : reinterpret_cast<uint4*>(a.record) + (int64_t)unit * (kReplaySteps / 8) * record_stride + (int64_t)h * 2 + (WIDE ? 0 : half);   // (wide waves: both halves, [0] and [1])
     const int step_end = units > 1 || ESTIMATE ? min(step_begin + steps_per_unit, steps_total) : steps_total;
     const int last_loadable = (int)table_steps(n) - 1;
 
@@ -435,7 +461,7 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
     // scores them, in queue order, under its own hypothesis
     const sfm::SedGate gate = sfm::sed_gate(thr);
     // bytes: point (step_begin x 32 + 16 half - 16) of the correspondences (kMaxPoints x 32 bytes = 128 MB: 32 bits are plenty)
-    const unsigned lane_off = (unsigned)((step_begin * kTile + 16 * half - 16) * (int)sizeof(Corr));
+    const unsigned lane_off = (unsigned)((step_begin * kTile + (WIDE ? 0 : 16 * half) - 16) * (int)sizeof(Corr));
     auto round = [&]() __attribute__((always_inline)) {
         Corr p[kPops];
         bool active[kPops];
@@ -445,7 +471,8 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
                 const unsigned entry = *ring_slot(head);
                 head += kSlotBytes;
                 cur = entry & 0xffffu;
-                cur_off = lane_off + ((entry >> 16) << 10);   // (the entry keeps the step relative to its range: 32 points x 32 bytes)
+                // (the entry keeps the step relative to its range: 32 points x 32 bytes; wide waves: 2 x step + half: 16 points x 32 bytes)
+                cur_off = lane_off + ((entry >> 16) << (WIDE ? 9 : 10));
             }
             active[k] = cur != 0u;
             const unsigned lz = (unsigned)__builtin_clz(cur | 1u);   // 16..31 for a live entry: bit 15 - j is register j = point j of the lane's sixteen
@@ -499,6 +526,7 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
 
     unsigned survivors = 0;   // ESTIMATE
     unsigned rec[4] = {0u, 0u, 0u, 0u}, rec_low = 0u;   // ESTIMATE, recording: the reject words of the last eight steps
+    unsigned rec_upper[4] = {0u, 0u, 0u, 0u}, rec_upper_low = 0u;   // ... wide waves: of the lane's other half
     static_assert((kAhead + 1) % 2 == 0 || !SFM_MATRIX_REPLAY, "the recording pre-pass packs the steps of a loop group two to a dword");
     const int first_step = step_begin + (replaying ? kReplaySteps : 0);   // (the host replays only when every range has that many steps)
     if (step_begin < step_end) {
@@ -526,19 +554,37 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
         if (replaying) {
             // the first kReplaySteps steps of the range: the pre-pass' reject words instead of tier 1 (at most 16 pushes into an
             // empty ring of kCap = 32: no round can be due)
-            unsigned words[kReplaySteps / 2];
+            unsigned words[kReplaySteps / 2], words_upper[kReplaySteps / 2];   // (wide waves: the lane's two halves)
 #pragma unroll
             for (int q = 0; q < kReplaySteps / 8; ++q) {
                 const uint4 w = my_record[q * record_stride];
                 words[4 * q] = w.x, words[4 * q + 1] = w.y, words[4 * q + 2] = w.z, words[4 * q + 3] = w.w;
+                if (WIDE) {
+                    const uint4 u = my_record[q * record_stride + 1];
+                    words_upper[4 * q] = u.x, words_upper[4 * q + 1] = u.y, words_upper[4 * q + 2] = u.z, words_upper[4 * q + 3] = u.w;
+                }
             }
 #pragma unroll
             for (int s = 0; s < kReplaySteps; ++s) {
                 const unsigned rejected = (s & 1) ? words[s >> 1] >> 16 : words[s >> 1] & 0xffffu;
+                const unsigned field = WIDE ? 2u * (unsigned)s : (unsigned)s;
                 if (rejected != 0xffffu) {
-                    *ring_slot(tail) = ~(rejected ^ (((unsigned)s << 16) ^ 0xffff0000u));
+                    *ring_slot(tail) = ~(rejected ^ ((field << 16) ^ 0xffff0000u));
                     tail += kSlotBytes;
                 }
+                if (WIDE) {
+                    const unsigned upper = (s & 1) ? words_upper[s >> 1] >> 16 : words_upper[s >> 1] & 0xffffu;
+                    if (upper != 0xffffu) {
+                        *ring_slot(tail) = ~(upper ^ (((field + 1u) << 16) ^ 0xffff0000u));
+                        tail += kSlotBytes;
+                    }
+                }
+            }
+            // (wide waves push up to 2 x kReplaySteps = kCap entries: the ring may be full now, and the step loop below looks
+            // at the queues only BEHIND a group of steps)
+            if (WIDE && __builtin_amdgcn_ballot_w64((int)(tail - head) >= kHigh * (int)kSlotBytes) != 0ull) {
+                __builtin_amdgcn_wave_barrier();
+                do round(); while (__builtin_amdgcn_ballot_w64((int)(tail - head) > kLow * (int)kSlotBytes) != 0ull);
             }
         }
         int t0 = first_step;
@@ -561,6 +607,23 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
 #pragma unroll
             for (int j = 0; j < ((SFM_MATRIX_ABLATE & 4) ? 1 : 16); ++j)
                 rejected = __builtin_amdgcn_alignbit(rejected, __float_as_uint(__builtin_fmaf(-r[j], r[j], d[j])), 31);
+            unsigned rejected_upper = 0xffffu;   // wide waves: the other half's word of this lane's hypothesis (below)
+            if (WIDE) {
+                // the same step against the operand rows of columns 32 .. 63, then the lane halves exchange words: v_permlane32_swap
+                // swaps vdst[32..63] with src0[0..31] — lower lanes keep their first-group word (points 0 .. 15 of hypothesis `col`)
+                // and receive the upper lanes' (points 16 .. 31); upper lanes receive the lower lanes' second-group word and keep theirs
+                float16v r2 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, d2 = r2;
+                r2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[stage][0]), C0, r2, 0, 0, 0);
+                d2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[stage][2]), C2, d2, 0, 0, 0);
+                r2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[stage][1]), C1, r2, 0, 0, 0);
+                unsigned second = 0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    second = __builtin_amdgcn_alignbit(second, __float_as_uint(__builtin_fmaf(-r2[j], r2[j], d2[j])), 31);
+                const auto swapped = __builtin_amdgcn_permlane32_swap(rejected, second, false, false);
+                rejected = swapped[0];         // half 0 of this lane's hypothesis
+                rejected_upper = swapped[1];   // half 1
+            }
             // (sixteen shifts: the upper half of `rejected` is zero.)  keep = ~rejected & 0xffff — bit 15 - j: register j = point
             // 16 half + j of this step — is never materialised on the scoring path: "any survivor" is rejected != 0xffff and the
             // queue entry (step << 16) | keep is one exclusive-nor of `rejected` with a wave-uniform word
@@ -574,7 +637,7 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
                 // (a buffer load: descriptor + scalar step offset + the lane's constant 32-bit offset + immediate are the load's own
                 // addressing mode — no vector instruction computes an address in this loop; the scalar offset goes through the asm)
                 unsigned step_bytes = (unsigned)min(t + kStages, last_loadable) * (unsigned)(kBlocks * 64 * 16);   // (wave-uniform: a scalar register)
-                asm volatile("" : "+s"(step_bytes), "+v"(rejected));
+                asm volatile("" : "+s"(step_bytes), "+v"(rejected), "+v"(rejected_upper));
 #if !(SFM_MATRIX_ABLATE & 1)
 #if SFM_MATRIX_BUFFER_LOADS
 #pragma unroll
@@ -589,23 +652,36 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
             }
             if (ESTIMATE) {
                 survivors += (unsigned)__builtin_popcount(SFM_KEEP_OF(rejected));
+                if (WIDE) survivors += (unsigned)__builtin_popcount(SFM_KEEP_OF(rejected_upper));
                 if (recording) {   // two steps make a dword, four dwords a 16-byte store (below): not sixteen scattered 2-byte stores a wave
                     if (stage & 1) {
                         rec[0] = rec[1];
                         rec[1] = rec[2];
                         rec[2] = rec[3];
                         rec[3] = rec_low | (rejected << 16);
+                        if (WIDE) {
+                            rec_upper[0] = rec_upper[1];
+                            rec_upper[1] = rec_upper[2];
+                            rec_upper[2] = rec_upper[3];
+                            rec_upper[3] = rec_upper_low | (rejected_upper << 16);
+                        }
                     } else {
                         rec_low = rejected;
+                        rec_upper_low = rejected_upper;
                     }
                 }
             } else {
 #if SFM_MATRIX_ABLATE & 8
                 survivors += (unsigned)__builtin_popcount(SFM_KEEP_OF(rejected));
 #else
+                const unsigned field = WIDE ? 2u * (unsigned)(t - step_begin) : (unsigned)(t - step_begin);   // (wide waves: 2 x step + half)
                 if (rejected != 0xffffu) {   // push: one entry with this step's survivors
                     // (step << 16) | keep  ==  ~(rejected ^ k),  k = (step << 16) ^ 0xffff0000 (wave-uniform): one v_xnor
-                    *ring_slot(tail) = ~(rejected ^ ((((unsigned)(t - step_begin)) << 16) ^ 0xffff0000u));
+                    *ring_slot(tail) = ~(rejected ^ ((field << 16) ^ 0xffff0000u));
+                    tail += kSlotBytes;
+                }
+                if (WIDE && rejected_upper != 0xffffu) {
+                    *ring_slot(tail) = ~(rejected_upper ^ (((field + 1u) << 16) ^ 0xffff0000u));
                     tail += kSlotBytes;
                 }
 #endif
@@ -613,7 +689,10 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
           }
           t0 += kStages;
           if (recording && ((t0 - step_begin) & 7) == 0)   // (wave-uniform) the last eight steps' words: [t0 - 8, t0)
+          {
               my_record[((t0 - step_begin) / 8 - 1) * record_stride] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
+              if (WIDE) my_record[((t0 - step_begin) / 8 - 1) * record_stride + 1] = make_uint4(rec_upper[0], rec_upper[1], rec_upper[2], rec_upper[3]);
+          }
           queue_full = !ESTIMATE && __builtin_amdgcn_ballot_w64((int)(tail - head) >= kHigh * (int)kSlotBytes) != 0ull;
          } while (t0 < step_end && !queue_full);
          // Rounds of the exact tier are looked at once per group of kStages steps, not between its stages, and run OUTSIDE the
@@ -631,11 +710,11 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
         }
     }
     if (ESTIMATE) {   // survivors per 1024 points of this hypothesis (both lanes) in sixteenths, at least 1 when there was any
-        const unsigned both = survivors + (unsigned)__shfl_xor((int)survivors, 32, 64);
+        const unsigned both = WIDE ? survivors : survivors + (unsigned)__shfl_xor((int)survivors, 32, 64);
         const unsigned scanned = (unsigned)min(units * steps_per_unit * kTile, n);   // by all ranges of the pre-pass together
         unsigned sixteenths = (unsigned)(((unsigned long long)both * 16384ull) / (scanned > 0u ? scanned : 1u));
         sixteenths = both > 0u && sixteenths == 0u ? 1u : sixteenths;
-        if (half == 0 && valid) {
+        if ((WIDE || half == 0) && valid) {
             // integer sums: any order (the launcher zeroed cnt).  (Plain stores instead — a timing experiment — change nothing: 70 vs 73 us.)
             if (units > 1) atomicAdd(cnt + h, (int32_t)sixteenths);
             else cnt[h] = (int32_t)sixteenths;
@@ -667,12 +746,13 @@ SFM_DEVICE void matrix_item(const MatrixPair& a, int n, int h_count, double thr,
     // XCDs — all of them on XCD 0, which finished a quarter of the launch after the other seven.)
     SFM_STAMP(4);
     // the two lanes of a hypothesis: first half + second half
-    const int c_other = __shfl_xor(c, 32, 64);
-    const double a1_other = __shfl_xor(a1, 32, 64), a2_other = __shfl_xor(a2, 32, 64);
+    // (wide waves: a lane has scored all of its hypothesis' points of this range itself, in point order)
+    const int c_other = WIDE ? 0 : __shfl_xor(c, 32, 64);
+    const double a1_other = WIDE ? 0.0 : __shfl_xor(a1, 32, 64), a2_other = WIDE ? 0.0 : __shfl_xor(a2, 32, 64);
     const int ck = c + c_other;
-    const double s1k = half == 0 ? a1 + a1_other : a1_other + a1;
-    const double s2k = half == 0 ? a2 + a2_other : a2_other + a2;
-    if (half == 0 && valid) {
+    const double s1k = WIDE ? a1 : (half == 0 ? a1 + a1_other : a1_other + a1);
+    const double s2k = WIDE ? a2 : (half == 0 ? a2 + a2_other : a2_other + a2);
+    if ((WIDE || half == 0) && valid) {
         const int64_t hp = sfmws::split_padded(h_count);
         if (units <= 1) {   // the totals, with the correction for the sample points behind them
             const int32_t* fix_c = reinterpret_cast<const int32_t*>(a.fix);
@@ -765,20 +845,41 @@ __global__ __launch_bounds__(256) void matrix_fold_kernel(const unsigned char* _
 // Items of XCD x (tickets[16 x]): the ranges u = x (mod 8) of every group when the ranges are a multiple of eight — an XCD then
 // streams only its own eighth of the point operand table through its L2, as the block order of round 3 did; otherwise one
 // counter serves all.  The counters are zeroed by score_reset_kernel (they live behind the class counters).
-template <bool ESTIMATE, int MASK_GROUP = 0>
-__global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
+// WIDE_WAVES (one pair, in cost order, many hypotheses: launch_matrix): the entries [0, wide_from) of the order — the heaviest
+// hypotheses, whose items are the longest of the launch — go in waves of 32 as everywhere else, the entries behind them in waves
+// of 64 (matrix_item's WIDE): the step's operands are loaded once for 2048 evaluations instead of 1024 — the operand stream keeps
+// a CU's vector L1 ~90 % busy otherwise (profiles/r05/README.md) — and a lane scores all 32 points of a step under its
+// hypothesis.  All of them wide, the heaviest items would take as long as the whole launch (50 000 x 100 000: 888 us median for
+// the first 2048 entries, 1.27 ms the longest, of a 1.27 ms launch).  wide_from is a multiple of 128: whole blocks of either kind.
+// The kernel with wide waves needs 163 VGPRs: three waves per SIMD.
+template <bool ESTIMATE, int MASK_GROUP = 0, bool WIDE_WAVES = false>
+__global__ __launch_bounds__(256, WIDE_WAVES ? kWideOcc : SFM_MATRIX_OCC) void score_sed_matrix_kernel(
     const Corr* __restrict__ pts, const uint4* __restrict__ hyp_table, const uint4* __restrict__ table, int n,
     const double* __restrict__ E, int h_count, double thr, const int32_t* __restrict__ order, int32_t* __restrict__ cnt,
     double* __restrict__ s1, double* __restrict__ s2, int units, int steps_per_unit, unsigned char* __restrict__ split,
     const unsigned char* __restrict__ fix, int batch, int blocks_per_pair, int32_t* __restrict__ tickets,
-    uint16_t* __restrict__ record, int range_stride, int record_ranges) {
+    uint16_t* __restrict__ record, int range_stride, int record_ranges, const int32_t* __restrict__ wide_word) {
     __shared__ alignas(kCap * kWave * 4) uint32_t queues[ESTIMATE ? 1 : 256 / kWave][ESTIMATE ? 1 : kCap][kWave];   // (a wave's ring: 8 KiB, aligned: ring_slot() in matrix_item)
     const int lane = threadIdx.x & (kWave - 1);
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     uint32_t* const my_queue = &queues[ESTIMATE ? 0 : wave_in_block][0][lane];
     MatrixPair a{pts, hyp_table, table, E, order, cnt, s1, s2, split, fix, record, range_stride};
+    // wave index of the launch -> first entry of the order it takes, and the kind of wave: indices below narrow_waves are waves of
+    // 32 over the entries [0, wide_from), the rest waves of 64 behind them
+    // (the launch's wave indices [0, kWideFromMax / 32) are waves of 32 — those at or behind wide_from have nothing to do —, the rest
+    // waves of 64 from wide_from on)
+    const int wide_from = WIDE_WAVES ? min(*wide_word, h_count) : h_count;   // (wave-uniform: a scalar load)
+    constexpr int narrow_waves = kWideFromMax / kHyps;
+    auto item = [&](int wave, int unit, unsigned item_id, int ranges) __attribute__((always_inline)) {
+        if (WIDE_WAVES && wave >= narrow_waves)
+            matrix_item<ESTIMATE, MASK_GROUP, true>(a, n, h_count, thr, ranges, steps_per_unit, wide_from + (wave - narrow_waves) * 2 * kHyps, h_count,
+                                                    unit, my_queue, lane, item_id);
+        else
+            matrix_item<ESTIMATE, MASK_GROUP, false>(a, n, h_count, thr, ranges, steps_per_unit, wave * kHyps, wide_from, unit, my_queue, lane,
+                                                     item_id);
+    };
     if (tickets != nullptr) {
-        const int waves32 = (h_count + kHyps - 1) / kHyps;
+        const int waves32 = WIDE_WAVES ? narrow_waves + (h_count - wide_from + 2 * kHyps - 1) / (2 * kHyps) : (h_count + kHyps - 1) / kHyps;
         const bool by_xcc = units % 8 == 0;
         unsigned xcc = 0;
         if (by_xcc) {
@@ -798,8 +899,7 @@ __global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
                 if (t >= items) break;   // (every wave gets here: the counter only grows)
                 const int wave = t / mine;
                 const int unit = by_xcc ? (int)x + 8 * (t % mine) : t % mine;
-                matrix_item<ESTIMATE, MASK_GROUP>(a, n, h_count, thr, units, steps_per_unit, wave, unit, my_queue, lane,
-                                      (unsigned)(wave * units + unit));
+                item(wave, unit, (unsigned)(wave * units + unit), units);
             }
         }
         return;
@@ -841,11 +941,10 @@ __global__ __launch_bounds__(256, SFM_MATRIX_OCC) void score_sed_matrix_kernel(
         // for the 256 pairs of C5 cost more in starting up than the replay saves)
         const int per_wave = record_ranges / units;
         for (int p = 0; p < per_wave; ++p)
-            matrix_item<ESTIMATE, MASK_GROUP>(a, n, h_count, thr, record_ranges, steps_per_unit, wave, unit * per_wave + p, my_queue, lane, 0u);
+            item(wave, unit * per_wave + p, 0u, record_ranges);
         return;
     }
-    matrix_item<ESTIMATE, MASK_GROUP>(a, n, h_count, thr, units, steps_per_unit, wave, unit, my_queue, lane,
-                          blockIdx.x * (256 / kWave) + wave_in_block);
+    item(wave, unit, blockIdx.x * (256 / kWave) + wave_in_block, units);
 }
 
 }  // namespace matrixscore

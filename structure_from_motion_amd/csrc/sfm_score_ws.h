@@ -98,8 +98,10 @@ __host__ __device__ inline int64_t workspace_bytes_for(int64_t n, int64_t h_coun
 }
 // Work counters of the matrix-pipe kernel's persistent waves (one per XCD, a 64-byte line each), in the words of the class-counter
 // block that no class uses (classes end at int 16 * 240 = 3840); score_reset_kernel zeroes them with the class counters.
+constexpr int kWideFromWord = 3844;         // int: entry of the scoring order where the waves of 64 hypotheses begin (sfm_score_matrix.h: WIDE_WAVES), written by the sort
 constexpr int kTicketWords = 3968;          // ints [3968, 3968 + 8 * 16): the scoring launch
 constexpr int kTicketWordsPrepass = 3848;   // ints [3848 + 8 x], x < 8: the cost pre-pass (eight 32-byte slots)
+static_assert(16 * (kClasses - 1) < kWideFromWord && kWideFromWord < kTicketWordsPrepass, "a free word behind the class counters");
 static_assert(16 * (kClasses - 1) < kTicketWordsPrepass && kTicketWordsPrepass + 8 * 8 <= kTicketWords &&
               kTicketWords + 8 * 16 <= kBuckets, "the work counters sit between the class counters and the end of the block");
 
