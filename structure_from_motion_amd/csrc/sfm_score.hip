@@ -1300,7 +1300,7 @@ int launch_matrix(const FilteredLaunch& a) {
     const unsigned grid_blocks = persistent ? (unsigned)std::min<int64_t>(item_blocks, resident_blocks) : (unsigned)item_blocks;
     // (the pops of a round that share one execution-mask region: sfm_score_matrix.h, matrix_item's MASK_GROUP)
     const auto scoring_kernel = a.batch > 1 ? score_sed_matrix_kernel<false, SFM_MATRIX_MASK_GROUP_BATCH, false>
-                                : wide_waves ? score_sed_matrix_kernel<false, SFM_MATRIX_MASK_GROUP_SINGLE, true>
+                                : wide_waves ? score_sed_matrix_kernel<false, SFM_MATRIX_MASK_GROUP_WIDE, true>
                                              : score_sed_matrix_kernel<false, SFM_MATRIX_MASK_GROUP_SINGLE, false>;
     hipLaunchKernelGGL(scoring_kernel, dim3(grid_blocks), dim3(256), 0, a.st, a.corr, hyp_table, table, a.n,
                        a.E, a.h_count, a.thr, order_arg, a.cnt, a.s1, a.s2, a.units, a.chunks_per_unit, split, fix,

@@ -87,6 +87,9 @@
 #ifndef SFM_MATRIX_MASK_GROUP_SINGLE
 #define SFM_MATRIX_MASK_GROUP_SINGLE 4   // pops of an exact-tier round that share one execution-mask region, launches of one pair (0: no masking; A/B builds)
 #endif
+#ifndef SFM_MATRIX_MASK_GROUP_WIDE
+#define SFM_MATRIX_MASK_GROUP_WIDE 2     // ... launches of one pair with wide waves (-0.2 ... -0.9 % against 4 at 60 000 ... 250 000 hypotheses)
+#endif
 #ifndef SFM_MATRIX_MASK_GROUP_BATCH
 #define SFM_MATRIX_MASK_GROUP_BATCH 2    // ... launches over a batch of pairs
 #endif
@@ -125,7 +128,7 @@ __device__ unsigned long long g_matrix_stamps[10 * 65536];   // begin, operands 
 constexpr bool kWideWaves = SFM_MATRIX_WIDE != 0;   // the launcher may pick the kernel with wide waves (score_sed_matrix_kernel<.., .., true>)
 constexpr int kWideOcc = 3;
 #ifndef SFM_MATRIX_WIDE_MIN_HYPOTHESES
-#define SFM_MATRIX_WIDE_MIN_HYPOTHESES 49152   // ... for one pair with at least this many hypotheses, in cost order (40 000: +6 ... +10 %, 60 000: -7 %)
+#define SFM_MATRIX_WIDE_MIN_HYPOTHESES 8192    // ... for one pair with at least this many hypotheses, in cost order (measured down to 200 000 x 10 000: -4 %)
 #endif
 #ifndef SFM_MATRIX_WIDE_FROM
 #define SFM_MATRIX_WIDE_FROM 4096              // entries of the heaviest-first order that stay in waves of 32 (a multiple of 128: whole blocks)

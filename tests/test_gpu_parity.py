@@ -1475,6 +1475,29 @@ def test_matrix_score_ranges_and_order(dev, split, order):
                                           b.view(np.int64) if b.dtype == np.float64 else b)
 
 
+@pytest.mark.parametrize("n,h", [(8200, 8191), (8200, 8192), (8200, 8193), (9000, 12345), (8192, 20001), (16000, 40000)])
+@pytest.mark.parametrize("split,persistent", [(-1, 0), (3, 0), (8, 0), (8, 1), (16, 1)])
+def test_matrix_score_wide_waves(dev, n, h, split, persistent):
+    """One pair of 8192 hypotheses and more, in cost order: the entries of the order behind the heaviest classes go in waves of 64
+    hypotheses (two operand groups per step, the reject words exchanged between the lane halves; the boundary is the first class
+    boundary at or behind entry 4096, written by the sort) — around the threshold, with hypothesis counts that leave ragged last
+    waves of both kinds, cut into ranges, with persistent waves: counts equal to the all-fp64 kernel's, sums to summation order,
+    the same bits when repeated, and the same counts as the launch without the order (waves of 32 throughout)."""
+    _, _, _, corr = scene(n)
+    S = orc.philox_sample_table(41, 3, h, n)
+    E = dev.fit_eight_point(dev.to_device(corr.reshape(1, n, 4)), dev.to_device(S.reshape(1, h, 8), torch.int32))[0].cpu().numpy().reshape(h, 3, 3)
+    options = _options(kernel="matrix", split=split, persistent=persistent)
+    for thr in (1.5e-6, 2e-4):
+        exact, filt = _score_both(dev, corr, E, S, thr, options)
+        _assert_same_scores(exact, filt)
+        _, again = _score_both(dev, corr, E, S, thr, options)
+        for a, b in zip(filt, again):
+            np.testing.assert_array_equal(a.view(np.int64) if a.dtype == np.float64 else a,
+                                          b.view(np.int64) if b.dtype == np.float64 else b)
+        _, plain = _score_both(dev, corr, E, S, thr, _options(kernel="matrix", split=split, persistent=persistent, order=0))
+        np.testing.assert_array_equal(filt[0], plain[0])
+
+
 @pytest.mark.parametrize("split", [-1, 1, 3, 8, 16])
 def test_matrix_score_persistent_waves(dev, split):
     """sfm_score_options.persistent = 1: the grid is what the chip holds and every wave takes (group of 32 hypotheses, range)
