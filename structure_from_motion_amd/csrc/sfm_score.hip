@@ -1252,10 +1252,15 @@ int launch_matrix(const FilteredLaunch& a) {
     const bool persistent = a.batch == 1 && a.persistent;
     // one pair, in cost order, many hypotheses: waves of 64 hypotheses behind the heaviest entries of the order (the kernel's
     // WIDE_WAVES); everything else — batches, unordered launches, fewer hypotheses — waves of 32
-    const bool wide_waves = kWideWaves && a.batch == 1 && a.use_order && a.h_count >= SFM_MATRIX_WIDE_MIN_HYPOTHESES;
-    // (where the wide waves begin is decided on the device — the sort leaves it in buckets[kWideFromWord] —, anywhere from 0 to
-    // kWideFromMax: the grid covers kWideFromMax entries in waves of 32 and all entries in waves of 64; waves without entries return)
-    const int64_t waves = wide_waves ? kWideFromMax / kHyps + (a.h_count + 2 * kHyps - 1) / (2 * kHyps) : (a.h_count + kHyps - 1) / kHyps;
+    const bool wide_waves = kWideWaves && a.use_order &&
+                            a.h_count >= (a.batch == 1 ? SFM_MATRIX_WIDE_MIN_HYPOTHESES : SFM_MATRIX_WIDE_MIN_HYPOTHESES_BATCH);
+    // entries of a pair's order that stay in waves of 32 at least — one pair: SFM_MATRIX_WIDE_FROM; a pair of a batch: an eighth
+    // of its hypotheses, in whole blocks — and at most (four times that)
+    const int wide_from_min = a.batch == 1 ? SFM_MATRIX_WIDE_FROM : std::max(128, (int)(a.h_count / 8 / 128 * 128));
+    const int wide_from_max = 4 * wide_from_min;
+    // (where the wide waves begin is decided on the device — the sort leaves it in the pair's buckets[kWideFromWord] —, anywhere from
+    // 0 to wide_from_max: the grid covers wide_from_max entries in waves of 32 and all entries in waves of 64; waves without entries return)
+    const int64_t waves = wide_waves ? wide_from_max / kHyps + (a.h_count + 2 * kHyps - 1) / (2 * kHyps) : (a.h_count + kHyps - 1) / kHyps;
     const unsigned blocks = grid_for(waves, 256 / kWave);
     const unsigned blocks_of_32 = grid_for((a.h_count + kHyps - 1) / kHyps, 256 / kWave);   // the cost pre-pass: waves of 32 always
     const unsigned resident_blocks = (unsigned)compute_units() * (unsigned)(wide_waves ? kWideOcc : SFM_MATRIX_OCC);
@@ -1279,16 +1284,22 @@ int launch_matrix(const FilteredLaunch& a) {
         const int e_units = record != nullptr ? (a.batch == 1 ? std::max(1, a.units / SFM_MATRIX_RECORD_RANGES_PER_WAVE) : 1)
                                               : (a.batch == 1 && e_steps >= 128 ? 4 : 1);
         // (the ranges of the pre-pass add into `cnt`: zeroed by matrix_setup_kernel)
-        const unsigned flat_of_32 = a.batch > 1 ? flat : blocks_of_32;   // (batches never take wide waves: blocks == blocks_of_32)
-        hipLaunchKernelGGL(score_sed_matrix_kernel<true>, dim3(flat_of_32 * (unsigned)e_units), dim3(256), 0, a.st, a.corr, hyp_table, table,
+#ifndef SFM_MATRIX_WIDE_PREPASS
+#define SFM_MATRIX_WIDE_PREPASS 0   // measurement build: the cost pre-pass of one pair in waves of 64 hypotheses as well
+#endif
+        const bool wide_prepass = SFM_MATRIX_WIDE_PREPASS && a.batch == 1;
+        const unsigned blocks_prepass = wide_prepass ? grid_for((a.h_count + 2 * kHyps - 1) / (2 * kHyps), 256 / kWave) : blocks_of_32;
+        const unsigned flat_of_32 = a.batch > 1 ? blocks_of_32 * (unsigned)((a.batch + 7) / 8 * 8) : blocks_prepass;
+        const auto prepass_kernel = wide_prepass ? score_sed_matrix_kernel<true, 0, true> : score_sed_matrix_kernel<true, 0, false>;
+        hipLaunchKernelGGL(prepass_kernel, dim3(flat_of_32 * (unsigned)e_units), dim3(256), 0, a.st, a.corr, hyp_table, table,
                            a.n, a.E, a.h_count, a.thr, (const int32_t*)nullptr, a.cnt, a.s1, a.s2, e_units,
                            record != nullptr ? kReplaySteps : e_steps / e_units,
-                           (unsigned char*)nullptr, (const unsigned char*)nullptr, (int)a.batch, blocks_per_pair * e_units, (int32_t*)nullptr,
-                           record, a.chunks_per_unit, a.units, (const int32_t*)nullptr);
+                           (unsigned char*)nullptr, (const unsigned char*)nullptr, (int)a.batch, (a.batch > 1 ? (int)blocks_of_32 : 0) * e_units, (int32_t*)nullptr,
+                           record, a.chunks_per_unit, a.units, (const int32_t*)nullptr, 0);
         const dim3 per_hyp(grid_for(a.h_count, 256), pairs);
         hipLaunchKernelGGL(score_class_count_kernel, per_hyp, dim3(256), 0, a.st, a.cnt, a.h_count, a.buckets);
         hipLaunchKernelGGL(score_class_scan_scatter_kernel, per_hyp, dim3(256), 0, a.st, a.cnt, a.h_count, a.buckets, a.order,
-                           wide_waves ? SFM_MATRIX_WIDE_FROM : 0, kWideFromMax);
+                           wide_waves ? wide_from_min : 0, wide_from_max);
         const int rc = check_launch("score order kernels");
         if (rc != SFM_OK) return rc;
         order_arg = a.order;
@@ -1299,13 +1310,13 @@ int launch_matrix(const FilteredLaunch& a) {
     const int64_t item_blocks = (int64_t)flat * a.units;
     const unsigned grid_blocks = persistent ? (unsigned)std::min<int64_t>(item_blocks, resident_blocks) : (unsigned)item_blocks;
     // (the pops of a round that share one execution-mask region: sfm_score_matrix.h, matrix_item's MASK_GROUP)
-    const auto scoring_kernel = a.batch > 1 ? score_sed_matrix_kernel<false, SFM_MATRIX_MASK_GROUP_BATCH, false>
-                                : wide_waves ? score_sed_matrix_kernel<false, SFM_MATRIX_MASK_GROUP_WIDE, true>
-                                             : score_sed_matrix_kernel<false, SFM_MATRIX_MASK_GROUP_SINGLE, false>;
+    const auto scoring_kernel = wide_waves ? score_sed_matrix_kernel<false, SFM_MATRIX_MASK_GROUP_WIDE, true>
+                                : a.batch > 1 ? score_sed_matrix_kernel<false, SFM_MATRIX_MASK_GROUP_BATCH, false>
+                                              : score_sed_matrix_kernel<false, SFM_MATRIX_MASK_GROUP_SINGLE, false>;
     hipLaunchKernelGGL(scoring_kernel, dim3(grid_blocks), dim3(256), 0, a.st, a.corr, hyp_table, table, a.n,
                        a.E, a.h_count, a.thr, order_arg, a.cnt, a.s1, a.s2, a.units, a.chunks_per_unit, split, fix,
                        (int)a.batch, blocks_per_pair * a.units, persistent ? a.buckets + kTicketWords : (int32_t*)nullptr, record, 0, 0,
-                       wide_waves ? a.buckets + kWideFromWord : (const int32_t*)nullptr);
+                       wide_waves ? a.buckets + kWideFromWord : (const int32_t*)nullptr, wide_from_max);
     if (a.event_after) (void)hipEventRecord(a.event_after, a.st);
     if (a.deferred != nullptr) {   // a fused pass folds the ranges inside its selection launch
         *a.deferred = sfmhost::LargeScore{a.units, split, fix};

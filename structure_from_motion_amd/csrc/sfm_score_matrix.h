@@ -28,6 +28,13 @@
 // nearly full (looked at once per group of steps, outside the hot loop) and go on until every queue is down to kLow, so with
 // hypotheses of similar load in a wave (the heaviest-first order is dealt row-major here) nearly all lanes are busy in every round.
 //
+// Waves of 64 hypotheses (round 5; one pair in cost order from 8192 hypotheses on, behind the heaviest classes): the three matrix
+// instructions of a step run twice — operand rows of columns 0-31, then of columns 32-63 — and one v_permlane32_swap of the two
+// reject words gives every lane both halves of ONE hypothesis (lower lanes: first group, upper lanes: second).  Everything
+// behind tier 1 is unchanged — one queue, one E, one (count, sum, sum of squares) per lane; entries carry 2 x step + half — and
+// the operands of a step are loaded once for 2048 evaluations: that stream (3 KiB per wave and step) keeps a CU's vector L1
+// ~90 % busy in waves of 32.  See WIDE_WAVES at the kernel.
+//
 // The cost pre-pass (the <true> instantiation: tier 1 alone, survivors counted) scans, for a launch of eight ranges, the first 16
 // steps of each range and leaves its reject words for the scoring waves, which replay them instead of computing those steps
 // again (MatrixPair::record).
@@ -129,6 +136,9 @@ constexpr bool kWideWaves = SFM_MATRIX_WIDE != 0;   // the launcher may pick the
 constexpr int kWideOcc = 3;
 #ifndef SFM_MATRIX_WIDE_MIN_HYPOTHESES
 #define SFM_MATRIX_WIDE_MIN_HYPOTHESES 8192    // ... for one pair with at least this many hypotheses, in cost order (measured down to 200 000 x 10 000: -4 %)
+#endif
+#ifndef SFM_MATRIX_WIDE_MIN_HYPOTHESES_BATCH
+#define SFM_MATRIX_WIDE_MIN_HYPOTHESES_BATCH (1 << 30)   // ... per pair of a batch (measurement builds: 1024)
 #endif
 #ifndef SFM_MATRIX_WIDE_FROM
 #define SFM_MATRIX_WIDE_FROM 4096              // entries of the heaviest-first order that stay in waves of 32 (a multiple of 128: whole blocks)
@@ -861,7 +871,7 @@ __global__ __launch_bounds__(256, WIDE_WAVES ? kWideOcc : SFM_MATRIX_OCC) void s
     const double* __restrict__ E, int h_count, double thr, const int32_t* __restrict__ order, int32_t* __restrict__ cnt,
     double* __restrict__ s1, double* __restrict__ s2, int units, int steps_per_unit, unsigned char* __restrict__ split,
     const unsigned char* __restrict__ fix, int batch, int blocks_per_pair, int32_t* __restrict__ tickets,
-    uint16_t* __restrict__ record, int range_stride, int record_ranges, const int32_t* __restrict__ wide_word) {
+    uint16_t* __restrict__ record, int range_stride, int record_ranges, const int32_t* __restrict__ wide_word, int wide_max) {
     __shared__ alignas(kCap * kWave * 4) uint32_t queues[ESTIMATE ? 1 : 256 / kWave][ESTIMATE ? 1 : kCap][kWave];   // (a wave's ring: 8 KiB, aligned: ring_slot() in matrix_item)
     const int lane = threadIdx.x & (kWave - 1);
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
@@ -869,10 +879,11 @@ __global__ __launch_bounds__(256, WIDE_WAVES ? kWideOcc : SFM_MATRIX_OCC) void s
     MatrixPair a{pts, hyp_table, table, E, order, cnt, s1, s2, split, fix, record, range_stride};
     // wave index of the launch -> first entry of the order it takes, and the kind of wave: indices below narrow_waves are waves of
     // 32 over the entries [0, wide_from), the rest waves of 64 behind them
-    // (the launch's wave indices [0, kWideFromMax / 32) are waves of 32 — those at or behind wide_from have nothing to do —, the rest
-    // waves of 64 from wide_from on)
-    const int wide_from = WIDE_WAVES ? min(*wide_word, h_count) : h_count;   // (wave-uniform: a scalar load)
-    constexpr int narrow_waves = kWideFromMax / kHyps;
+    // (a pair's wave indices [0, wide_max / 32) are waves of 32 — those at or behind wide_from have nothing to do —, the rest waves
+    // of 64 from wide_from on; wide_from: what the sort left in the pair's word, anywhere in [0, wide_max])
+    // (wide_word == nullptr: every wave wide — the cost pre-pass of a measurement build)
+    int wide_from = WIDE_WAVES ? (wide_word != nullptr ? min(*wide_word, h_count) : 0) : h_count;   // (wave-uniform: a scalar load; a batch: set again below, per pair)
+    const int narrow_waves = wide_max / kHyps;
     auto item = [&](int wave, int unit, unsigned item_id, int ranges) __attribute__((always_inline)) {
         if (WIDE_WAVES && wave >= narrow_waves)
             matrix_item<ESTIMATE, MASK_GROUP, true>(a, n, h_count, thr, ranges, steps_per_unit, wide_from + (wave - narrow_waves) * 2 * kHyps, h_count,
@@ -933,6 +944,7 @@ __global__ __launch_bounds__(256, WIDE_WAVES ? kWideOcc : SFM_MATRIX_OCC) void s
         a.s2 += pair * (int64_t)h_count;
         if (a.fix != nullptr) a.fix += pair * sfmws::matrix_fix_bytes(h_count);
         if (a.record != nullptr) a.record += pair * (sfmws::matrix_record_bytes(h_count) / 2);
+        if (WIDE_WAVES && wide_word != nullptr) wide_from = min(wide_word[pair * sfmws::kBuckets], h_count);
     } else if (units > 1) {   // `units` consecutive blocks take the same hypotheses over one range of the points each
         unit = block_of_range % units;
         block_of_range /= units;
