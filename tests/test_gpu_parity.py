@@ -1498,6 +1498,39 @@ def test_matrix_score_wide_waves(dev, n, h, split, persistent):
         np.testing.assert_array_equal(filt[0], plain[0])
 
 
+def test_matrix_score_wide_waves_class_boundaries(dev):
+    """Where the waves of 64 begin is a class boundary of the cost order: all hypotheses in ONE class (no boundary in
+    [4096, 16384]: every wave wide from entry 0), a heavy class of exactly 4096 (boundary at the lower end), one of 16 384 (at the
+    upper end) and one of 16 385 (just beyond: all wide), NaN hypotheses (the class without survivors, last in the order) — counts
+    equal to the all-fp64 kernel's, sums to summation order, repeated launches bit-identical."""
+    n = 8300
+    _, _, _, corr = scene(n)
+    S_all = orc.philox_sample_table(43, 0, 64, n)
+    E_all = dev.fit_eight_point(dev.to_device(corr.reshape(1, n, 4)), dev.to_device(S_all.reshape(1, 64, 8), torch.int32))[0].cpu().numpy().reshape(64, 3, 3)
+    sed = np.stack([orc.sed_values(E_all[k], corr) for k in range(64)])
+    dense = int(np.argmax((sed <= 1.5e-6).sum(axis=1)))          # a model of the scene: thousands of inliers
+    sparse = int(np.argmin((sed <= 1.5e-6).sum(axis=1)))         # a stray one: a handful
+    options = _options(kernel="matrix")
+
+    def run(picks):
+        E = E_all[picks]
+        S = S_all[picks]
+        exact, filt = _score_both(dev, corr, E, S, 1.5e-6, options)
+        _assert_same_scores(exact, filt)
+        _, again = _score_both(dev, corr, E, S, 1.5e-6, options)
+        for a, b in zip(filt, again):
+            np.testing.assert_array_equal(a.view(np.int64) if a.dtype == np.float64 else a, b.view(np.int64) if b.dtype == np.float64 else b)
+
+    run(np.full(9000, dense))                                                         # one class
+    for heavy in (4096, 16384, 16385):
+        run(np.concatenate([np.full(heavy, dense), np.full(20000 - heavy, sparse)]))  # two classes, the boundary at `heavy`
+    mixed = np.concatenate([np.full(3000, dense), np.arange(64).repeat(150), np.full(2500, sparse)])
+    E = E_all[mixed].copy()
+    E[::7] = np.nan                                                                   # hypotheses that never count anything
+    exact, filt = _score_both(dev, corr, E, S_all[mixed], 1.5e-6, options)
+    _assert_same_scores(exact, filt)
+
+
 @pytest.mark.parametrize("split", [-1, 1, 3, 8, 16])
 def test_matrix_score_persistent_waves(dev, split):
     """sfm_score_options.persistent = 1: the grid is what the chip holds and every wave takes (group of 32 hypotheses, range)
