@@ -1627,7 +1627,7 @@ def test_matrix_kernel_beyond_two_million_points(dev):
 
 
 def test_score_kernel_size_rule_picks_the_matrix_kernel(dev):
-    """Left to itself (options.kernel = auto) a single-pair launch of at least 8192 points, 4096 hypotheses and 5 x 10^8
+    """Left to itself (options.kernel = auto) a single-pair launch of at least 8192 points, 4096 hypotheses and 3.5 x 10^8
     evaluations runs the matrix-pipe kernel: same counts as the all-fp64 kernel, and as the VALU-filter kernel forced by
     its option."""
     n, h = 8200, 62_000
