@@ -125,7 +125,7 @@ int sfm_hartley_normalize(const double* coords, int64_t n, double* out, void* st
  * processed longest-first; identical counts and inlier decisions — the exact tier decides with sed.py's own operation sequence
  * wherever a cheaper form of the same fp64 value is not clear of the threshold by 1e-13 — sums in a fixed order, each summand
  * within 1.2e-15 of the all-fp64 kernel's): the fp32 VALU filter, and for a
- * single pair of at least 8192 points, 4096 hypotheses and 3.5e8 evaluations (at most 4 194 304 points) the kernel with the
+ * single pair of at least 4000 points, 2048 hypotheses and 3.5e8 evaluations (at most 4 194 304 points) the kernel with the
  * filter on the fp16 / bf16 matrix pipe and a lane-per-hypothesis exact tier (sfm_score_options.kernel forces it on / off).
  * Large single-pair launches are cut into ranges of the points whose partial results are added in range order.  NULL selects
  * the all-fp64 kernel.

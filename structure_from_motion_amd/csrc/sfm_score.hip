@@ -1083,7 +1083,9 @@ bool valid_options(const sfm_score_options& o) {
 bool use_matrix_kernel(int64_t n, int64_t h_count, int64_t batch, const sfm_score_options& opt) {
     const int matrix_env = opt.kernel == SFM_SCORE_KERNEL_MATRIX ? 1 : opt.kernel == SFM_SCORE_KERNEL_FILTERED ? 0 : -1;
     // By itself when the launch is large enough to fill the chip with its waves of 32 hypotheses over ranges of the points: at
-    // least 8192 points, 4096 hypotheses and 3.5 x 10^8 evaluations (5 x 10^8 until the wide waves of round 5 — whole pass, default
+    // least 4000 points, 2048 hypotheses and 3.5 x 10^8 evaluations (8192, 4096 and 5 x 10^8 until the wide waves of round 5; below
+    // them now: 6000 x 100 000 481 vs 251 us, 5000 x 80 000 382 vs 245, 4000 x 200 000 469 vs 351, 100 000 x 3600 526 vs 489,
+    // 200 000 x 2048 1000 vs 903; 3000 x 150 000 312 vs 335: the floor on the points — whole pass, default
     // route against the fused large pass with this kernel: 10 000 x 40 000 268 vs 227 us, 12 000 x 30 000 268 vs 222, 20 000 x 20 000
     // 275 vs 226, 30 000 x 15 000 321 vs 235, 40 000 x 10 000 337 vs 248; 25 000 x 12 000 219 vs 225 and 16 000 x 16 000 208 vs 214:
     // even; 8192 x 25 000 150 vs 208.  Round 3, same box, VALU vs matrix kernel: 50 000 x 100 000 2.49 vs 1.49
@@ -1095,7 +1097,7 @@ bool use_matrix_kernel(int64_t n, int64_t h_count, int64_t batch, const sfm_scor
     const int64_t waves32_all = (h_count + matrixscore::kHyps - 1) / matrixscore::kHyps * batch;
     const bool matrix_fits = n <= matrixscore::kMaxPoints &&
                              sfmhost::grid_fits((int64_t)grid_for((h_count + 31) / 32, 256 / kWave) * ((batch + 7) / 8 * 8), 1, 256);
-    const bool matrix_pays = batch == 1 ? (n >= 8192 && h_count >= 4096 && (double)n * (double)h_count >= 3.5e8)
+    const bool matrix_pays = batch == 1 ? (n >= 4000 && h_count >= 2048 && (double)n * (double)h_count >= 3.5e8)
                                         : (n >= 8192 && h_count >= 1024 && waves32_all >= 6144 &&
                                            (double)n * (double)h_count * (double)batch >= 5e8);
     return matrix_fits && (matrix_env > 0 || (matrix_env < 0 && matrix_pays));

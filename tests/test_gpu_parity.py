@@ -985,6 +985,34 @@ def test_fused_batch_and_large_pass_random_sizes(dev, monkeypatch):
         dev.set_default_score_options(saved)
 
 
+@pytest.mark.parametrize("n,h", [(4_000, 87_500), (4_100, 90_000), (7_000, 50_001), (171_000, 2_048), (90_000, 4_000)])
+def test_large_pass_at_the_floors_of_the_size_rule(dev, n, h):
+    """The size rule of the matrix-pipe kernel (4000 points, 2048 hypotheses, 3.5 x 10^8 evaluations since round 5) at its floors:
+    the pass the default route takes there — fused, matrix-pipe kernel, wide waves where the hypotheses are many — against the
+    separate calls with the all-fp64 scoring kernel: same samples and E, same counts, same winner and mask, sums to summation order."""
+    from structure_from_motion_amd import _native
+    from structure_from_motion_amd._native import AGG_RMS
+
+    assert _native.load().sfm_score_kernel_choice(n, h, 1) == 2 and dev.large_pass_eligible(1, n, h)
+    _, _, _, corr = scene(n, seed=14)
+    corr_d = dev.to_device(corr).reshape(1, n, 4)
+    thr, min_extra = 1.5e-6, 10
+    a, b = dev.RansacWorkspace(1, n, h), dev.RansacWorkspace(1, n, h)
+    a.run(corr_d, thr, min_extra, AGG_RMS, philox=(9, 100, 1))
+    dev.sample_fit_philox(corr_d, 9, 100, b.S, b.E, b.flags, 1)
+    b.cnt, b.s1, b.s2 = dev.score_sed(corr_d, b.E, b.S, thr, exact_only=True)
+    dev.select_best(b.cnt, b.s1, b.s2, b.flags, min_extra, AGG_RMS, 0, b.result)
+    dev.inlier_mask(corr_d, b.E, b.S, b.result, thr, b.mask)
+    for key in ("S", "E", "flags", "cnt", "mask"):
+        np.testing.assert_array_equal(getattr(a, key).cpu().numpy(), getattr(b, key).cpu().numpy(), err_msg=key)
+    ra, rb = dev.read_select(a.result)[0], dev.read_select(b.result)[0]
+    assert (ra.best_h, ra.best_cnt, ra.n_flagged) == (rb.best_h, rb.best_cnt, rb.n_flagged) and ra.best_h >= 0
+    for key in ("s1", "s2"):
+        x, y = getattr(a, key).cpu().numpy(), getattr(b, key).cpu().numpy()
+        both_nan = np.isnan(x) & np.isnan(y)
+        np.testing.assert_allclose(x[~both_nan], y[~both_nan], rtol=1e-13, atol=0)
+
+
 @pytest.mark.parametrize("n,h", [(9_000, 20_000), (20_000, 3_000), (600, 900)])
 def test_large_pass_entry_on_sizes_of_the_other_kernels(dev, n, h):
     """sfm_ransac_pass_large takes any size: where sfm_score_sed would not pick the matrix-pipe kernel its own launches run,
@@ -1627,7 +1655,7 @@ def test_matrix_kernel_beyond_two_million_points(dev):
 
 
 def test_score_kernel_size_rule_picks_the_matrix_kernel(dev):
-    """Left to itself (options.kernel = auto) a single-pair launch of at least 8192 points, 4096 hypotheses and 3.5 x 10^8
+    """Left to itself (options.kernel = auto) a single-pair launch of at least 4000 points, 2048 hypotheses and 3.5 x 10^8
     evaluations runs the matrix-pipe kernel: same counts as the all-fp64 kernel, and as the VALU-filter kernel forced by
     its option."""
     n, h = 8200, 62_000

@@ -69,7 +69,7 @@ def test_score_workspace_holds_every_region(native_lib):
 
 
 def test_score_kernel_choice_rule(native_lib):
-    """sfm_score_kernel_choice_ex: 2 = the matrix-pipe kernel — single pairs from 8192 points x 4096 hypotheses x 3.5e8 evaluations,
+    """sfm_score_kernel_choice_ex: 2 = the matrix-pipe kernel — single pairs from 4000 points x 2048 hypotheses x 3.5e8 evaluations,
     batches from 8192 x 1024 per pair with 6144 waves and 5e8 evaluations over the batch, never beyond 4 M points per pair;
     options.kernel forces it on (where it applies) / off."""
     from structure_from_motion_amd import _native
@@ -81,7 +81,8 @@ def test_score_kernel_choice_rule(native_lib):
 
     assert choice(50_000, 100_000, 1) == 2 and choice(50_000, 125_000, 1) == 2 and choice(50_000, 10_000, 1) == 2
     assert choice(20_000, 20_000, 1) == 2 and choice(25_000, 12_000, 1) == 1 and choice(8_192, 42_725, 1) == 2 and choice(8_192, 42_724, 1) == 1
-    assert choice(5_000, 10_000, 1) == 1 and choice(16_000, 16_000, 1) == 1 and choice(8_191, 1_000_000, 1) == 1
+    assert choice(5_000, 10_000, 1) == 1 and choice(16_000, 16_000, 1) == 1 and choice(3_999, 1_000_000, 1) == 1
+    assert choice(4_000, 87_500, 1) == 2 and choice(4_000, 87_499, 1) == 1 and choice(200_000, 2_048, 1) == 2 and choice(200_000, 2_047, 1) == 1
     assert choice(70_000, 100_000, 1) == 2 and choice(5_000_000, 100_000, 1) == 1
     assert choice(10_000, 2_000, 256) == 2 and choice(10_000, 2_000, 16) == 1 and choice(4_000, 2_000, 256) == 1
     assert choice(50_000, 100_000, 1, valu) == 1
